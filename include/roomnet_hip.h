@@ -1,0 +1,178 @@
+/*
+ * roomnet_hip.h -- C ABI of libroomnet_hip.so, the MI355X (gfx950) implementation
+ * of RoomNet's forward-pass inference path.
+ *
+ * The reference (ironhide23586/RoomNet) has no native / FFI interface: its
+ * boundary is the Python API of network.RoomNet, which hands the whole forward
+ * pass to TensorFlow through tf.Session.run.  This library replaces exactly
+ * that hand-off.  Each entry point names the reference interface it replaces
+ * (file:line into the reference tree); INTEGRATION.md shows the ctypes binding
+ * a maintainer of the reference would add to network.py.
+ *
+ * Conventions
+ *   - plain C types only; the caller owns every buffer it passes in; the
+ *     library owns its device memory, stream(s), events and packed weights.
+ *   - every function returning int returns RN_OK (0) or a negative RN_E_* code;
+ *     rn_last_error() returns a thread-local message for the last failure.
+ *   - a handle is bound to one device and one stream; calls on one handle must
+ *     be serialised by the caller (the reference is single-threaded,
+ *     infer.py:79-82); distinct handles are independent.
+ *   - tensors are NHWC, C-contiguous.  Images are [n, S, S, 3].
+ */
+#ifndef ROOMNET_HIP_H
+#define ROOMNET_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#if defined(__GNUC__)
+#define RN_API __attribute__((visibility("default")))
+#else
+#define RN_API
+#endif
+
+#define RN_OK 0
+#define RN_E_INVALID (-1)   /* bad argument / unsupported graph                     */
+#define RN_E_HIP (-2)       /* a HIP runtime call failed (message has the details) */
+#define RN_E_NOMEM (-3)     /* host or device allocation failed                    */
+#define RN_E_STATE (-4)     /* call not valid in the handle's current state        */
+#define RN_E_RANGE (-5)     /* n exceeds max_batch, bad node id, buffer too small  */
+
+/* storage / MFMA input type of activations and conv weights.  Accumulation,
+ * ReLU6, pooling, BN, the residual resize-add and the dense head are always
+ * float32. */
+#define RN_DTYPE_F32 0      /* reference arithmetic type (TensorFlow float32)      */
+#define RN_DTYPE_BF16 1
+#define RN_DTYPE_F16 2
+
+/* rn_create flags */
+#define RN_FLAG_TAPS 1u     /* unfused per-node path; every graph node can be read
+                               back with rn_tap (float32 only)                     */
+
+#define RN_MAX_STAGES 16
+#define RN_MAX_DENSE 8
+#define RN_NAME_LEN 32
+
+typedef struct rn_handle rn_handle;
+
+/* One conv stage = conv3x3 VALID stride-1 no-bias -> ReLU6 -> [avg-pool k,s VALID]
+ * -> BN(inference) -> [ + legacy bilinear resize(output of skip_stage) -> BN ].
+ * Mirrors one depth step of conv_block (reference network.py:172-208). */
+typedef struct rn_conv_stage {
+    int32_t cin, cout;
+    int32_t pool_k, pool_s;   /* pool_k == 0: no pooling                            */
+    int32_t skip_stage;       /* index of the stage whose output is added, or -1    */
+    const float* kernel;      /* HWIO [3,3,cin,cout]         (convN/kernel)         */
+    const float* gamma;       /* BN after the pool, [cout]   (batch_normalization_N)*/
+    const float* beta;
+    const float* mean;
+    const float* variance;
+    const float* gamma2;      /* BN after the residual add, or NULL                 */
+    const float* beta2;
+    const float* mean2;
+    const float* variance2;
+} rn_conv_stage;
+
+/* One dense_block (reference network.py:210-223): x@W [+ bias] -> ReLU6 -> [BN] */
+typedef struct rn_dense_layer {
+    int32_t nin, nout;
+    const float* kernel;      /* [nin, nout]                                        */
+    const float* bias;        /* [nout] or NULL                                     */
+    const float* gamma;       /* BN params or NULL (all four NULL together)         */
+    const float* beta;
+    const float* mean;
+    const float* variance;
+} rn_dense_layer;
+
+/* The restored model: what RoomNet.__init__ + RoomNet.load build and restore
+ * (reference network.py:21-48, :105-126).  Pointers are host memory and are
+ * only read during rn_create. */
+typedef struct rn_weights {
+    int32_t im_side;          /* RoomNet(im_side=...)                               */
+    int32_t num_classes;      /* RoomNet(num_classes=...)                           */
+    int32_t n_stages;
+    int32_t n_dense;
+    float bn_epsilon;         /* tf.layers.batch_normalization default 1e-3         */
+    const rn_conv_stage* stages;
+    const rn_dense_layer* dense;
+} rn_weights;
+
+/* per-call device timing of the last rn_forward_* (HIP events on the handle's stream) */
+typedef struct rn_stage_ms {
+    int32_t n_stages;                 /* conv stages timed                          */
+    float preprocess_ms;              /* uint8 -> float (only when it is a separate launch) */
+    float stage_ms[RN_MAX_STAGES];    /* one fused launch (or launch group) per stage */
+    float head_ms;                    /* flatten + dense blocks + softmax + argmax  */
+    float total_ms;                   /* first launch -> last launch                */
+} rn_stage_ms;
+
+typedef struct rn_node_info {
+    char name[RN_NAME_LEN];           /* "s3.conv", "s3.pool", "s3.bn", "s3.add", "s3.bn2", "d0.mm", ... */
+    int32_t h, w, c;                  /* per-image shape (h = w = 1 for head nodes) */
+} rn_node_info;
+
+/* ---- lifetime ------------------------------------------------------------
+ * rn_create replaces RoomNet.__init__(optimized_inference=True) + RoomNet.init()
+ * + RoomNet.load(path) (reference network.py:21-48, :87-91, :105-126): it builds
+ * the execution plan for `w`, packs/uploads the weights and sizes the workspace
+ * for up to max_batch images per call. */
+RN_API int rn_create(const rn_weights* w, int device, int dtype, int max_batch, unsigned flags, rn_handle** out);
+RN_API void rn_destroy(rn_handle* h);
+RN_API const char* rn_last_error(void);
+RN_API int rn_device_count(void);
+RN_API const char* rn_version(void);
+
+/* ---- forward pass ----------------------------------------------------------
+ * rn_forward_u8 replaces RoomNet.infer(im_batch) (reference network.py:128-135):
+ * BGR uint8 [n,S,S,3] -> channel flip + ((x/255.)*2)-1 (float64 semantics, then
+ * float32) -> graph -> (argmax int64 [n], softmax float32 [n,num_classes]).
+ * Host buffers; blocks until the results are in probs/ids. */
+RN_API int rn_forward_u8(rn_handle* h, const uint8_t* bgr_nhwc, int n, float* probs, int64_t* ids);
+
+/* rn_forward_f32 replaces sess.run(outs_final, {x_tensor: im}) (reference
+ * network.py:133/:155) for an already pre-processed RGB float32 batch in [-1,1]. */
+RN_API int rn_forward_f32(rn_handle* h, const float* rgb_nhwc, int n, float* probs, int64_t* ids);
+
+/* Device-resident variants: all pointers are device memory on the handle's
+ * device; the call only enqueues work on the handle's stream (asynchronous).
+ * Use rn_sync (or your own event on the stream) before reading the outputs. */
+RN_API int rn_forward_u8_device(rn_handle* h, const uint8_t* d_bgr_nhwc, int n, float* d_probs, int64_t* d_ids);
+RN_API int rn_forward_f32_device(rn_handle* h, const float* d_rgb_nhwc, int n, float* d_probs, int64_t* d_ids);
+RN_API int rn_sync(rn_handle* h);
+
+/* Run on a caller-provided hipStream_t (e.g. the framework's current stream)
+ * instead of the handle's own; NULL restores the handle's stream. */
+RN_API int rn_set_stream(rn_handle* h, void* hip_stream);
+
+/* ---- introspection -----------------------------------------------------------
+ * rn_tap copies graph node `node_id` of the last forward call to host float32
+ * (layout [n, h, w, c]); needs RN_FLAG_TAPS for conv/pool/add nodes, stage
+ * outputs ("sK.bn" / "sK.bn2") are always available.  This is the per-layer
+ * debug read-out the reference gets from self.layers (network.py:30, :207). */
+RN_API int rn_node_count(const rn_handle* h);
+RN_API int rn_node_info_get(const rn_handle* h, int node_id, rn_node_info* out);
+RN_API int rn_tap(rn_handle* h, int node_id, float* out, size_t cap_elems, size_t* n_elems);
+
+/* Enable/disable per-stage event timing (adds event records to every forward). */
+RN_API int rn_set_profiling(rn_handle* h, int enable);
+RN_API int rn_timing(rn_handle* h, rn_stage_ms* out);
+
+/* Name of the kernel that dominates the forward pass of this handle (for
+ * matching rocprofv3 rows) and the stage index it belongs to. */
+RN_API int rn_dominant_stage(const rn_handle* h);
+
+/* ---- simple device memory helpers (so a host language without a HIP binding
+ * can keep batches resident in HBM) ---------------------------------------- */
+RN_API int rn_device_malloc(rn_handle* h, size_t bytes, void** d_ptr);
+RN_API int rn_device_free(rn_handle* h, void* d_ptr);
+RN_API int rn_memcpy_h2d(rn_handle* h, void* d_dst, const void* src, size_t bytes);
+RN_API int rn_memcpy_d2h(rn_handle* h, void* dst, const void* d_src, size_t bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ROOMNET_HIP_H */

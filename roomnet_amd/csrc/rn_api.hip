@@ -1,0 +1,737 @@
+// Host side of libroomnet_hip.so: execution plan, weight upload, forward orchestration,
+// taps and timing.  See include/roomnet_hip.h for the contract of every entry point and
+// the reference interface (file:line) it replaces.
+#include "rn_internal.h"
+#include "rn_fused.h"
+
+#include <cmath>
+#include <cstring>
+#include <new>
+
+// ------------------------------------------------------------------------- errors
+static thread_local char g_err[512] = "";
+
+void rn_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char* rn_last_error(void) { return g_err; }
+extern "C" const char* rn_version(void) { return RN_VERSION_STRING; }
+
+extern "C" int rn_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+// ------------------------------------------------------------------------ helpers
+namespace {
+
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = false;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        ok = hipSetDevice(dev) == hipSuccess;
+    }
+    ~DeviceGuard() {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+};
+
+int dev_alloc(rn_handle* h, size_t bytes, void** out) {
+    void* p = nullptr;
+    if (bytes == 0) bytes = 16;
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e != hipSuccess) {
+        rn_set_error("hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e));
+        return RN_E_NOMEM;
+    }
+    h->allocs.push_back(p);
+    *out = p;
+    return RN_OK;
+}
+
+template <typename T>
+int upload(rn_handle* h, const T* src, size_t count, T** out) {
+    void* p = nullptr;
+    int rc = dev_alloc(h, count * sizeof(T), &p);
+    if (rc != RN_OK) return rc;
+    RN_HIP(hipMemcpy(p, src, count * sizeof(T), hipMemcpyHostToDevice));
+    *out = static_cast<T*>(p);
+    return RN_OK;
+}
+
+int upload_bn(rn_handle* h, int c, const float* gamma, const float* beta, const float* mean, const float* var,
+              float eps, BnDev* out) {
+    std::vector<float> inv(c);
+    for (int i = 0; i < c; ++i) inv[i] = (1.0f / sqrtf(var[i] + eps)) * gamma[i];
+    int rc;
+    if ((rc = upload(h, mean, c, &out->mean)) != RN_OK) return rc;
+    if ((rc = upload(h, inv.data(), c, &out->inv)) != RN_OK) return rc;
+    if ((rc = upload(h, beta, c, &out->beta)) != RN_OK) return rc;
+    return RN_OK;
+}
+
+// TF-1.13 compute_interpolation_weights, align_corners=False, no half-pixel centres
+int upload_resize_tab(rn_handle* h, int in_size, int out_size, ResizeTab* rt) {
+    std::vector<int32_t> lo(out_size), hi(out_size);
+    std::vector<float> lerp(out_size);
+    const float scale = static_cast<float>(in_size) / static_cast<float>(out_size);
+    for (int i = out_size - 1; i >= 0; --i) {
+        const float src = static_cast<float>(i) * scale;
+        lo[i] = static_cast<int32_t>(src);
+        hi[i] = lo[i] + 1 < in_size - 1 ? lo[i] + 1 : in_size - 1;
+        lerp[i] = src - static_cast<float>(lo[i]);
+    }
+    int rc;
+    if ((rc = upload(h, lo.data(), out_size, &rt->lo)) != RN_OK) return rc;
+    if ((rc = upload(h, hi.data(), out_size, &rt->hi)) != RN_OK) return rc;
+    if ((rc = upload(h, lerp.data(), out_size, &rt->lerp)) != RN_OK) return rc;
+    return RN_OK;
+}
+
+int add_node(rn_handle* h, const char* name, int hh, int ww, int cc) {
+    NodeBuf nb;
+    std::memset(&nb.info, 0, sizeof(nb.info));
+    std::snprintf(nb.info.name, RN_NAME_LEN, "%s", name);
+    nb.info.h = hh;
+    nb.info.w = ww;
+    nb.info.c = cc;
+    h->nodes.push_back(nb);
+    return static_cast<int>(h->nodes.size()) - 1;
+}
+
+size_t node_elems(const NodeBuf& nb) { return static_cast<size_t>(nb.info.h) * nb.info.w * nb.info.c; }
+
+size_t dtype_size(int dtype) { return dtype == RN_DTYPE_F32 ? 4 : 2; }
+
+bool fused_mode(const rn_handle* h) { return h->dtype != RN_DTYPE_F32; }
+
+int validate(const rn_weights* w, int dtype, int max_batch, unsigned flags) {
+    if (!w || !w->stages || !w->dense) {
+        rn_set_error("rn_create: null weights");
+        return RN_E_INVALID;
+    }
+    if (w->n_stages < 1 || w->n_stages > RN_MAX_STAGES || w->n_dense < 1 || w->n_dense > RN_MAX_DENSE) {
+        rn_set_error("rn_create: unsupported stage/dense count (%d/%d)", w->n_stages, w->n_dense);
+        return RN_E_INVALID;
+    }
+    if (w->im_side < 8 || w->num_classes < 1 || w->num_classes > 64) {
+        rn_set_error("rn_create: bad im_side %d / num_classes %d", w->im_side, w->num_classes);
+        return RN_E_INVALID;
+    }
+    if (dtype != RN_DTYPE_F32 && dtype != RN_DTYPE_BF16 && dtype != RN_DTYPE_F16) {
+        rn_set_error("rn_create: unknown dtype %d", dtype);
+        return RN_E_INVALID;
+    }
+    if ((flags & RN_FLAG_TAPS) && dtype != RN_DTYPE_F32) {
+        rn_set_error("rn_create: RN_FLAG_TAPS needs RN_DTYPE_F32 (the unfused per-node path)");
+        return RN_E_INVALID;
+    }
+    if (max_batch < 1) {
+        rn_set_error("rn_create: max_batch must be >= 1");
+        return RN_E_INVALID;
+    }
+    if (w->stages[0].cin != 3) {
+        rn_set_error("rn_create: first stage must take 3 input channels");
+        return RN_E_INVALID;
+    }
+    return RN_OK;
+}
+
+int build_plan(rn_handle* h, const rn_weights* w) {
+    int side = w->im_side, ch = 3, rc;
+    h->node_input = add_node(h, "input", side, side, 3);
+    char name[RN_NAME_LEN];
+    for (int i = 0; i < w->n_stages; ++i) {
+        const rn_conv_stage& s = w->stages[i];
+        if (s.cin != ch || s.cout < 1 || s.cout > 512 || !s.kernel || !s.gamma || !s.beta || !s.mean ||
+            !s.variance) {
+            rn_set_error("stage %d: inconsistent description (cin %d, expected %d)", i, s.cin, ch);
+            return RN_E_INVALID;
+        }
+        StagePlan p{};
+        p.cin = s.cin;
+        p.cout = s.cout;
+        p.in_side = side;
+        p.conv_side = side - 2;
+        p.pool_k = s.pool_k;
+        p.pool_s = s.pool_k ? s.pool_s : 1;
+        if (p.conv_side < 1 || (p.pool_k && (p.conv_side < p.pool_k || p.pool_s < 1))) {
+            rn_set_error("stage %d: im_side too small for this graph", i);
+            return RN_E_INVALID;
+        }
+        p.out_side = p.pool_k ? (p.conv_side - p.pool_k) / p.pool_s + 1 : p.conv_side;
+        p.skip_stage = s.skip_stage;
+        if (s.skip_stage >= 0) {
+            if (s.skip_stage >= i || h->stages[s.skip_stage].cout != s.cout || !s.gamma2 || !s.beta2 ||
+                !s.mean2 || !s.variance2) {
+                rn_set_error("stage %d: bad residual description", i);
+                return RN_E_INVALID;
+            }
+            p.skip_side = h->stages[s.skip_stage].out_side;
+        }
+        if ((rc = upload(h, s.kernel, static_cast<size_t>(9) * s.cin * s.cout, &p.w_f32)) != RN_OK) return rc;
+        if ((rc = upload_bn(h, s.cout, s.gamma, s.beta, s.mean, s.variance, w->bn_epsilon, &p.bn)) != RN_OK)
+            return rc;
+        if (s.skip_stage >= 0) {
+            if ((rc = upload_bn(h, s.cout, s.gamma2, s.beta2, s.mean2, s.variance2, w->bn_epsilon, &p.bn2)) !=
+                RN_OK)
+                return rc;
+            if ((rc = upload_resize_tab(h, p.skip_side, p.out_side, &p.rt)) != RN_OK) return rc;
+        }
+        std::snprintf(name, sizeof(name), "s%d.conv", i);
+        p.node_conv = add_node(h, name, p.conv_side, p.conv_side, p.cout);
+        if (p.pool_k) {
+            std::snprintf(name, sizeof(name), "s%d.pool", i);
+            p.node_pool = add_node(h, name, p.out_side, p.out_side, p.cout);
+        }
+        std::snprintf(name, sizeof(name), "s%d.bn", i);
+        p.node_bn = add_node(h, name, p.out_side, p.out_side, p.cout);
+        if (s.skip_stage >= 0) {
+            std::snprintf(name, sizeof(name), "s%d.add", i);
+            p.node_add = add_node(h, name, p.out_side, p.out_side, p.cout);
+            std::snprintf(name, sizeof(name), "s%d.bn2", i);
+            p.node_bn2 = add_node(h, name, p.out_side, p.out_side, p.cout);
+        }
+        h->stages.push_back(p);
+        side = p.out_side;
+        ch = p.cout;
+    }
+    const int flat_len = side * side * ch;
+    h->node_flat = add_node(h, "flat", 1, 1, flat_len);
+    int nin = flat_len;
+    for (int d = 0; d < w->n_dense; ++d) {
+        const rn_dense_layer& l = w->dense[d];
+        if (l.nin != nin || l.nout < 1 || l.nout > 64 || !l.kernel) {
+            rn_set_error("dense %d: expected %d inputs, got %d (is the checkpoint for this im_side?)", d, nin,
+                         l.nin);
+            return RN_E_INVALID;
+        }
+        DensePlan p{};
+        p.nin = l.nin;
+        p.nout = l.nout;
+        if ((rc = upload(h, l.kernel, static_cast<size_t>(l.nin) * l.nout, &p.w)) != RN_OK) return rc;
+        if (l.bias && (rc = upload(h, l.bias, l.nout, &p.bias)) != RN_OK) return rc;
+        if (l.gamma) {
+            if (!l.beta || !l.mean || !l.variance) {
+                rn_set_error("dense %d: incomplete BN parameters", d);
+                return RN_E_INVALID;
+            }
+            // tf.nn.batch_normalization: inv = rsqrt(var+eps)*gamma; shift = beta - mean*inv
+            std::vector<float> inv(l.nout), shift(l.nout);
+            for (int j = 0; j < l.nout; ++j) {
+                inv[j] = (1.0f / sqrtf(l.variance[j] + w->bn_epsilon)) * l.gamma[j];
+                shift[j] = l.beta[j] - l.mean[j] * inv[j];
+            }
+            if ((rc = upload(h, inv.data(), l.nout, &p.inv)) != RN_OK) return rc;
+            if ((rc = upload(h, shift.data(), l.nout, &p.shift)) != RN_OK) return rc;
+        }
+        std::snprintf(name, sizeof(name), "d%d.mm", d);
+        p.node_mm = add_node(h, name, 1, 1, l.nout);
+        std::snprintf(name, sizeof(name), "d%d.relu", d);
+        p.node_relu = add_node(h, name, 1, 1, l.nout);
+        if (l.gamma) {
+            std::snprintf(name, sizeof(name), "d%d.bn", d);
+            p.node_bn = add_node(h, name, 1, 1, l.nout);
+        }
+        h->dense.push_back(p);
+        nin = l.nout;
+    }
+    if (nin != w->num_classes) {
+        rn_set_error("last dense layer has %d outputs, num_classes is %d", nin, w->num_classes);
+        return RN_E_INVALID;
+    }
+    h->node_softmax = add_node(h, "softmax", 1, 1, w->num_classes);
+    return RN_OK;
+}
+
+// Allocate activation buffers.  Stage outputs always get their own buffer (they are
+// skip sources and are always tappable).  In the unfused path the conv/pool/add
+// intermediates share two scratch buffers unless RN_FLAG_TAPS asks for all of them.
+int alloc_buffers(rn_handle* h) {
+    const size_t nb = static_cast<size_t>(h->max_batch);
+    int rc;
+    const bool taps = (h->flags & RN_FLAG_TAPS) != 0;
+    const bool fused = fused_mode(h);
+    void* p = nullptr;
+    // input (fp32 RGB): unfused path only; the fused stage 0 reads uint8 directly
+    if (!fused) {
+        if ((rc = dev_alloc(h, nb * node_elems(h->nodes[h->node_input]) * 4, &p)) != RN_OK) return rc;
+        h->nodes[h->node_input].ptr = p;
+    }
+    size_t scratch_elems = 0;
+    for (auto& s : h->stages) {
+        const int out_node = s.node_bn2 >= 0 ? s.node_bn2 : s.node_bn;
+        for (int id : {s.node_conv, s.node_pool, s.node_bn, s.node_add, s.node_bn2}) {
+            if (id < 0) continue;
+            NodeBuf& n = h->nodes[id];
+            const bool is_out = (id == out_node) || (id == s.node_bn);
+            if (fused) {
+                if (id == out_node) {
+                    n.dtype = h->dtype;
+                    if ((rc = dev_alloc(h, nb * node_elems(n) * dtype_size(h->dtype) + 256, &p)) != RN_OK) return rc;
+                    n.ptr = p;
+                }
+                continue;
+            }
+            if (taps || is_out) {
+                if ((rc = dev_alloc(h, nb * node_elems(n) * 4, &p)) != RN_OK) return rc;
+                n.ptr = p;
+            } else {
+                scratch_elems = std::max(scratch_elems, node_elems(n));
+            }
+        }
+    }
+    if (!fused && !taps) {
+        void* s0 = nullptr;
+        void* s1 = nullptr;
+        if ((rc = dev_alloc(h, nb * scratch_elems * 4, &s0)) != RN_OK) return rc;
+        if ((rc = dev_alloc(h, nb * scratch_elems * 4, &s1)) != RN_OK) return rc;
+        for (auto& s : h->stages) {
+            if (s.node_conv >= 0 && !h->nodes[s.node_conv].ptr) h->nodes[s.node_conv].ptr = s0;
+            if (s.node_pool >= 0 && !h->nodes[s.node_pool].ptr) h->nodes[s.node_pool].ptr = s1;
+            if (s.node_add >= 0 && !h->nodes[s.node_add].ptr) h->nodes[s.node_add].ptr = s0;
+        }
+    }
+    // flat aliases the last stage output
+    {
+        const StagePlan& last = h->stages.back();
+        const NodeBuf& src = h->nodes[last.node_bn2 >= 0 ? last.node_bn2 : last.node_bn];
+        h->nodes[h->node_flat].ptr = src.ptr;
+        h->nodes[h->node_flat].dtype = src.dtype;
+    }
+    for (auto& d : h->dense)
+        for (int id : {d.node_mm, d.node_relu, d.node_bn}) {
+            if (id < 0) continue;
+            if ((rc = dev_alloc(h, nb * node_elems(h->nodes[id]) * 4, &p)) != RN_OK) return rc;
+            h->nodes[id].ptr = p;
+        }
+    // staging for the host-buffer entry points + softmax node
+    if ((rc = dev_alloc(h, nb * h->im_side * h->im_side * 3, &p)) != RN_OK) return rc;
+    h->d_in_u8 = static_cast<uint8_t*>(p);
+    if ((rc = dev_alloc(h, nb * h->num_classes * 4, &p)) != RN_OK) return rc;
+    h->d_probs = static_cast<float*>(p);
+    h->nodes[h->node_softmax].ptr = p;
+    if ((rc = dev_alloc(h, nb * 8, &p)) != RN_OK) return rc;
+    h->d_ids = static_cast<int64_t*>(p);
+    return RN_OK;
+}
+
+void record(rn_handle* h, int idx) {
+    if (h->profiling && idx < static_cast<int>(h->events.size())) (void)hipEventRecord(h->events[idx], h->stream);
+}
+
+int run_head(rn_handle* h, int n, float* d_probs, int64_t* d_ids) {
+    HeadArgs a{};
+    a.n_dense = static_cast<int>(h->dense.size());
+    for (int d = 0; d < a.n_dense; ++d) {
+        const DensePlan& p = h->dense[d];
+        a.nin[d] = p.nin;
+        a.nout[d] = p.nout;
+        a.w[d] = p.w;
+        a.bias[d] = p.bias;
+        a.inv[d] = p.inv;
+        a.shift[d] = p.shift;
+        a.tap_mm[d] = static_cast<float*>(h->nodes[p.node_mm].ptr);
+        a.tap_relu[d] = static_cast<float*>(h->nodes[p.node_relu].ptr);
+        a.tap_bn[d] = p.node_bn >= 0 ? static_cast<float*>(h->nodes[p.node_bn].ptr) : nullptr;
+    }
+    const NodeBuf& flat = h->nodes[h->node_flat];
+    return rn_launch_head(h->stream, flat.ptr, flat.dtype, n, a, d_probs, d_ids);
+}
+
+// Unfused float32 forward: one launch per graph node.
+int forward_unfused(rn_handle* h, const float* d_rgb, int n, float* d_probs, int64_t* d_ids) {
+    int rc;
+    const float* cur = d_rgb;
+    for (size_t i = 0; i < h->stages.size(); ++i) {
+        StagePlan& s = h->stages[i];
+        float* conv = static_cast<float*>(h->nodes[s.node_conv].ptr);
+        if ((rc = rn_launch_conv3x3_relu6_f32(h->stream, cur, s.w_f32, conv, n, s.in_side, s.in_side, s.cin,
+                                              s.cout)) != RN_OK)
+            return rc;
+        const float* pooled = conv;
+        if (s.pool_k) {
+            float* pl = static_cast<float*>(h->nodes[s.node_pool].ptr);
+            if ((rc = rn_launch_avgpool_f32(h->stream, conv, pl, n, s.conv_side, s.conv_side, s.cout, s.pool_k,
+                                            s.pool_s)) != RN_OK)
+                return rc;
+            pooled = pl;
+        }
+        float* bn = static_cast<float*>(h->nodes[s.node_bn].ptr);
+        const int64_t npix = static_cast<int64_t>(n) * s.out_side * s.out_side;
+        if ((rc = rn_launch_bn_f32(h->stream, pooled, bn, npix, s.cout, s.bn)) != RN_OK) return rc;
+        cur = bn;
+        if (s.skip_stage >= 0) {
+            const StagePlan& sk = h->stages[s.skip_stage];
+            const float* skip = static_cast<const float*>(h->nodes[sk.node_bn].ptr);
+            float* add = static_cast<float*>(h->nodes[s.node_add].ptr);
+            if ((rc = rn_launch_resize_add_f32(h->stream, bn, skip, add, n, s.out_side, s.skip_side, s.cout,
+                                               s.rt)) != RN_OK)
+                return rc;
+            float* bn2 = static_cast<float*>(h->nodes[s.node_bn2].ptr);
+            if ((rc = rn_launch_bn_f32(h->stream, add, bn2, npix, s.cout, s.bn2)) != RN_OK) return rc;
+            cur = bn2;
+        }
+        record(h, 2 + static_cast<int>(i));
+    }
+    if ((rc = run_head(h, n, d_probs, d_ids)) != RN_OK) return rc;
+    record(h, 2 + static_cast<int>(h->stages.size()));
+    return RN_OK;
+}
+
+int check_call(rn_handle* h, int n, const void* a, const void* b, const void* c) {
+    if (!h) {
+        rn_set_error("null handle");
+        return RN_E_INVALID;
+    }
+    if (!a || !b || !c) {
+        rn_set_error("null buffer");
+        return RN_E_INVALID;
+    }
+    if (n < 1 || n > h->max_batch) {
+        rn_set_error("batch %d out of range (max_batch %d)", n, h->max_batch);
+        return RN_E_RANGE;
+    }
+    return RN_OK;
+}
+
+}  // namespace
+
+int rn_run_head(rn_handle* h, int n, float* d_probs, int64_t* d_ids) { return run_head(h, n, d_probs, d_ids); }
+void rn_record_event(rn_handle* h, int idx) { record(h, idx); }
+
+// ---------------------------------------------------------------------------- API
+extern "C" int rn_create(const rn_weights* w, int device, int dtype, int max_batch, unsigned flags,
+                         rn_handle** out) {
+    if (!out) {
+        rn_set_error("rn_create: null out pointer");
+        return RN_E_INVALID;
+    }
+    *out = nullptr;
+    int rc = validate(w, dtype, max_batch, flags);
+    if (rc != RN_OK) return rc;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) {
+        rn_set_error("rn_create: no HIP device available");
+        return RN_E_HIP;
+    }
+    if (device < 0 || device >= ndev) {
+        rn_set_error("rn_create: device %d out of range (%d devices)", device, ndev);
+        return RN_E_INVALID;
+    }
+    DeviceGuard guard(device);
+    if (!guard.ok) {
+        rn_set_error("rn_create: hipSetDevice(%d) failed", device);
+        return RN_E_HIP;
+    }
+    rn_handle* h = new (std::nothrow) rn_handle();
+    if (!h) {
+        rn_set_error("rn_create: out of host memory");
+        return RN_E_NOMEM;
+    }
+    h->device = device;
+    h->dtype = dtype;
+    h->flags = flags;
+    h->max_batch = max_batch;
+    h->im_side = w->im_side;
+    h->num_classes = w->num_classes;
+    h->bn_eps = w->bn_epsilon;
+    auto fail = [&](int code) {
+        rn_destroy(h);
+        return code;
+    };
+    if (hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking) != hipSuccess) {
+        rn_set_error("rn_create: hipStreamCreate failed");
+        return fail(RN_E_HIP);
+    }
+    h->stream = h->own_stream;
+    if ((rc = build_plan(h, w)) != RN_OK) return fail(rc);
+    // uint8 -> float32 table, evaluated in float64 like the reference's NumPy expression
+    {
+        float lut[256];
+        for (int v = 0; v < 256; ++v) lut[v] = static_cast<float>(((static_cast<double>(v) / 255.) * 2) - 1);
+        if ((rc = upload(h, lut, 256, &h->lut)) != RN_OK) return fail(rc);
+    }
+    if (fused_mode(h) && (rc = rn_fused_prepare(h, w)) != RN_OK) return fail(rc);
+    if ((rc = alloc_buffers(h)) != RN_OK) return fail(rc);
+    h->events.resize(3 + h->stages.size());
+    for (auto& e : h->events)
+        if (hipEventCreate(&e) != hipSuccess) {
+            rn_set_error("rn_create: hipEventCreate failed");
+            return fail(RN_E_HIP);
+        }
+    if (hipDeviceSynchronize() != hipSuccess) {
+        rn_set_error("rn_create: device synchronize failed");
+        return fail(RN_E_HIP);
+    }
+    *out = h;
+    return RN_OK;
+}
+
+extern "C" void rn_destroy(rn_handle* h) {
+    if (!h) return;
+    DeviceGuard guard(h->device);
+    (void)hipDeviceSynchronize();
+    for (auto e : h->events)
+        if (e) (void)hipEventDestroy(e);
+    for (void* p : h->allocs) (void)hipFree(p);
+    if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
+    delete h;
+}
+
+extern "C" int rn_set_stream(rn_handle* h, void* hip_stream) {
+    if (!h) {
+        rn_set_error("null handle");
+        return RN_E_INVALID;
+    }
+    h->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : h->own_stream;
+    return RN_OK;
+}
+
+extern "C" int rn_sync(rn_handle* h) {
+    if (!h) {
+        rn_set_error("null handle");
+        return RN_E_INVALID;
+    }
+    DeviceGuard guard(h->device);
+    RN_HIP(hipStreamSynchronize(h->stream));
+    return RN_OK;
+}
+
+extern "C" int rn_forward_f32_device(rn_handle* h, const float* d_rgb, int n, float* d_probs, int64_t* d_ids) {
+    int rc = check_call(h, n, d_rgb, d_probs, d_ids);
+    if (rc != RN_OK) return rc;
+    DeviceGuard guard(h->device);
+    h->timing_valid = false;
+    record(h, 0);
+    record(h, 1);
+    if (fused_mode(h))
+        rc = rn_fused_forward(h, nullptr, d_rgb, n, d_probs, d_ids);
+    else {
+        // keep the "input" node readable through rn_tap
+        float* in_node = static_cast<float*>(h->nodes[h->node_input].ptr);
+        if (in_node != d_rgb)
+            RN_HIP(hipMemcpyAsync(in_node, d_rgb, static_cast<size_t>(n) * h->im_side * h->im_side * 3 * 4,
+                                  hipMemcpyDeviceToDevice, h->stream));
+        rc = forward_unfused(h, in_node, n, d_probs, d_ids);
+    }
+    if (rc != RN_OK) return rc;
+    h->last_n = n;
+    h->timing_valid = h->profiling;
+    return RN_OK;
+}
+
+extern "C" int rn_forward_u8_device(rn_handle* h, const uint8_t* d_bgr, int n, float* d_probs, int64_t* d_ids) {
+    int rc = check_call(h, n, d_bgr, d_probs, d_ids);
+    if (rc != RN_OK) return rc;
+    DeviceGuard guard(h->device);
+    h->timing_valid = false;
+    record(h, 0);
+    if (fused_mode(h)) {
+        record(h, 1);
+        rc = rn_fused_forward(h, d_bgr, nullptr, n, d_probs, d_ids);
+    } else {
+        float* in_node = static_cast<float*>(h->nodes[h->node_input].ptr);
+        rc = rn_launch_preprocess_u8(h->stream, d_bgr, in_node, h->lut,
+                                     static_cast<int64_t>(n) * h->im_side * h->im_side);
+        if (rc != RN_OK) return rc;
+        record(h, 1);
+        rc = forward_unfused(h, in_node, n, d_probs, d_ids);
+    }
+    if (rc != RN_OK) return rc;
+    h->last_n = n;
+    h->timing_valid = h->profiling;
+    return RN_OK;
+}
+
+extern "C" int rn_forward_u8(rn_handle* h, const uint8_t* bgr, int n, float* probs, int64_t* ids) {
+    int rc = check_call(h, n, bgr, probs, ids);
+    if (rc != RN_OK) return rc;
+    DeviceGuard guard(h->device);
+    const size_t in_bytes = static_cast<size_t>(n) * h->im_side * h->im_side * 3;
+    RN_HIP(hipMemcpyAsync(h->d_in_u8, bgr, in_bytes, hipMemcpyHostToDevice, h->stream));
+    if ((rc = rn_forward_u8_device(h, h->d_in_u8, n, h->d_probs, h->d_ids)) != RN_OK) return rc;
+    RN_HIP(hipMemcpyAsync(probs, h->d_probs, static_cast<size_t>(n) * h->num_classes * 4, hipMemcpyDeviceToHost,
+                          h->stream));
+    RN_HIP(hipMemcpyAsync(ids, h->d_ids, static_cast<size_t>(n) * 8, hipMemcpyDeviceToHost, h->stream));
+    RN_HIP(hipStreamSynchronize(h->stream));
+    return RN_OK;
+}
+
+extern "C" int rn_forward_f32(rn_handle* h, const float* rgb, int n, float* probs, int64_t* ids) {
+    int rc = check_call(h, n, rgb, probs, ids);
+    if (rc != RN_OK) return rc;
+    if (fused_mode(h)) {
+        rn_set_error("rn_forward_f32: 16-bit handles take uint8 input (use rn_forward_u8)");
+        return RN_E_STATE;
+    }
+    DeviceGuard guard(h->device);
+    float* in_node = static_cast<float*>(h->nodes[h->node_input].ptr);
+    const size_t in_bytes = static_cast<size_t>(n) * h->im_side * h->im_side * 3 * 4;
+    RN_HIP(hipMemcpyAsync(in_node, rgb, in_bytes, hipMemcpyHostToDevice, h->stream));
+    if ((rc = rn_forward_f32_device(h, in_node, n, h->d_probs, h->d_ids)) != RN_OK) return rc;
+    RN_HIP(hipMemcpyAsync(probs, h->d_probs, static_cast<size_t>(n) * h->num_classes * 4, hipMemcpyDeviceToHost,
+                          h->stream));
+    RN_HIP(hipMemcpyAsync(ids, h->d_ids, static_cast<size_t>(n) * 8, hipMemcpyDeviceToHost, h->stream));
+    RN_HIP(hipStreamSynchronize(h->stream));
+    return RN_OK;
+}
+
+extern "C" int rn_node_count(const rn_handle* h) { return h ? static_cast<int>(h->nodes.size()) : 0; }
+
+extern "C" int rn_node_info_get(const rn_handle* h, int node_id, rn_node_info* out) {
+    if (!h || !out || node_id < 0 || node_id >= static_cast<int>(h->nodes.size())) {
+        rn_set_error("rn_node_info_get: bad argument");
+        return RN_E_RANGE;
+    }
+    *out = h->nodes[node_id].info;
+    return RN_OK;
+}
+
+extern "C" int rn_tap(rn_handle* h, int node_id, float* out, size_t cap_elems, size_t* n_elems) {
+    if (!h || !out || node_id < 0 || node_id >= static_cast<int>(h->nodes.size())) {
+        rn_set_error("rn_tap: bad argument");
+        return RN_E_RANGE;
+    }
+    if (h->last_n < 1) {
+        rn_set_error("rn_tap: no forward pass has run on this handle");
+        return RN_E_STATE;
+    }
+    const NodeBuf& nb = h->nodes[node_id];
+    if (!nb.ptr) {
+        rn_set_error("rn_tap: node %s is not materialised on this handle (create with RN_FLAG_TAPS)", nb.info.name);
+        return RN_E_STATE;
+    }
+    const bool shared_scratch = !(h->flags & RN_FLAG_TAPS) && !fused_mode(h);
+    if (shared_scratch) {
+        const char* nm = nb.info.name;
+        const size_t len = std::strlen(nm);
+        const bool inter = (len > 5 && (!std::strcmp(nm + len - 5, ".conv") || !std::strcmp(nm + len - 5, ".pool"))) ||
+                           (len > 4 && !std::strcmp(nm + len - 4, ".add"));
+        if (inter) {
+            rn_set_error("rn_tap: node %s shares scratch memory on this handle (create with RN_FLAG_TAPS)", nm);
+            return RN_E_STATE;
+        }
+    }
+    const size_t total = static_cast<size_t>(h->last_n) * node_elems(nb);
+    if (n_elems) *n_elems = total;
+    if (cap_elems < total) {
+        rn_set_error("rn_tap: buffer too small (%zu < %zu elements)", cap_elems, total);
+        return RN_E_RANGE;
+    }
+    DeviceGuard guard(h->device);
+    RN_HIP(hipStreamSynchronize(h->stream));
+    if (nb.dtype == RN_DTYPE_F32) {
+        RN_HIP(hipMemcpy(out, nb.ptr, total * 4, hipMemcpyDeviceToHost));
+    } else {
+        float* tmp = nullptr;
+        RN_HIP(hipMalloc(reinterpret_cast<void**>(&tmp), total * 4));
+        int rc = rn_launch_convert_to_f32(h->stream, nb.ptr, nb.dtype, tmp, static_cast<int64_t>(total));
+        if (rc == RN_OK && hipStreamSynchronize(h->stream) != hipSuccess) rc = RN_E_HIP;
+        if (rc == RN_OK && hipMemcpy(out, tmp, total * 4, hipMemcpyDeviceToHost) != hipSuccess) rc = RN_E_HIP;
+        (void)hipFree(tmp);
+        if (rc != RN_OK) {
+            if (rc == RN_E_HIP) rn_set_error("rn_tap: device copy failed");
+            return rc;
+        }
+    }
+    return RN_OK;
+}
+
+extern "C" int rn_set_profiling(rn_handle* h, int enable) {
+    if (!h) {
+        rn_set_error("null handle");
+        return RN_E_INVALID;
+    }
+    h->profiling = enable != 0;
+    h->timing_valid = false;
+    return RN_OK;
+}
+
+extern "C" int rn_timing(rn_handle* h, rn_stage_ms* out) {
+    if (!h || !out) {
+        rn_set_error("rn_timing: bad argument");
+        return RN_E_INVALID;
+    }
+    if (!h->timing_valid) {
+        rn_set_error("rn_timing: no profiled forward pass (call rn_set_profiling(h,1) first)");
+        return RN_E_STATE;
+    }
+    DeviceGuard guard(h->device);
+    const int ns = static_cast<int>(h->stages.size());
+    RN_HIP(hipEventSynchronize(h->events[2 + ns]));
+    std::memset(out, 0, sizeof(*out));
+    out->n_stages = ns;
+    RN_HIP(hipEventElapsedTime(&out->preprocess_ms, h->events[0], h->events[1]));
+    for (int i = 0; i < ns; ++i) RN_HIP(hipEventElapsedTime(&out->stage_ms[i], h->events[1 + i], h->events[2 + i]));
+    RN_HIP(hipEventElapsedTime(&out->head_ms, h->events[1 + ns], h->events[2 + ns]));
+    RN_HIP(hipEventElapsedTime(&out->total_ms, h->events[0], h->events[2 + ns]));
+    return RN_OK;
+}
+
+extern "C" int rn_dominant_stage(const rn_handle* h) {
+    if (!h) return -1;
+    int best = 0;
+    double bestf = -1;
+    for (size_t i = 0; i < h->stages.size(); ++i) {
+        const StagePlan& s = h->stages[i];
+        const double f = 2.0 * s.conv_side * s.conv_side * 9.0 * s.cin * s.cout;
+        if (f > bestf) {
+            bestf = f;
+            best = static_cast<int>(i);
+        }
+    }
+    return best;
+}
+
+extern "C" int rn_device_malloc(rn_handle* h, size_t bytes, void** d_ptr) {
+    if (!h || !d_ptr) {
+        rn_set_error("rn_device_malloc: bad argument");
+        return RN_E_INVALID;
+    }
+    DeviceGuard guard(h->device);
+    hipError_t e = hipMalloc(d_ptr, bytes ? bytes : 16);
+    if (e != hipSuccess) {
+        rn_set_error("hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+        return RN_E_NOMEM;
+    }
+    return RN_OK;
+}
+
+extern "C" int rn_device_free(rn_handle* h, void* d_ptr) {
+    if (!h) {
+        rn_set_error("null handle");
+        return RN_E_INVALID;
+    }
+    DeviceGuard guard(h->device);
+    RN_HIP(hipFree(d_ptr));
+    return RN_OK;
+}
+
+extern "C" int rn_memcpy_h2d(rn_handle* h, void* d_dst, const void* src, size_t bytes) {
+    if (!h || !d_dst || !src) {
+        rn_set_error("rn_memcpy_h2d: bad argument");
+        return RN_E_INVALID;
+    }
+    DeviceGuard guard(h->device);
+    RN_HIP(hipMemcpyAsync(d_dst, src, bytes, hipMemcpyHostToDevice, h->stream));
+    RN_HIP(hipStreamSynchronize(h->stream));
+    return RN_OK;
+}
+
+extern "C" int rn_memcpy_d2h(rn_handle* h, void* dst, const void* d_src, size_t bytes) {
+    if (!h || !dst || !d_src) {
+        rn_set_error("rn_memcpy_d2h: bad argument");
+        return RN_E_INVALID;
+    }
+    DeviceGuard guard(h->device);
+    RN_HIP(hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, h->stream));
+    RN_HIP(hipStreamSynchronize(h->stream));
+    return RN_OK;
+}

@@ -1,0 +1,281 @@
+// Unfused float32 kernels: one launch per graph node, every node tappable.
+// This is the RN_DTYPE_F32 execution path (BASELINE config 2: batch-1 fp32 forward,
+// per-layer correctness) and the on-device cross-check for the fused MFMA path.
+//
+// Node semantics follow the TF-1.13 CPU kernels the reference calls:
+//   conv3x3_relu6   network.py:184-186  tf.layers.conv2d(3, strides=1, VALID, no bias, relu6)
+//   avgpool         network.py:189      tf.nn.avg_pool VALID, divisor k*k
+//   bn              network.py:193/:202 FusedBatchNorm(is_training=False): (x-mean)*inv+beta
+//   resize_add      network.py:199      out + resize_bilinear(skip) (legacy, align_corners=False)
+//   head            network.py:231-237, :44-45  flatten, 4 dense blocks, softmax, argmax
+#include "rn_internal.h"
+#include <hip/hip_bf16.h>
+#include <hip/hip_fp16.h>
+
+namespace {
+
+__device__ __forceinline__ float relu6f(float v) { return fminf(fmaxf(v, 0.f), 6.f); }
+
+__device__ __forceinline__ float load_as_f32(const void* p, int dtype, int64_t i) {
+    if (dtype == RN_DTYPE_F32) return reinterpret_cast<const float*>(p)[i];
+    if (dtype == RN_DTYPE_BF16) {
+        const unsigned short u = reinterpret_cast<const unsigned short*>(p)[i];
+        return __uint_as_float(static_cast<unsigned>(u) << 16);
+    }
+    return __half2float(reinterpret_cast<const __half*>(p)[i]);
+}
+
+// uint8 BGR -> float32 RGB through the 256-entry table fp32(fp64(v)/255*2-1)
+__global__ __launch_bounds__(256) void preprocess_u8_kernel(const uint8_t* __restrict__ bgr,
+                                                            float* __restrict__ rgb,
+                                                            const float* __restrict__ lut, int64_t npix) {
+    const int64_t p = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (p >= npix) return;
+    const uint8_t b = bgr[3 * p + 0], g = bgr[3 * p + 1], r = bgr[3 * p + 2];
+    rgb[3 * p + 0] = lut[r];
+    rgb[3 * p + 1] = lut[g];
+    rgb[3 * p + 2] = lut[b];
+}
+
+// Direct 3x3 VALID convolution + ReLU6.  16x16 output pixels per block, one pixel per
+// thread, CO_T output channels per thread; input tile staged in LDS channel-major so
+// that a wave's 16 x-neighbours read consecutive banks; weights are wave-uniform and
+// come in through scalar loads.
+template <int CO_T>
+__global__ __launch_bounds__(256) void conv3x3_relu6_f32_kernel(const float* __restrict__ in,
+                                                                const float* __restrict__ w,
+                                                                float* __restrict__ out, int H, int W,
+                                                                int Cin, int Cout, int co_groups) {
+    constexpr int TILE = 16, IT = TILE + 2, CCH = 8;
+    __shared__ float tile[CCH * IT * IT];
+    const int n = blockIdx.z / co_groups, cog = blockIdx.z % co_groups;
+    const int ox0 = blockIdx.x * TILE, oy0 = blockIdx.y * TILE;
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int Ho = H - 2, Wo = W - 2;
+    float acc[CO_T];
+#pragma unroll
+    for (int o = 0; o < CO_T; ++o) acc[o] = 0.f;
+    for (int c0 = 0; c0 < Cin; c0 += CCH) {
+        const int cc = min(CCH, Cin - c0);
+        for (int i = threadIdx.x; i < IT * IT * CCH; i += 256) {
+            const int c = i % CCH, p = i / CCH;
+            const int ix = p % IT, iy = p / IT;
+            const int gy = oy0 + iy, gx = ox0 + ix;
+            float v = 0.f;
+            if (c < cc && gy < H && gx < W)
+                v = in[((static_cast<int64_t>(n) * H + gy) * W + gx) * Cin + c0 + c];
+            tile[c * IT * IT + iy * IT + ix] = v;
+        }
+        __syncthreads();
+        for (int ky = 0; ky < 3; ++ky)
+            for (int kx = 0; kx < 3; ++kx)
+                for (int c = 0; c < cc; ++c) {
+                    const float v = tile[c * IT * IT + (ty + ky) * IT + tx + kx];
+                    const float* wr = w + (static_cast<int64_t>(ky * 3 + kx) * Cin + c0 + c) * Cout + cog * CO_T;
+#pragma unroll
+                    for (int o = 0; o < CO_T; ++o) acc[o] = fmaf(v, wr[o], acc[o]);
+                }
+        __syncthreads();
+    }
+    const int oy = oy0 + ty, ox = ox0 + tx;
+    if (oy < Ho && ox < Wo) {
+        float* op = out + ((static_cast<int64_t>(n) * Ho + oy) * Wo + ox) * Cout + cog * CO_T;
+#pragma unroll
+        for (int o = 0; o < CO_T; ++o) op[o] = relu6f(acc[o]);
+    }
+}
+
+__global__ __launch_bounds__(256) void avgpool_f32_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                          int H, int W, int C, int k, int s, int Ho, int Wo,
+                                                          int64_t total) {
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int c = i % C;
+    int64_t p = i / C;
+    const int x = p % Wo;
+    p /= Wo;
+    const int y = p % Ho;
+    const int64_t n = p / Ho;
+    float acc = 0.f;
+    for (int ky = 0; ky < k; ++ky)
+        for (int kx = 0; kx < k; ++kx)
+            acc += in[((n * H + (y * s + ky)) * W + (x * s + kx)) * C + c];
+    out[i] = acc / static_cast<float>(k * k);
+}
+
+__global__ __launch_bounds__(256) void bn_f32_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                     int C, const float* __restrict__ mean,
+                                                     const float* __restrict__ inv,
+                                                     const float* __restrict__ beta, int64_t total) {
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int c = i % C;
+    // (x - mean) * inv + beta, un-contracted like the reference's Eigen expression
+    out[i] = __fadd_rn(__fmul_rn(__fsub_rn(in[i], mean[c]), inv[c]), beta[c]);
+}
+
+__global__ __launch_bounds__(256) void resize_add_f32_kernel(const float* __restrict__ x,
+                                                             const float* __restrict__ skip,
+                                                             float* __restrict__ out, int side, int sside,
+                                                             int C, const int32_t* __restrict__ lo,
+                                                             const int32_t* __restrict__ hi,
+                                                             const float* __restrict__ lerp, int64_t total) {
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int c = i % C;
+    int64_t p = i / C;
+    const int ox = p % side;
+    p /= side;
+    const int oy = p % side;
+    const int64_t n = p / side;
+    const float* r0 = skip + (n * sside + lo[oy]) * sside * C;
+    const float* r1 = skip + (n * sside + hi[oy]) * sside * C;
+    const float tl = r0[lo[ox] * C + c], tr = r0[hi[ox] * C + c];
+    const float bl = r1[lo[ox] * C + c], br = r1[hi[ox] * C + c];
+    const float xl = lerp[ox], yl = lerp[oy];
+    const float top = __fadd_rn(tl, __fmul_rn(__fsub_rn(tr, tl), xl));
+    const float bottom = __fadd_rn(bl, __fmul_rn(__fsub_rn(br, bl), xl));
+    const float r = __fadd_rn(top, __fmul_rn(__fsub_rn(bottom, top), yl));
+    out[i] = __fadd_rn(x[i], r);
+}
+
+__global__ __launch_bounds__(256) void convert_to_f32_kernel(const void* __restrict__ in, int dtype,
+                                                             float* __restrict__ out, int64_t total) {
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i < total) out[i] = load_as_f32(in, dtype, i);
+}
+
+// One 64-thread block (one wavefront) per image: flatten, dense chain, softmax, argmax.
+constexpr int HEAD_MAX_FLAT = 4096;
+__global__ __launch_bounds__(64) void head_kernel(const void* __restrict__ flat, int flat_dtype, HeadArgs a,
+                                                  float* __restrict__ probs, int64_t* __restrict__ ids) {
+    __shared__ float buf0[HEAD_MAX_FLAT];
+    __shared__ float small[2][64];
+    const int img = blockIdx.x;
+    const int lane = threadIdx.x;
+    const int nin0 = a.nin[0];
+    for (int i = lane; i < nin0; i += 64) buf0[i] = load_as_f32(flat, flat_dtype, static_cast<int64_t>(img) * nin0 + i);
+    __syncthreads();
+    const float* cur = buf0;
+    for (int d = 0; d < a.n_dense; ++d) {
+        const int nin = a.nin[d], nout = a.nout[d];
+        float* dst = small[d & 1];
+        if (lane < nout) {
+            float v = 0.f;
+            const float* wd = a.w[d];
+            for (int k = 0; k < nin; ++k) v = fmaf(cur[k], wd[k * nout + lane], v);
+            if (a.bias[d]) v = __fadd_rn(v, a.bias[d][lane]);
+            if (a.tap_mm[d]) a.tap_mm[d][static_cast<int64_t>(img) * nout + lane] = v;
+            v = relu6f(v);
+            if (a.tap_relu[d]) a.tap_relu[d][static_cast<int64_t>(img) * nout + lane] = v;
+            if (a.inv[d]) {
+                v = __fadd_rn(__fmul_rn(v, a.inv[d][lane]), a.shift[d][lane]);
+                if (a.tap_bn[d]) a.tap_bn[d][static_cast<int64_t>(img) * nout + lane] = v;
+            }
+            dst[lane] = v;
+        }
+        __syncthreads();
+        cur = dst;
+    }
+    // softmax + argmax over the num_classes logits (wave-level: every lane holds one class)
+    const int nc = a.nout[a.n_dense - 1];
+    const float logit = lane < nc ? cur[lane] : -INFINITY;
+    float mx = logit;
+    for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+    const float e = lane < nc ? expf(logit - mx) : 0.f;
+    float sum = e;
+    for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off);
+    const float p = e / sum;
+    if (lane < nc) probs[static_cast<int64_t>(img) * nc + lane] = p;
+    // argmax with lowest-index tie-break (tf.argmax)
+    float bestv = lane < nc ? p : -1.f;
+    int besti = lane < nc ? lane : 0x7fffffff;
+    for (int off = 32; off > 0; off >>= 1) {
+        const float ov = __shfl_xor(bestv, off);
+        const int oi = __shfl_xor(besti, off);
+        if (ov > bestv || (ov == bestv && oi < besti)) {
+            bestv = ov;
+            besti = oi;
+        }
+    }
+    if (lane == 0) ids[img] = besti;
+}
+
+inline unsigned blocks_for(int64_t total, int bs = 256) { return static_cast<unsigned>((total + bs - 1) / bs); }
+
+}  // namespace
+
+int rn_launch_preprocess_u8(hipStream_t s, const uint8_t* bgr, float* rgb, const float* lut, int64_t npix) {
+    hipLaunchKernelGGL(preprocess_u8_kernel, dim3(blocks_for(npix)), dim3(256), 0, s, bgr, rgb, lut, npix);
+    RN_CHECK_LAUNCH();
+    return RN_OK;
+}
+
+int rn_launch_conv3x3_relu6_f32(hipStream_t s, const float* in, const float* w, float* out, int n, int h,
+                                int wd, int cin, int cout) {
+    const int ho = h - 2, wo = wd - 2;
+    dim3 block(256);
+    if (cout % 16 == 0) {
+        const int cg = cout / 16;
+        dim3 grid((wo + 15) / 16, (ho + 15) / 16, n * cg);
+        hipLaunchKernelGGL(conv3x3_relu6_f32_kernel<16>, grid, block, 0, s, in, w, out, h, wd, cin, cout, cg);
+    } else if (cout % 8 == 0) {
+        const int cg = cout / 8;
+        dim3 grid((wo + 15) / 16, (ho + 15) / 16, n * cg);
+        hipLaunchKernelGGL(conv3x3_relu6_f32_kernel<8>, grid, block, 0, s, in, w, out, h, wd, cin, cout, cg);
+    } else {
+        const int cg = cout;
+        dim3 grid((wo + 15) / 16, (ho + 15) / 16, n * cg);
+        hipLaunchKernelGGL(conv3x3_relu6_f32_kernel<1>, grid, block, 0, s, in, w, out, h, wd, cin, cout, cg);
+    }
+    RN_CHECK_LAUNCH();
+    return RN_OK;
+}
+
+int rn_launch_avgpool_f32(hipStream_t s, const float* in, float* out, int n, int h, int w, int c, int k, int st) {
+    const int ho = (h - k) / st + 1, wo = (w - k) / st + 1;
+    const int64_t total = static_cast<int64_t>(n) * ho * wo * c;
+    hipLaunchKernelGGL(avgpool_f32_kernel, dim3(blocks_for(total)), dim3(256), 0, s, in, out, h, w, c, k, st, ho,
+                       wo, total);
+    RN_CHECK_LAUNCH();
+    return RN_OK;
+}
+
+int rn_launch_bn_f32(hipStream_t s, const float* in, float* out, int64_t npix, int c, const BnDev& bn) {
+    const int64_t total = npix * c;
+    hipLaunchKernelGGL(bn_f32_kernel, dim3(blocks_for(total)), dim3(256), 0, s, in, out, c, bn.mean, bn.inv,
+                       bn.beta, total);
+    RN_CHECK_LAUNCH();
+    return RN_OK;
+}
+
+int rn_launch_resize_add_f32(hipStream_t s, const float* x, const float* skip, float* out, int n, int side,
+                             int skip_side, int c, const ResizeTab& rt) {
+    const int64_t total = static_cast<int64_t>(n) * side * side * c;
+    hipLaunchKernelGGL(resize_add_f32_kernel, dim3(blocks_for(total)), dim3(256), 0, s, x, skip, out, side,
+                       skip_side, c, rt.lo, rt.hi, rt.lerp, total);
+    RN_CHECK_LAUNCH();
+    return RN_OK;
+}
+
+int rn_launch_convert_to_f32(hipStream_t s, const void* in, int dtype, float* out, int64_t n) {
+    hipLaunchKernelGGL(convert_to_f32_kernel, dim3(blocks_for(n)), dim3(256), 0, s, in, dtype, out, n);
+    RN_CHECK_LAUNCH();
+    return RN_OK;
+}
+
+int rn_launch_head(hipStream_t s, const void* flat, int flat_dtype, int n, const HeadArgs& a, float* probs,
+                   int64_t* ids) {
+    if (a.nin[0] > HEAD_MAX_FLAT) {
+        rn_set_error("flatten length %d exceeds head kernel capacity %d", a.nin[0], HEAD_MAX_FLAT);
+        return RN_E_INVALID;
+    }
+    for (int d = 0; d < a.n_dense; ++d)
+        if (a.nout[d] > 64 || (d > 0 && a.nin[d] > 64)) {
+            rn_set_error("dense layer %d wider than 64 is not supported by the head kernel", d);
+            return RN_E_INVALID;
+        }
+    hipLaunchKernelGGL(head_kernel, dim3(n), dim3(64), 0, s, flat, flat_dtype, a, probs, ids);
+    RN_CHECK_LAUNCH();
+    return RN_OK;
+}

@@ -1,0 +1,225 @@
+"""``RoomNet`` -- drop-in for the reference's ``network.RoomNet`` inference surface
+(reference ``network.py:19-244``), executing on an MI355X through
+libroomnet_hip.so instead of a TensorFlow session.
+
+Kept from the reference (same names, argument meaning, return shapes/dtypes):
+``RoomNet(num_classes, im_side=600, ...)``, attributes ``num_classes``,
+``im_side``, ``sess``; ``init()``, ``load(model_path=None)``, ``save(suffix=None)``,
+``center_crop(x)``, ``infer(im_batch)``, ``infer_optimized(im)``.
+Training (``train_step``, loss/optimizer graph, ``network.py:49-85,158-170``) is out
+of scope and raises ``NotImplementedError``.
+
+MI355X-only keyword arguments (not in the reference): ``device``, ``dtype``
+("f32" | "bf16" | "f16"), ``max_batch``.
+"""
+from __future__ import annotations
+
+import os
+from glob import glob
+from typing import Dict, Optional
+
+import numpy as np
+
+from . import tf_bundle
+from ._capi import Engine
+from .graph import Graph, build_graph
+from .imageops import resize_linear_u8
+
+
+class _Session:
+    """Stand-in for the ``tf.Session`` the reference keeps in ``self.sess``: owns the
+    variable values; the device engine is (re)built from them on demand."""
+
+    def __init__(self, variables: Dict[str, np.ndarray]):
+        self.variables = variables
+        self.engine: Optional[Engine] = None
+
+    def close(self) -> None:
+        if self.engine is not None:
+            self.engine.close()
+            self.engine = None
+
+
+def _initializer_values(graph: Graph, seed: int = 0) -> Dict[str, np.ndarray]:
+    """What ``tf.global_variables_initializer`` produces for this graph
+    (``network.py:87-91``): glorot-uniform kernels, zero bias, BN gamma=1, beta=0,
+    moving_mean=0, moving_variance=1."""
+    rng = np.random.default_rng(seed)
+    out: Dict[str, np.ndarray] = {}
+    for name, shape in graph.variable_shapes().items():
+        leaf = name.rsplit("/", 1)[1]
+        if leaf == "kernel":
+            if len(shape) == 4:
+                fan_in, fan_out = shape[0] * shape[1] * shape[2], shape[0] * shape[1] * shape[3]
+            else:
+                fan_in, fan_out = shape
+            lim = np.sqrt(6.0 / (fan_in + fan_out))
+            out[name] = rng.uniform(-lim, lim, shape).astype(np.float32)
+        elif leaf in ("gamma", "moving_variance"):
+            out[name] = np.ones(shape, np.float32)
+        else:
+            out[name] = np.zeros(shape, np.float32)
+    return out
+
+
+class RoomNet:
+
+    def __init__(self, num_classes, im_side=600, compute_bn_mean_var=True, start_step=0, dropout_enabled=False,
+                 learn_rate=1e-4, l2_regularizer_coeff=1e-2, num_steps=10000, dropout_rate=.2,
+                 update_batchnorm_means_vars=True, optimized_inference=False, *, device=0, dtype="f32",
+                 max_batch=64):
+        self.num_classes = num_classes
+        self.im_side = im_side
+        self.compute_bn_mean_var = compute_bn_mean_var
+        self.optimized_inference = optimized_inference
+        self.start_step = start_step
+        self.step = start_step
+        self.learn_rate = learn_rate
+        self.dropout_enabled = False if optimized_inference else dropout_enabled
+        self.model_folder = 'all_trained_models/trained_models'
+        self.model_fpath_prefix = self.model_folder + '/' + 'roomnet-'
+        if compute_bn_mean_var:
+            # training=True batch statistics (network.py:193) need the training graph
+            raise NotImplementedError("compute_bn_mean_var=True (batch-statistics BN) belongs to the training "
+                                      "path, which is out of scope; construct with compute_bn_mean_var=False")
+        self.graph = build_graph(num_classes=num_classes, im_side=im_side)
+        self.device = device
+        self.dtype = dtype
+        self.max_batch = max_batch
+        self.sess: Optional[_Session] = None
+        # variables created by the dense blocks are not restored in training mode
+        # (restore_excluded_vars, network.py:242 / :78)
+        self._restore_excluded = set()
+        if not optimized_inference:
+            for d in self.graph.dense:
+                self._restore_excluded.add(d.name + "/")
+                if d.bn_name:
+                    self._restore_excluded.add(d.bn_name + "/")
+
+    # ------------------------------------------------------------- persistence
+    def init(self):
+        """network.py:87-91."""
+        if not self.sess:
+            self.sess = _Session(_initializer_values(self.graph))
+
+    def save(self, suffix=None):
+        """network.py:93-103 (writes the index + data shard; no .meta graph)."""
+        if not self.sess:
+            self.init()
+        if self.optimized_inference:
+            tf_bundle.write_bundle('roomnet', self.sess.variables)
+            print('Model Saved in optimized inference mode')
+            return
+        if suffix:
+            save_fpath = self.model_fpath_prefix + '-' + suffix + '--' + str(self.step)
+        else:
+            save_fpath = self.model_fpath_prefix + '-' + str(self.step)
+        tf_bundle.write_bundle(save_fpath, self.sess.variables)
+        print('Model saved at', save_fpath)
+
+    def load(self, model_path=None):
+        """network.py:105-126."""
+        if not self.sess:
+            self.init()
+        if model_path is None:
+            if os.path.isdir(self.model_folder):
+                existing_paths = glob(self.model_folder + '/*.index')
+                if len(existing_paths) == 0:
+                    print('No model found to restore from, initializing random weights')
+                    return
+                existing_ids = [int(p.split('--')[-1].replace('.index', '')) for p in existing_paths]
+                selected_idx = np.argmax(existing_ids)
+                self.step = existing_ids[selected_idx]
+                self.start_step = self.step
+                model_path = existing_paths[selected_idx].replace('.index', '')
+            else:
+                print('No model found to restore from, initializing random weights')
+                return
+        reader = tf_bundle.BundleReader(model_path)
+        shapes = self.graph.variable_shapes()
+        restored = dict(self.sess.variables)
+        for name, shape in shapes.items():
+            if any(name.startswith(p) for p in self._restore_excluded):
+                continue
+            if name not in reader:
+                raise tf_bundle.BundleError("Key %s not found in checkpoint %r" % (name, model_path))
+            val = reader.get(name)
+            if tuple(val.shape) != tuple(shape):
+                raise ValueError("Assign requires shapes of both tensors to match. lhs shape= %s rhs shape= %s "
+                                 "(variable %s; is the checkpoint for im_side=%d?)"
+                                 % (list(shape), list(val.shape), name, self.im_side))
+            restored[name] = val.astype(np.float32)
+        self.sess.close()
+        self.sess.variables = restored
+        print('Model restored from', model_path)
+
+    def set_variables(self, values: Dict[str, np.ndarray]) -> None:
+        """Assign variable values directly (what ``sess.run(tf.assign(...))`` does)."""
+        if not self.sess:
+            self.init()
+        shapes = self.graph.variable_shapes()
+        for k, v in values.items():
+            if k not in shapes:
+                raise KeyError("unknown variable %r" % k)
+            if tuple(np.shape(v)) != tuple(shapes[k]):
+                raise ValueError("variable %r: shape %s does not match %s" % (k, np.shape(v), shapes[k]))
+            self.sess.variables[k] = np.asarray(v, np.float32)
+        self.sess.close()
+
+    def _engine(self) -> Engine:
+        if not self.sess:
+            raise RuntimeError("Attempted to use a closed Session. (call init() or load() first)")
+        if self.sess.engine is None:
+            self.sess.engine = Engine(self.graph, self.sess.variables, device=self.device, dtype=self.dtype,
+                                      max_batch=self.max_batch)
+        return self.sess.engine
+
+    # ----------------------------------------------------------------- inference
+    def infer(self, im_in):
+        """network.py:128-135: [N,S,S,3] BGR batch already at im_side.  Returns
+        ``(argmax int64[N], softmax float32[N,C])`` in optimized mode, ``argmax``
+        alone otherwise (``outs_final`` differs: network.py:45 vs :72)."""
+        im = np.asarray(im_in)
+        if im.ndim != 4 or im.shape[1:] != (self.im_side, self.im_side, 3):
+            raise ValueError("Cannot feed value of shape %s for Tensor 'input_x_tensor:0', which has shape "
+                             "'(?, %d, %d, 3)'" % (im.shape, self.im_side, self.im_side))
+        eng = self._engine()
+        if im.dtype == np.uint8:
+            ids, probs = eng.forward_u8(im)
+        else:
+            # non-uint8 input: same float64 expression as the reference, cast at the feed
+            x = (((im[:, :, :, [2, 1, 0]] / 255.) * 2) - 1).astype(np.float32)
+            ids, probs = eng.forward_f32(x)
+        if self.optimized_inference:
+            return ids, probs
+        return ids
+
+    def center_crop(self, x):
+        """network.py:137-146."""
+        h, w, _ = x.shape
+        offset = abs((w - h) // 2)
+        if h < w:
+            x_pp = x[:, offset:offset + h, :]
+        elif w < h:
+            x_pp = x[offset:offset + w, :, :]
+        else:
+            x_pp = x.copy()
+        return x_pp
+
+    def infer_optimized(self, im_in):
+        """network.py:148-156: one BGR HWC image of any size -> ``(idx[1], conf[1,C])``."""
+        im = self.center_crop(im_in)
+        h, w, _ = im.shape
+        if h != self.im_side or w != self.im_side:
+            im = resize_linear_u8(im, self.im_side, self.im_side)
+        eng = self._engine()
+        im = np.ascontiguousarray(im)
+        if im.dtype == np.uint8:
+            out_label_idx, out_label_conf = eng.forward_u8(im[None])
+        else:
+            x = (((im[:, :, [2, 1, 0]] / 255.) * 2) - 1).astype(np.float32)
+            out_label_idx, out_label_conf = eng.forward_f32(x[None])
+        return out_label_idx, out_label_conf
+
+    def train_step(self, x_in, y):
+        raise NotImplementedError("training (network.py:158-170) is out of scope of the MI355X inference path")

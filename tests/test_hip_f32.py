@@ -1,0 +1,157 @@
+"""GPU parity of the float32 HIP path (RN_DTYPE_F32, unfused per-node kernels) with
+the oracle, through the C ABI.  BASELINE config 2: batch-1 / small-batch fp32 forward,
+per-layer correctness.  Tolerances are BASELINE.md section 5: logits abs <= 1e-4,
+probs abs <= 1e-5, ids identical where the top-2 margin > 1e-3; per-node max error
+<= 1e-4 of the node's abs-max."""
+import numpy as np
+import pytest
+
+from conftest import sample_positions
+from oracle import c_oracle, roomnet_ref as R
+from roomnet_amd import _capi
+from roomnet_amd.graph import build_graph
+
+pytestmark = pytest.mark.gpu
+
+TOL_LOGITS, TOL_PROBS, MARGIN = 1e-4, 1e-5, 1e-3
+
+
+@pytest.fixture(scope="module")
+def engine(weights):
+    e = _capi.Engine(build_graph(6, 224), weights, device=0, dtype="f32", max_batch=8, taps=True)
+    yield e
+    e.close()
+
+
+def test_library_sees_a_gpu():
+    assert _capi.device_count() >= 1
+
+
+def test_logits_probs_ids_vs_golden(engine, parity_images, golden_parity):
+    ids, probs = engine.forward_u8(parity_images)           # 40 images, chunks of max_batch
+    logits = engine.tap("d3.relu", 8)                        # last chunk
+    np.testing.assert_allclose(logits, golden_parity["logits_f64"][32:40], atol=TOL_LOGITS, rtol=0)
+    np.testing.assert_allclose(probs, golden_parity["probs_f64"], atol=TOL_PROBS, rtol=0)
+    safe = golden_parity["top2_margin"] > MARGIN
+    np.testing.assert_array_equal(ids[safe], golden_parity["ids"][safe])
+    assert ids.dtype == np.int64 and probs.dtype == np.float32
+    np.testing.assert_allclose(probs.sum(1), 1.0, atol=1e-5)
+
+
+def test_every_node_vs_oracle_full_tensors(engine, weights, parity_images):
+    idx = [14, 30]
+    ims = parity_images[idx]
+    ref = c_oracle.infer(weights, ims, taps=True)
+    ids, probs = engine.forward_u8(ims)
+    names = R.node_names()
+    assert set(names) == set(engine.nodes())
+    for name in names:
+        got = engine.tap(name, len(idx))
+        want = np.asarray(ref["taps"][name])
+        assert got.shape == want.shape, name
+        tol = 1e-4 * max(float(np.abs(want).max()), 1e-3)
+        np.testing.assert_allclose(got, want, atol=tol, rtol=0, err_msg=name)
+    np.testing.assert_array_equal(ids, ref["ids"])
+
+
+def test_taps_vs_committed_golden(engine, parity_images, golden_taps):
+    i = int(golden_taps["image_index"])
+    engine.forward_u8(parity_images[i:i + 1])
+    for name in R.node_names():
+        v = engine.tap(name, 1)[0].ravel().astype(np.float64)
+        absmax = float(golden_taps[name + "|absmax"])
+        tol = 1e-4 * max(absmax, 1e-3)
+        np.testing.assert_allclose(v[sample_positions(v.size)], golden_taps[name + "|samples"], atol=tol, rtol=0,
+                                   err_msg=name)
+        assert abs(v.mean() - float(golden_taps[name + "|mean"])) <= tol, name
+
+
+def test_batch_one_equals_batched(engine, parity_images):
+    ims = parity_images[[3, 17, 26]]
+    ids_b, probs_b = engine.forward_u8(ims)
+    for i in range(3):
+        ids_1, probs_1 = engine.forward_u8(ims[i:i + 1])
+        np.testing.assert_array_equal(probs_1[0], probs_b[i])      # bit-identical: no cross-image coupling
+        assert ids_1[0] == ids_b[i]
+
+
+def test_f32_entry_point_equals_u8_entry_point(engine, parity_images):
+    ims = parity_images[[8, 21]]
+    ids_u, probs_u = engine.forward_u8(ims)
+    ids_f, probs_f = engine.forward_f32(R.preprocess_batch(ims))
+    np.testing.assert_array_equal(probs_u, probs_f)
+    np.testing.assert_array_equal(ids_u, ids_f)
+    np.testing.assert_array_equal(engine.tap("input", 2), R.preprocess_batch(ims))
+
+
+def test_device_resident_entry_point(engine, parity_images):
+    ims = np.ascontiguousarray(parity_images[[0, 12, 38]])
+    d_in = engine.device_malloc(ims.nbytes)
+    d_probs = engine.device_malloc(3 * 6 * 4)
+    d_ids = engine.device_malloc(3 * 8)
+    try:
+        engine.h2d(d_in, ims)
+        engine.forward_u8_device(d_in, 3, d_probs, d_ids)
+        engine.sync()
+        probs = np.empty((3, 6), np.float32)
+        ids = np.empty(3, np.int64)
+        engine.d2h(probs, d_probs)
+        engine.d2h(ids, d_ids)
+    finally:
+        for p in (d_in, d_probs, d_ids):
+            engine.device_free(p)
+    ids_h, probs_h = engine.forward_u8(ims)
+    np.testing.assert_array_equal(probs, probs_h)
+    np.testing.assert_array_equal(ids, ids_h)
+
+
+def test_argmax_ties_resolve_to_lowest_index(engine, weights):
+    # a solid black image lands on exact 0.0 ties among the non-max logits; make sure the
+    # winner follows tf.argmax (lowest index) whenever the top logits tie exactly
+    ims = np.zeros((1, 224, 224, 3), np.uint8)
+    ids, probs = engine.forward_u8(ims)
+    assert ids[0] == int(np.flatnonzero(probs[0] == probs[0].max())[0])
+
+
+def test_error_conventions(engine, weights):
+    with pytest.raises(ValueError):
+        engine.forward_u8(np.zeros((1, 100, 100, 3), np.uint8))
+    lib = engine.lib
+    probs = np.empty((9, 6), np.float32)
+    ids = np.empty(9, np.int64)
+    ims = np.zeros((9, 224, 224, 3), np.uint8)
+    rc = lib.rn_forward_u8(engine.handle, ims.ctypes.data, 9, probs.ctypes.data, ids.ctypes.data)
+    assert rc == -5 and b"max_batch" in lib.rn_last_error()
+    rc = lib.rn_forward_u8(engine.handle, None, 1, probs.ctypes.data, ids.ctypes.data)
+    assert rc == -1
+    with pytest.raises(ValueError):
+        _capi.Engine(build_graph(6, 224), weights, device=99)
+    with pytest.raises(ValueError):   # the 224 checkpoint does not fit a 600 graph (dense/kernel 64 vs 3136)
+        _capi.Engine(build_graph(6, 600), weights, device=0)
+    with pytest.raises(KeyError):
+        bad = dict(weights)
+        del bad["conv2d_3/kernel"]
+        _capi.Engine(build_graph(6, 224), bad, device=0)
+
+
+def test_timing_is_reported(engine, parity_images):
+    engine.set_profiling(True)
+    engine.forward_u8(parity_images[:4])
+    t = engine.timing()
+    engine.set_profiling(False)
+    assert len(t["stage_ms"]) == 10 and all(x > 0 for x in t["stage_ms"]) and t["total_ms"] > 0
+    assert engine.dominant_stage() == 4
+
+
+def test_scratch_sharing_handle_matches_tap_handle(weights, parity_images, engine):
+    e2 = _capi.Engine(build_graph(6, 224), weights, device=0, dtype="f32", max_batch=4, taps=False)
+    try:
+        ims = parity_images[[5, 15, 25, 35]]
+        ids2, probs2 = e2.forward_u8(ims)
+        ids1, probs1 = engine.forward_u8(ims)
+        np.testing.assert_array_equal(probs1, probs2)
+        np.testing.assert_array_equal(e2.tap("s3.bn2", 4), engine.tap("s3.bn2", 4))
+        with pytest.raises(_capi.RoomNetLibraryError):
+            e2.tap("s3.conv", 4)
+    finally:
+        e2.close()

@@ -1,0 +1,185 @@
+"""The oracle (oracle/*) checked against the committed goldens, against itself
+(NumPy vs plain C) and against an independent torch-CPU restatement.
+
+TF parity is unpinned (TensorFlow 1.13.1 is not installable here and the reference
+holds no golden vectors); these tests pin the oracle structurally and by
+cross-implementation agreement."""
+import numpy as np
+import pytest
+
+from conftest import sample_positions
+from oracle import c_oracle, roomnet_ref as R
+
+TOL_LOGITS_F32 = 1e-4     # fp32 restatements vs fp64 truth
+TOL_PROBS_F32 = 1e-5
+
+
+def test_preprocess_is_the_reference_expression():
+    v = np.arange(256, dtype=np.uint8).reshape(1, 16, 16, 1).repeat(3, axis=3)
+    v[..., 1] = v[..., 1][..., ::-1]
+    v = np.ascontiguousarray(v)
+    ref = (((v[..., [2, 1, 0]] / 255.) * 2) - 1).astype(np.float32)
+    np.testing.assert_array_equal(R.preprocess_batch(v), ref)
+    np.testing.assert_array_equal(c_oracle.preprocess(v), ref)
+    assert ref.min() == -1.0 and ref.max() == 1.0
+
+
+def test_center_crop_matches_reference_cases():
+    x = np.arange(4 * 7 * 3).reshape(4, 7, 3)
+    out = R.center_crop(x)                     # h < w: offset = abs((7-4)//2) = 1
+    np.testing.assert_array_equal(out, x[:, 1:5, :])
+    y = np.arange(7 * 4 * 3).reshape(7, 4, 3)  # w < h: (4-7)//2 = -2 -> abs = 2 (floor division!)
+    np.testing.assert_array_equal(R.center_crop(y), y[2:6, :, :])
+    z = np.arange(5 * 5 * 3).reshape(5, 5, 3)
+    np.testing.assert_array_equal(R.center_crop(z), z)
+    assert R.center_crop(z) is not z
+
+
+def test_legacy_resize_tables():
+    # 21 -> 2: scale 10.5, src = 0, 10.5
+    lo, hi, lerp = R.resize_tables(21, 2)
+    assert lo.tolist() == [0, 10] and hi.tolist() == [1, 11]
+    np.testing.assert_allclose(lerp, [0.0, 0.5])
+    lo, hi, lerp = R.resize_tables(100, 48)
+    assert lo[-1] == int(np.float32(47) * (np.float32(100) / np.float32(48)))
+    assert hi.max() <= 99 and (hi - lo).max() == 1
+    # identity when sizes match
+    x = np.random.default_rng(0).standard_normal((1, 5, 5, 2)).astype(np.float32)
+    np.testing.assert_array_equal(R.resize_bilinear_legacy(x, 5), x)
+    # upper index clamps at the border
+    lo, hi, lerp = R.resize_tables(4, 8)
+    assert hi[-1] == 3 and lo[-1] == 3
+
+
+def test_numpy_f32_matches_golden_f64(weights, parity_images, golden_parity):
+    idx = [0, 1, 9, 14, 22, 27, 30, 35]
+    r = R.infer(weights, parity_images[idx], np.float32)
+    np.testing.assert_allclose(r["logits"], golden_parity["logits_f64"][idx], atol=TOL_LOGITS_F32, rtol=0)
+    np.testing.assert_allclose(r["probs"], golden_parity["probs_f64"][idx], atol=TOL_PROBS_F32, rtol=0)
+    safe = golden_parity["top2_margin"][idx] > 1e-3
+    np.testing.assert_array_equal(r["ids"][safe], golden_parity["ids"][idx][safe])
+    np.testing.assert_allclose(r["logits"], golden_parity["logits_f32"][idx], atol=2e-5, rtol=0)
+
+
+def test_c_oracle_matches_golden_and_numpy(weights, parity_images, golden_parity):
+    idx = [2, 5, 11, 14, 19, 25, 33, 39]
+    rc = c_oracle.infer(weights, parity_images[idx])
+    np.testing.assert_allclose(rc["logits"], golden_parity["logits_f64"][idx], atol=TOL_LOGITS_F32, rtol=0)
+    np.testing.assert_allclose(rc["probs"], golden_parity["probs_f64"][idx], atol=TOL_PROBS_F32, rtol=0)
+    safe = golden_parity["top2_margin"][idx] > 1e-3
+    np.testing.assert_array_equal(rc["ids"][safe], golden_parity["ids"][idx][safe])
+    assert rc["ids"].dtype == np.int64 and rc["probs"].dtype == np.float32
+
+
+def test_golden_set_is_not_degenerate(golden_parity):
+    assert set(golden_parity["ids"].tolist()) >= {0, 1, 2}
+    lg = golden_parity["logits_f64"]
+    assert (lg == 6.0).any() and (lg == 0.0).any()      # both clamps of the final ReLU6
+    assert (golden_parity["top2_margin"] > 0.2).sum() >= 25
+
+
+def test_per_node_taps_match_golden(weights, parity_images, golden_taps):
+    i = int(golden_taps["image_index"])
+    rc = c_oracle.infer(weights, parity_images[i:i + 1], taps=True)
+    rn = R.infer(weights, parity_images[i:i + 1], np.float32, taps=True)
+    names = R.node_names()
+    assert len(names) == 49
+    for name in names:
+        absmax = float(golden_taps[name + "|absmax"])
+        tol = 1e-4 * max(absmax, 1e-3)
+        for taps in (rc["taps"], rn["taps"]):
+            v = np.asarray(taps[name])[0]
+            assert list(v.shape) == golden_taps[name + "|shape"].tolist(), name
+            flat = v.ravel().astype(np.float64)
+            np.testing.assert_allclose(flat[sample_positions(flat.size)], golden_taps[name + "|samples"],
+                                       atol=tol, rtol=0, err_msg=name)
+            assert abs(flat.mean() - float(golden_taps[name + "|mean"])) <= tol, name
+            assert abs(np.abs(flat).max() - absmax) <= tol, name
+
+
+def test_argmax_lowest_index_on_ties():
+    x = np.array([[0.2, 0.2, 0.1], [0.0, 0.5, 0.5]], np.float32)
+    out = np.empty(2, np.int64)
+    c_oracle.lib().rn_ref_argmax(c_oracle._p(x), c_oracle._p(out), 2, 3)
+    assert out.tolist() == [0, 1]
+    assert np.argmax(x, axis=-1).tolist() == [0, 1]
+
+
+def test_torch_cpu_cross_check(weights, parity_images):
+    """Third, independent restatement with torch-CPU library ops."""
+    torch = pytest.importorskip("torch")
+    import torch.nn.functional as F
+    torch.set_num_threads(4)
+    idx = [14, 30]
+    x = torch.from_numpy(R.preprocess_batch(parity_images[idx])).permute(0, 3, 1, 2).contiguous()
+    w = {k: torch.from_numpy(np.asarray(v)) for k, v in weights.items()}
+
+    def nm(base, i):
+        return base if i == 0 else "%s_%d" % (base, i)
+
+    state = {"conv": 0, "bn": 0}
+
+    def bn(t):
+        n = nm("batch_normalization", state["bn"])
+        state["bn"] += 1
+        inv = torch.rsqrt(w[n + "/moving_variance"] + 1e-3) * w[n + "/gamma"]
+        shape = (1, -1, 1, 1) if t.dim() == 4 else (1, -1)
+        if t.dim() == 4:
+            return (t - w[n + "/moving_mean"].view(shape)) * inv.view(shape) + w[n + "/beta"].view(shape)
+        return t * inv.view(shape) + (w[n + "/beta"] - w[n + "/moving_mean"] * inv).view(shape)
+
+    def legacy_resize(t, out):
+        _, _, h, wd = t.shape
+        ylo, yhi, yl = R.resize_tables(h, out)
+        xlo, xhi, xl = R.resize_tables(wd, out)
+        yl = torch.from_numpy(yl).view(1, 1, -1, 1)
+        xl = torch.from_numpy(xl).view(1, 1, 1, -1)
+        rows0, rows1 = t[:, :, torch.from_numpy(ylo)], t[:, :, torch.from_numpy(yhi)]
+        xlo_t, xhi_t = torch.from_numpy(xlo), torch.from_numpy(xhi)
+        top = rows0[..., xlo_t] + (rows0[..., xhi_t] - rows0[..., xlo_t]) * xl
+        bot = rows1[..., xlo_t] + (rows1[..., xhi_t] - rows1[..., xlo_t]) * xl
+        return top + (bot - top) * yl
+
+    def block(t, pooling=True, k=3, s=1, depth=1):
+        first = None
+        for d in range(depth):
+            kern = w[nm("conv2d", state["conv"]) + "/kernel"].permute(3, 2, 0, 1).contiguous()
+            state["conv"] += 1
+            t = torch.clamp(F.conv2d(t, kern), 0.0, 6.0)
+            if pooling:
+                t = F.avg_pool2d(t, k, s)
+            t = bn(t)
+            if d == 0:
+                first = t
+        if depth > 1:
+            t = bn(t + legacy_resize(first, t.shape[2]))
+        return t
+
+    with torch.no_grad():
+        t = block(x)
+        t = block(t, k=4, s=1, depth=3)
+        t = block(t, k=4, s=2, depth=2)
+        t = block(t, pooling=False)
+        t = block(t, k=4, s=2, depth=3)
+        t = t.permute(0, 2, 3, 1).reshape(t.shape[0], -1)
+        for i in range(3):
+            t = bn(torch.clamp(t @ w[nm("dense", i) + "/kernel"], 0.0, 6.0))
+        logits = torch.clamp(t @ w["dense_3/kernel"] + w["dense_3/bias"], 0.0, 6.0)
+        probs = torch.softmax(logits, dim=-1)
+    rc = c_oracle.infer(weights, parity_images[idx])
+    np.testing.assert_allclose(logits.numpy(), rc["logits"], atol=TOL_LOGITS_F32, rtol=0)
+    np.testing.assert_allclose(probs.numpy(), rc["probs"], atol=TOL_PROBS_F32, rtol=0)
+    np.testing.assert_array_equal(probs.argmax(-1).numpy(), rc["ids"])
+
+
+def test_600_variant_golden(weights):
+    import os
+    from conftest import GOLDEN
+    from roomnet_amd.synth import parity_batch
+    g = np.load(os.path.join(GOLDEN, "parity_600.npz"))
+    w = dict(weights)
+    w["dense/kernel"] = R.synth_dense_kernel_600()
+    i = int(g["image_indices"][1])
+    im = parity_batch(600, seed=1)[i:i + 1]
+    rc = c_oracle.infer(w, im)
+    np.testing.assert_allclose(rc["logits"], g["logits_f64"][1:2], atol=TOL_LOGITS_F32, rtol=0)
