@@ -481,6 +481,7 @@ extern "C" void rn_destroy(rn_handle* h) {
     for (auto e : h->events)
         if (e) (void)hipEventDestroy(e);
     for (void* p : h->allocs) (void)hipFree(p);
+    rn_fused_release(h);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
     delete h;
 }

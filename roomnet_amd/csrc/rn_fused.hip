@@ -1,9 +1,738 @@
+// Fused 16-bit execution path (RN_DTYPE_BF16 / RN_DTYPE_F16): one launch per conv stage.
+//
+// A stage is   conv3x3 VALID s1 (no bias) -> ReLU6 -> [avg-pool k x k / s] -> BN
+//              -> [ + legacy-bilinear(skip) -> BN ]          (reference network.py:172-208)
+// Activations live in HBM as NHWC 16-bit tensors; a stage reads its input once and
+// writes its post-BN output once (the stage-boundary traffic model of SURVEY.md 8d).
+// Accumulation, ReLU6, pooling, BN and the residual are float32 in registers.
+//
+// Kernel structure (stages 1..N, `stage_mfma_kernel`):
+//   * a workgroup owns one image, one band of output rows and one block of columns and
+//     walks down its band one conv row per iteration ("row streaming"): the last
+//     3 input rows live in an LDS ring, the next row is prefetched into registers while
+//     the current one is computed -- every input row is fetched once per band.
+//   * implicit GEMM on the matrix cores, D[cout][pixel] = W^T[cout][k] * im2col[k][pixel]
+//     with v_mfma_f32_32x32x16_{bf16,f16}: a wave owns a tile of 32 consecutive conv
+//     columns; the B operand (8 consecutive channels of one tap of one pixel = 16 B) is a
+//     single ds_read_b128 from the NHWC ring, made bank-conflict free by XOR-swizzling the
+//     16-byte channel chunk inside each pixel; the A operand (weights) is pre-packed on
+//     the host in fragment order and read from LDS with lane-linear ds_read_b128.
+//   * the accumulator layout puts the pixel on the lane and the channel in the
+//     register, so ReLU6 is per register, the horizontal pool sum is two DPP wave shifts
+//     per register, the vertical pool sum is a register ring across iterations, BN is
+//     an fma, and the pooled tile never touches LDS or HBM before its final store.
+//   * neighbouring pixel tiles overlap by k-1 columns so that no cross-wave exchange is
+//     needed for the horizontal pool.
+// Stage 0 (3 input channels, K = 27) is not GEMM-shaped: `stage0_kernel` is a direct
+// VALU kernel that also fuses the uint8 -> [-1,1] pre-processing table.
 #include "rn_fused.h"
-int rn_fused_prepare(rn_handle*, const rn_weights*) {
-    rn_set_error("16-bit fused path not built yet");
-    return RN_E_INVALID;
+
+#include <cmath>
+#include <cstring>
+
+namespace {
+
+using i32x4 = __attribute__((ext_vector_type(4))) int;
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
+
+template <int DT>
+__device__ __forceinline__ f32x16 mfma32(i32x4 a, i32x4 b, f32x16 c) {
+    if constexpr (DT == RN_DTYPE_BF16)
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b),
+                                                       c, 0, 0, 0);
+    else
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c,
+                                                      0, 0, 0);
 }
-int rn_fused_forward(rn_handle*, const uint8_t*, const float*, int, float*, int64_t*) {
-    rn_set_error("16-bit fused path not built yet");
-    return RN_E_INVALID;
+
+template <int DT>
+__device__ __forceinline__ unsigned short to16(float v) {
+    if constexpr (DT == RN_DTYPE_BF16)
+        return __builtin_bit_cast(unsigned short, static_cast<__bf16>(v));
+    else
+        return __builtin_bit_cast(unsigned short, static_cast<_Float16>(v));
+}
+
+template <int DT>
+__device__ __forceinline__ float from16(unsigned short u) {
+    if constexpr (DT == RN_DTYPE_BF16)
+        return __uint_as_float(static_cast<unsigned>(u) << 16);
+    else
+        return static_cast<float>(__builtin_bit_cast(_Float16, u));
+}
+
+template <int DT>
+__device__ __forceinline__ uint2 pack4(float a, float b, float c, float d) {
+    uint2 r;
+    r.x = static_cast<unsigned>(to16<DT>(a)) | (static_cast<unsigned>(to16<DT>(b)) << 16);
+    r.y = static_cast<unsigned>(to16<DT>(c)) | (static_cast<unsigned>(to16<DT>(d)) << 16);
+    return r;
+}
+
+template <int DT>
+__device__ __forceinline__ f32x4 unpack4(uint2 v) {
+    f32x4 r;
+    r[0] = from16<DT>(static_cast<unsigned short>(v.x & 0xffff));
+    r[1] = from16<DT>(static_cast<unsigned short>(v.x >> 16));
+    r[2] = from16<DT>(static_cast<unsigned short>(v.y & 0xffff));
+    r[3] = from16<DT>(static_cast<unsigned short>(v.y >> 16));
+    return r;
+}
+
+// value of lane+1 (DPP wave shift left by one; lane 63 reads 0)
+__device__ __forceinline__ float lane_next(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130, 0xf, 0xf, false));
+}
+
+__device__ __forceinline__ float relu6f(float v) { return __builtin_amdgcn_fmed3f(v, 0.f, 6.f); }
+
+// ------------------------------------------------------------------------------ stage 0
+// uint8 BGR [N,S,S,3] -> table -> conv3x3 (3->COUT0) -> ReLU6 -> avg-pool 3x3/1 -> BN -> 16-bit NHWC.
+// Output tile 32 x 8 pixels per 256-thread workgroup.
+constexpr int S0_TW = 32, S0_TH = 8, S0_CO = 8;
+
+template <int DT>
+__global__ __launch_bounds__(256) void stage0_kernel(const uint8_t* __restrict__ bgr,
+                                                     const float* __restrict__ lut,
+                                                     const float* __restrict__ w,   // [3][3][3][8] HWIO
+                                                     const float* __restrict__ bn_mean,
+                                                     const float* __restrict__ bn_inv,
+                                                     const float* __restrict__ bn_beta,
+                                                     unsigned short* __restrict__ out, int S, int So) {
+    constexpr int CW = S0_TW + 2, CH = S0_TH + 2;     // conv tile 34 x 10
+    constexpr int IW = CW + 2, IH = CH + 2;           // input tile 36 x 12
+    __shared__ float s_in[3][IH][IW];
+    __shared__ __attribute__((aligned(16))) float s_conv[CH][CW][S0_CO];
+    const int n = blockIdx.z;
+    const int ox0 = blockIdx.x * S0_TW, oy0 = blockIdx.y * S0_TH;
+    const int tid = threadIdx.x;
+    const uint8_t* img = bgr + static_cast<int64_t>(n) * S * S * 3;
+    for (int p = tid; p < IW * IH; p += 256) {
+        const int ix = p % IW, iy = p / IW;
+        const int gx = ox0 + ix, gy = oy0 + iy;
+        float r = 0.f, g = 0.f, b = 0.f;
+        if (gx < S && gy < S) {
+            const uint8_t* px = img + (static_cast<int64_t>(gy) * S + gx) * 3;
+            b = lut[px[0]];
+            g = lut[px[1]];
+            r = lut[px[2]];
+        }
+        s_in[0][iy][ix] = r;
+        s_in[1][iy][ix] = g;
+        s_in[2][iy][ix] = b;
+    }
+    __syncthreads();
+    for (int p = tid; p < CW * CH; p += 256) {
+        const int cx = p % CW, cy = p / CW;
+        float acc[S0_CO];
+#pragma unroll
+        for (int o = 0; o < S0_CO; ++o) acc[o] = 0.f;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const float v = s_in[c][cy + ky][cx + kx];
+                    const float* wr = w + ((ky * 3 + kx) * 3 + c) * S0_CO;
+#pragma unroll
+                    for (int o = 0; o < S0_CO; ++o) acc[o] = fmaf(v, wr[o], acc[o]);
+                }
+#pragma unroll
+        for (int o = 0; o < S0_CO; ++o) s_conv[cy][cx][o] = relu6f(acc[o]);
+    }
+    __syncthreads();
+    const int tx = tid % S0_TW, ty = tid / S0_TW;
+    const int ox = ox0 + tx, oy = oy0 + ty;
+    if (ox < So && oy < So) {
+        float acc[S0_CO];
+#pragma unroll
+        for (int o = 0; o < S0_CO; ++o) acc[o] = 0.f;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const f32x4 a = *reinterpret_cast<const f32x4*>(&s_conv[ty + ky][tx + kx][0]);
+                const f32x4 b = *reinterpret_cast<const f32x4*>(&s_conv[ty + ky][tx + kx][4]);
+#pragma unroll
+                for (int o = 0; o < 4; ++o) {
+                    acc[o] += a[o];
+                    acc[4 + o] += b[o];
+                }
+            }
+        float y[S0_CO];
+#pragma unroll
+        for (int o = 0; o < S0_CO; ++o) y[o] = (acc[o] / 9.0f - bn_mean[o]) * bn_inv[o] + bn_beta[o];
+        const uint2 lo = pack4<DT>(y[0], y[1], y[2], y[3]);
+        const uint2 hi = pack4<DT>(y[4], y[5], y[6], y[7]);
+        uint4 v;
+        v.x = lo.x;
+        v.y = lo.y;
+        v.z = hi.x;
+        v.w = hi.y;
+        *reinterpret_cast<uint4*>(out + ((static_cast<int64_t>(n) * So + oy) * So + ox) * S0_CO) = v;
+    }
+}
+
+// ------------------------------------------------------------------------ MFMA stage
+struct StageArgs {
+    const unsigned short* in;     // [N, H, W, CIN]
+    unsigned short* out;          // [N, Ho, Wo, COUT]
+    const i32x4* wfrag;           // [KC][CT][64] fragments of 8 x 16-bit
+    const float* bn_mean;
+    const float* bn_inv;
+    const float* bn_beta;
+    const unsigned short* skip;   // [N, Ss, Ss, COUT] (residual stages)
+    const float* bn2_mean;
+    const float* bn2_inv;
+    const float* bn2_beta;
+    const int32_t* rlo;           // legacy bilinear tables, [Ho]
+    const int32_t* rhi;
+    const float* rlerp;
+    int H, W;                     // input rows / cols
+    int Ho, Wo;                   // output rows / cols
+    int Ss;                       // skip side
+    int rows_per_band, n_bands, n_colblocks, n_ctg, npt;
+};
+
+template <int CIN>
+struct StageGeom {
+    static constexpr int CP = CIN / 8;                               // 16-byte chunks per pixel
+    static constexpr int K = 9 * CIN;
+    static constexpr int KC = (K + 15) / 16;                         // 16-deep K chunks
+    static constexpr int PIX_PER_BANKROW = CP >= 16 ? 1 : 16 / CP;   // pixels per 256-byte LDS bank row
+    static constexpr int LPT = (34 * CP + 63) / 64;                  // ring-row chunks a thread prefetches
+};
+
+constexpr int NSLOT = 4;   // LDS ring: 3 live input rows + 1 being filled
+
+__host__ __device__ constexpr int tile_nout(int pk, int ps) { return pk ? (32 - pk) / ps + 1 : 32; }
+__host__ __device__ constexpr int tile_stride(int pk, int ps) { return pk ? tile_nout(pk, ps) * ps : 32; }
+
+// chunk swizzle: XOR the 16-byte chunk index inside a pixel with a function of the pixel
+// column so that 16 consecutive pixels reading the same chunk index hit 16 distinct
+// 16-byte slots of the 256-byte LDS bank row.
+template <int CP>
+__device__ __forceinline__ int chunk_swz(int pix) {
+    if constexpr (CP == 1)
+        return 0;
+    else if constexpr (CP >= 16)
+        return pix & 15;
+    else
+        return (pix / (16 / CP)) & (CP - 1);
+}
+
+template <int DT, int CIN, int COUT, int PK, int PS, bool RES, int CTW>
+__global__ __launch_bounds__(512) void stage_mfma_kernel(const StageArgs a) {
+    using G = StageGeom<CIN>;
+    constexpr int CP = G::CP, KC = G::KC, LPT = G::LPT;
+    constexpr int CT = (COUT + 31) / 32;                 // 32-wide cout tiles in the stage
+    constexpr int NG = COUT >= 32 ? 4 : COUT / 8;        // groups of 4 consecutive couts per lane half-row
+    constexpr int TSTRIDE = tile_stride(PK, PS);
+    constexpr int NOUT_T = tile_nout(PK, PS);
+    constexpr int RING = PK ? PK - 1 : 0;
+    constexpr int PIXB = CIN * 2;                        // bytes per pixel
+    static_assert(CIN % 8 == 0 && COUT % 8 == 0, "channels must be multiples of 8");
+    static_assert(CT % CTW == 0, "cout tiles must split evenly over workgroups");
+    static_assert(!PK || PS == 1 || PS == 2, "pool stride 1 or 2");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, hh = lane >> 5;
+    const int nthreads = blockDim.x;
+    const int npt = a.npt;
+
+    int bid = blockIdx.x;
+    const int ctg = bid % a.n_ctg;
+    bid /= a.n_ctg;
+    const int cb = bid % a.n_colblocks;
+    const int band = bid / a.n_colblocks;
+    const int n = blockIdx.y;
+
+    const int ringcols = (npt - 1) * TSTRIDE + 34;
+    const int rowbytes = ringcols * PIXB;
+    char* const wl = smem;                                  // weights [KC][CTW][64] x 16 B
+    char* const ring = smem + KC * CTW * 1024;              // NSLOT rows
+
+    // rows of this band
+    const int yo0 = band * a.rows_per_band;
+    const int yo1 = min(a.Ho, yo0 + a.rows_per_band);
+    const int yc0 = PK ? yo0 * PS : yo0;
+    const int nconv = PK ? (yo1 - yo0 - 1) * PS + PK : (yo1 - yo0);
+    const int nin = nconv + 2;
+    // columns of this block
+    const int x0c = cb * npt * TSTRIDE;                     // first conv / input column of the block
+    const int xo_blk0 = PK ? x0c / PS : x0c;
+
+    // ---- weights -> LDS (fragment order, lane linear)
+    {
+        const i32x4* src = a.wfrag;
+        for (int i = tid; i < KC * CTW * 64; i += nthreads) {
+            const int l = i & 63, t = i >> 6;
+            const int ct = t % CTW, kc = t / CTW;
+            reinterpret_cast<i32x4*>(wl)[i] = src[(kc * CT + ctg * CTW + ct) * 64 + l];
+        }
+    }
+
+    // ---- input-row loader: thread owns up to LPT 16-byte chunks of a ring row
+    const int nchunks = ringcols * CP;
+    const unsigned short* const in_img = a.in + static_cast<int64_t>(n) * a.H * a.W * CIN;
+    int ld_goff[LPT];     // element offset inside an input row, or -1 (zero fill / not mine)
+    int ld_loff[LPT];     // byte offset inside a ring row
+#pragma unroll
+    for (int i = 0; i < LPT; ++i) {
+        const int q = tid + i * nthreads;
+        const int p = q / CP, c8 = q % CP;
+        ld_loff[i] = q < nchunks ? (p * CP + (c8 ^ chunk_swz<CP>(p))) * 16 : -1;
+        ld_goff[i] = (q < nchunks && x0c + p < a.W) ? (x0c + p) * CIN + c8 * 8 : -1;
+    }
+    i32x4 pre[LPT];
+    auto fetch_row = [&](int j) {   // input row yc0 + j -> registers
+        const unsigned short* row = in_img + static_cast<int64_t>(yc0 + j) * a.W * CIN;
+#pragma unroll
+        for (int i = 0; i < LPT; ++i) {
+            i32x4 v = {0, 0, 0, 0};
+            if (ld_goff[i] >= 0) v = *reinterpret_cast<const i32x4*>(row + ld_goff[i]);
+            pre[i] = v;
+        }
+    };
+    auto store_row = [&](int j) {   // registers -> ring slot j % NSLOT
+        char* dst = ring + (j & (NSLOT - 1)) * rowbytes;
+#pragma unroll
+        for (int i = 0; i < LPT; ++i)
+            if (ld_loff[i] >= 0) *reinterpret_cast<i32x4*>(dst + ld_loff[i]) = pre[i];
+    };
+    for (int j = 0; j < 3; ++j) {
+        fetch_row(j);
+        store_row(j);
+    }
+    __syncthreads();
+
+    // ---- per-lane constants of this wave's pixel tile
+    const int xrel0 = wave * TSTRIDE + r;             // ring column of conv column (tap kx = 0)
+    int boff[3];                                      // byte offset of pixel (xrel0 + kx) chunk 0
+    int bswz[3];
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+        boff[kx] = (xrel0 + kx) * PIXB;
+        bswz[kx] = chunk_swz<CP>(xrel0 + kx);
+    }
+    const int xc = x0c + xrel0;                       // conv column of this lane
+    const int xo = PK ? xc / PS : xc;                 // output column of this lane
+    const bool lane_out = (PK ? (r % PS == 0 && r <= 32 - PK) : true) && xo < a.Wo &&
+                          (xo - xo_blk0) < npt * NOUT_T;
+    const int cout_lane = ctg * CTW * 32 + 4 * hh;    // + ct*32 + 8*g + j
+
+    int rx_lo = 0, rx_hi = 0;
+    float rx_l = 0.f;
+    if constexpr (RES) {
+        const int xq = min(xo, a.Wo - 1);
+        rx_lo = a.rlo[xq];
+        rx_hi = a.rhi[xq];
+        rx_l = a.rlerp[xq];
+    }
+
+    float vring[RING > 0 ? RING : 1][CTW][16];
+#pragma unroll
+    for (int i = 0; i < (RING > 0 ? RING : 1); ++i)
+#pragma unroll
+        for (int ct = 0; ct < CTW; ++ct)
+#pragma unroll
+            for (int g = 0; g < 16; ++g) vring[i][ct][g] = 0.f;
+
+    const char* const wl_lane = wl + lane * 16;
+
+    for (int it = 0; it < nconv; ++it) {
+        const bool have_next = it + 3 < nin;
+        if (have_next) fetch_row(it + 3);
+
+        // ---------------- implicit GEMM for conv row yc0 + it
+        f32x16 acc[CTW];
+#pragma unroll
+        for (int ct = 0; ct < CTW; ++ct)
+#pragma unroll
+            for (int g = 0; g < 16; ++g) acc[ct][g] = 0.f;
+
+        const char* rowp[3];
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) rowp[ky] = ring + ((it + ky) & (NSLOT - 1)) * rowbytes;
+
+        if constexpr (CIN >= 16) {
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int ky = tap / 3, kx = tap % 3;
+                const char* pb = rowp[ky] + boff[kx];
+#pragma unroll
+                for (int cc = 0; cc < CIN / 16; ++cc) {
+                    const int kc = tap * (CIN / 16) + cc;
+                    const int c8 = cc * 2 + hh;
+                    const i32x4 b = *reinterpret_cast<const i32x4*>(pb + ((c8 ^ bswz[kx]) << 4));
+#pragma unroll
+                    for (int ct = 0; ct < CTW; ++ct) {
+                        const i32x4 wv = *reinterpret_cast<const i32x4*>(wl_lane + (kc * CTW + ct) * 1024);
+                        acc[ct] = mfma32<DT>(wv, b, acc[ct]);
+                    }
+                }
+            }
+        } else {
+            // CIN == 8: a 16-deep chunk spans two taps; the lane half selects the tap
+#pragma unroll
+            for (int kc = 0; kc < KC; ++kc) {
+                int tap = 2 * kc + hh;
+                tap = tap > 8 ? 8 : tap;                      // K padded 72 -> 80: weights are zero there
+                const int ky = tap / 3, kx = tap - ky * 3;
+                const char* pb = ring + ((it + ky) & (NSLOT - 1)) * rowbytes + (xrel0 + kx) * PIXB;
+                const i32x4 b = *reinterpret_cast<const i32x4*>(pb);
+#pragma unroll
+                for (int ct = 0; ct < CTW; ++ct) {
+                    const i32x4 wv = *reinterpret_cast<const i32x4*>(wl_lane + (kc * CTW + ct) * 1024);
+                    acc[ct] = mfma32<DT>(wv, b, acc[ct]);
+                }
+            }
+        }
+
+        // ---------------- ReLU6 + horizontal pool sum (lanes) + vertical pool sum (register ring)
+        const int lrow = it;
+        bool emit;
+        int yo;
+        if constexpr (PK > 0) {
+            emit = lrow >= PK - 1 && ((lrow - (PK - 1)) % PS) == 0;
+            yo = yo0 + (lrow - (PK - 1)) / PS;
+        } else {
+            emit = true;
+            yo = yo0 + lrow;
+        }
+#pragma unroll
+        for (int ct = 0; ct < CTW; ++ct) {
+            float hs[16];
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                const float v = relu6f(acc[ct][g]);
+                if constexpr (PK == 4) {
+                    const float t = v + lane_next(v);
+                    hs[g] = t + lane_next(lane_next(t));
+                } else if constexpr (PK == 3) {
+                    const float v1 = lane_next(v);
+                    hs[g] = (v + v1) + lane_next(v1);
+                } else if constexpr (PK == 2) {
+                    hs[g] = v + lane_next(v);
+                } else {
+                    hs[g] = v;
+                }
+            }
+            float tot[16];
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                float s = hs[g];
+                if constexpr (RING > 0) {
+                    float t = vring[0][ct][g];
+#pragma unroll
+                    for (int i = 1; i < RING; ++i) t += vring[i][ct][g];
+                    s = t + s;
+#pragma unroll
+                    for (int i = 0; i + 1 < RING; ++i) vring[i][ct][g] = vring[i + 1][ct][g];
+                    vring[RING - 1][ct][g] = hs[g];
+                }
+                tot[g] = s;
+            }
+            if (emit) {
+                // ---------------- BN (+ residual + BN) + store, 4 consecutive channels at a time
+                constexpr float inv_area = PK ? 1.0f / static_cast<float>(PK * PK) : 1.0f;
+                float yl = 0.f;
+                const unsigned short* sk0 = nullptr;
+                const unsigned short* sk1 = nullptr;
+                if constexpr (RES) {
+                    const int ylo = a.rlo[yo], yhi = a.rhi[yo];
+                    yl = a.rlerp[yo];
+                    const unsigned short* skn = a.skip + static_cast<int64_t>(n) * a.Ss * a.Ss * COUT;
+                    sk0 = skn + static_cast<int64_t>(ylo) * a.Ss * COUT;
+                    sk1 = skn + static_cast<int64_t>(yhi) * a.Ss * COUT;
+                }
+                unsigned short* orow = a.out + ((static_cast<int64_t>(n) * a.Ho + yo) * a.Wo + xo) * COUT;
+#pragma unroll
+                for (int g = 0; g < NG; ++g) {
+                    const int c0 = cout_lane + ct * 32 + 8 * g;
+                    const f32x4 mean = *reinterpret_cast<const f32x4*>(a.bn_mean + c0);
+                    const f32x4 inv = *reinterpret_cast<const f32x4*>(a.bn_inv + c0);
+                    const f32x4 beta = *reinterpret_cast<const f32x4*>(a.bn_beta + c0);
+                    float y[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) y[j] = (tot[4 * g + j] * inv_area - mean[j]) * inv[j] + beta[j];
+                    if constexpr (RES) {
+                        if (lane_out) {
+                            const f32x4 tl = unpack4<DT>(*reinterpret_cast<const uint2*>(sk0 + rx_lo * COUT + c0));
+                            const f32x4 tr = unpack4<DT>(*reinterpret_cast<const uint2*>(sk0 + rx_hi * COUT + c0));
+                            const f32x4 bl = unpack4<DT>(*reinterpret_cast<const uint2*>(sk1 + rx_lo * COUT + c0));
+                            const f32x4 br = unpack4<DT>(*reinterpret_cast<const uint2*>(sk1 + rx_hi * COUT + c0));
+                            const f32x4 mean2 = *reinterpret_cast<const f32x4*>(a.bn2_mean + c0);
+                            const f32x4 inv2 = *reinterpret_cast<const f32x4*>(a.bn2_inv + c0);
+                            const f32x4 beta2 = *reinterpret_cast<const f32x4*>(a.bn2_beta + c0);
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                const float top = tl[j] + (tr[j] - tl[j]) * rx_l;
+                                const float bot = bl[j] + (br[j] - bl[j]) * rx_l;
+                                const float rs = top + (bot - top) * yl;
+                                y[j] = ((y[j] + rs) - mean2[j]) * inv2[j] + beta2[j];
+                            }
+                        }
+                    }
+                    if (lane_out) *reinterpret_cast<uint2*>(orow + c0) = pack4<DT>(y[0], y[1], y[2], y[3]);
+                }
+            }
+        }
+
+        if (have_next) store_row(it + 3);
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------- host side
+unsigned short f32_to_bf16(float f) {
+    uint32_t u;
+    std::memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return static_cast<unsigned short>((u >> 16) | 0x40);   // NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return static_cast<unsigned short>(u >> 16);
+}
+
+unsigned short f32_to_f16(float f) {
+    uint32_t x;
+    std::memcpy(&x, &f, 4);
+    const uint32_t sign = (x >> 16) & 0x8000u;
+    x &= 0x7fffffffu;
+    if (x >= 0x7f800000u) return static_cast<unsigned short>(sign | 0x7c00u | (x > 0x7f800000u ? 0x200u : 0));
+    if (x >= 0x477ff000u) return static_cast<unsigned short>(sign | 0x7c00u);          // overflow -> inf
+    if (x < 0x33000001u) return static_cast<unsigned short>(sign);                     // underflow -> 0
+    int e = static_cast<int>(x >> 23) - 127;
+    uint32_t m = (x & 0x7fffffu) | 0x800000u;
+    int shift;
+    if (e < -14) {
+        shift = 13 + (-14 - e);
+        e = -15;
+    } else {
+        shift = 13;
+    }
+    uint32_t half = m >> shift;
+    const uint32_t rem = m & ((1u << shift) - 1), halfway = 1u << (shift - 1);
+    if (rem > halfway || (rem == halfway && (half & 1))) ++half;
+    uint32_t out;
+    if (e == -15)
+        out = half;                                   // subnormal (may carry into exponent 1)
+    else
+        out = (static_cast<uint32_t>(e + 15) << 10) + (half - 0x400u);
+    return static_cast<unsigned short>(sign | out);
+}
+
+struct FusedStage {
+    int variant = -1;            // index into the dispatch table
+    int ctw = 1;                 // cout tiles per workgroup
+    int npt = 1;                 // pixel tiles (= waves) per workgroup
+    int n_colblocks = 1;
+    size_t lds_bytes = 0;
+    i32x4* wfrag = nullptr;
+};
+
+using LaunchFn = int (*)(hipStream_t, const StageArgs&, dim3, dim3, size_t);
+
+template <int DT, int CIN, int COUT, int PK, int PS, bool RES, int CTW>
+int launch_variant(hipStream_t s, const StageArgs& a, dim3 grid, dim3 block, size_t lds) {
+    auto kern = stage_mfma_kernel<DT, CIN, COUT, PK, PS, RES, CTW>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        RN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   160 * 1024));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, grid, block, lds, s, a);
+    RN_CHECK_LAUNCH();
+    return RN_OK;
+}
+
+struct Variant {
+    int cin, cout, pk, ps, res, ctw;
+    LaunchFn fn[2];   // [bf16, f16]
+};
+
+#define RN_VARIANT(CIN, COUT, PK, PS, RES, CTW)                                                   \
+    {                                                                                             \
+        CIN, COUT, PK, PS, RES, CTW, {                                                            \
+            launch_variant<RN_DTYPE_BF16, CIN, COUT, PK, PS, RES != 0, CTW>,                      \
+                launch_variant<RN_DTYPE_F16, CIN, COUT, PK, PS, RES != 0, CTW>                    \
+        }                                                                                         \
+    }
+
+const Variant kVariants[] = {
+    RN_VARIANT(8, 32, 4, 1, 0, 1),    // stage 1
+    RN_VARIANT(32, 32, 4, 1, 0, 1),   // stage 2
+    RN_VARIANT(32, 32, 4, 1, 1, 1),   // stage 3 (+ residual)
+    RN_VARIANT(32, 64, 4, 2, 0, 2),   // stage 4
+    RN_VARIANT(64, 64, 4, 2, 1, 2),   // stage 5 (+ residual)
+    RN_VARIANT(64, 128, 0, 1, 0, 2),  // stage 6 (no pool; cout tiles split over 2 workgroups)
+    RN_VARIANT(128, 16, 4, 2, 0, 1),  // stage 7
+    RN_VARIANT(16, 16, 4, 2, 0, 1),   // stage 8
+    RN_VARIANT(16, 16, 4, 2, 1, 1),   // stage 9 (+ residual)
+};
+constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
+
+struct FusedState {
+    std::vector<FusedStage> st;
+};
+
+}  // namespace
+
+void rn_fused_release(rn_handle* h) {
+    delete static_cast<FusedState*>(h->fused);
+    h->fused = nullptr;
+}
+
+int rn_fused_prepare(rn_handle* h, const rn_weights* w) {
+    const int dti = h->dtype == RN_DTYPE_BF16 ? 0 : 1;
+    (void)dti;
+    auto* fs = new FusedState();
+    fs->st.resize(h->stages.size());
+    h->fused = fs;
+    if (h->stages[0].cin != 3 || h->stages[0].cout != S0_CO || h->stages[0].pool_k != 3 ||
+        h->stages[0].pool_s != 1 || h->stages[0].skip_stage >= 0) {
+        rn_set_error("16-bit path: stage 0 must be conv(3->8) + pool 3/1 (got %d->%d pool %d/%d)", h->stages[0].cin,
+                     h->stages[0].cout, h->stages[0].pool_k, h->stages[0].pool_s);
+        return RN_E_INVALID;
+    }
+    for (size_t i = 1; i < h->stages.size(); ++i) {
+        StagePlan& s = h->stages[i];
+        FusedStage& f = fs->st[i];
+        for (int v = 0; v < kNumVariants; ++v) {
+            const Variant& k = kVariants[v];
+            if (k.cin == s.cin && k.cout == s.cout && k.pk == s.pool_k && (s.pool_k == 0 || k.ps == s.pool_s) &&
+                k.res == (s.skip_stage >= 0 ? 1 : 0)) {
+                f.variant = v;
+                break;
+            }
+        }
+        if (f.variant < 0) {
+            rn_set_error("16-bit path: no kernel variant for stage %zu (cin %d cout %d pool %d/%d res %d)", i, s.cin,
+                         s.cout, s.pool_k, s.pool_s, s.skip_stage >= 0);
+            return RN_E_INVALID;
+        }
+        const Variant& k = kVariants[f.variant];
+        f.ctw = k.ctw;
+        const int tstride = tile_stride(s.pool_k, s.pool_s), nout_t = tile_nout(s.pool_k, s.pool_s);
+        const int tiles = (s.out_side + nout_t - 1) / nout_t;
+        f.npt = tiles >= 8 ? 8 : tiles;
+        f.n_colblocks = (tiles + f.npt - 1) / f.npt;
+        const int kc = (9 * s.cin + 15) / 16;
+        const int ringcols = (f.npt - 1) * tstride + 34;
+        f.lds_bytes = static_cast<size_t>(kc) * f.ctw * 1024 + static_cast<size_t>(NSLOT) * ringcols * s.cin * 2;
+        if (f.lds_bytes > 160 * 1024) {
+            rn_set_error("16-bit path: stage %zu needs %zu bytes of LDS", i, f.lds_bytes);
+            return RN_E_INVALID;
+        }
+        // pack weights: frag[kc][ct][lane][j] = W[k = kc*16 + 8*(lane>>5) + j][cout = ct*32 + (lane&31)]
+        const int ct_n = (s.cout + 31) / 32;
+        std::vector<unsigned short> frag(static_cast<size_t>(kc) * ct_n * 64 * 8, 0);
+        const float* wsrc = w->stages[i].kernel;   // HWIO == [k = tap*cin + c][cout]
+        const int K = 9 * s.cin;
+        for (int c = 0; c < kc; ++c)
+            for (int t = 0; t < ct_n; ++t)
+                for (int l = 0; l < 64; ++l)
+                    for (int j = 0; j < 8; ++j) {
+                        const int kk = c * 16 + 8 * (l >> 5) + j, co = t * 32 + (l & 31);
+                        float v = 0.f;
+                        if (kk < K && co < s.cout) v = wsrc[static_cast<size_t>(kk) * s.cout + co];
+                        frag[((static_cast<size_t>(c) * ct_n + t) * 64 + l) * 8 + j] =
+                            h->dtype == RN_DTYPE_BF16 ? f32_to_bf16(v) : f32_to_f16(v);
+                    }
+        void* d = nullptr;
+        hipError_t e = hipMalloc(&d, frag.size() * 2);
+        if (e != hipSuccess) {
+            rn_set_error("hipMalloc(weights) failed: %s", hipGetErrorString(e));
+            return RN_E_NOMEM;
+        }
+        h->allocs.push_back(d);
+        RN_HIP(hipMemcpy(d, frag.data(), frag.size() * 2, hipMemcpyHostToDevice));
+        f.wfrag = static_cast<i32x4*>(d);
+    }
+    return RN_OK;
+}
+
+int rn_fused_forward(rn_handle* h, const uint8_t* d_bgr, const float* d_rgb, int n, float* d_probs,
+                     int64_t* d_ids) {
+    if (!d_bgr || d_rgb) {
+        rn_set_error("16-bit handles take uint8 BGR input (the pre-processing table is fused into stage 0)");
+        return RN_E_STATE;
+    }
+    FusedState* fs = static_cast<FusedState*>(h->fused);
+    if (!fs) {
+        rn_set_error("fused plan missing");
+        return RN_E_STATE;
+    }
+    const int dti = h->dtype == RN_DTYPE_BF16 ? 0 : 1;
+    // stage 0
+    {
+        const StagePlan& s = h->stages[0];
+        unsigned short* out = static_cast<unsigned short*>(h->nodes[s.node_bn].ptr);
+        dim3 grid((s.out_side + S0_TW - 1) / S0_TW, (s.out_side + S0_TH - 1) / S0_TH, n);
+        if (dti == 0)
+            hipLaunchKernelGGL(stage0_kernel<RN_DTYPE_BF16>, grid, dim3(256), 0, h->stream, d_bgr, h->lut, s.w_f32,
+                               s.bn.mean, s.bn.inv, s.bn.beta, out, s.in_side, s.out_side);
+        else
+            hipLaunchKernelGGL(stage0_kernel<RN_DTYPE_F16>, grid, dim3(256), 0, h->stream, d_bgr, h->lut, s.w_f32,
+                               s.bn.mean, s.bn.inv, s.bn.beta, out, s.in_side, s.out_side);
+        RN_CHECK_LAUNCH();
+        rn_record_event(h, 2);
+    }
+    for (size_t i = 1; i < h->stages.size(); ++i) {
+        const StagePlan& s = h->stages[i];
+        const FusedStage& f = fs->st[i];
+        const StagePlan& prev = h->stages[i - 1];
+        StageArgs a{};
+        a.in = static_cast<const unsigned short*>(h->nodes[prev.node_bn2 >= 0 ? prev.node_bn2 : prev.node_bn].ptr);
+        a.out = static_cast<unsigned short*>(h->nodes[s.node_bn2 >= 0 ? s.node_bn2 : s.node_bn].ptr);
+        a.wfrag = f.wfrag;
+        a.bn_mean = s.bn.mean;
+        a.bn_inv = s.bn.inv;
+        a.bn_beta = s.bn.beta;
+        if (s.skip_stage >= 0) {
+            const StagePlan& sk = h->stages[s.skip_stage];
+            // the skip source is the first BN output of the block (network.py:195-196)
+            if (sk.node_bn2 >= 0) {
+                rn_set_error("16-bit path: skip source with its own residual is not supported");
+                return RN_E_INVALID;
+            }
+            a.skip = static_cast<const unsigned short*>(h->nodes[sk.node_bn].ptr);
+            a.bn2_mean = s.bn2.mean;
+            a.bn2_inv = s.bn2.inv;
+            a.bn2_beta = s.bn2.beta;
+            a.rlo = s.rt.lo;
+            a.rhi = s.rt.hi;
+            a.rlerp = s.rt.lerp;
+            a.Ss = s.skip_side;
+        }
+        a.H = a.W = s.in_side;
+        a.Ho = a.Wo = s.out_side;
+        const int n_ctg = ((s.cout + 31) / 32) / f.ctw;
+        // bands: aim for >= ~2 workgroups per CU across the launch, at least 4 output rows per band
+        const int per_band_wgs = n * f.n_colblocks * n_ctg;
+        int bands = (768 + per_band_wgs - 1) / per_band_wgs;
+        const int max_bands = (s.out_side + 3) / 4;
+        if (bands > max_bands) bands = max_bands;
+        if (bands < 1) bands = 1;
+        a.rows_per_band = (s.out_side + bands - 1) / bands;
+        a.n_bands = (s.out_side + a.rows_per_band - 1) / a.rows_per_band;
+        a.n_colblocks = f.n_colblocks;
+        a.n_ctg = n_ctg;
+        a.npt = f.npt;
+        dim3 grid(a.n_bands * a.n_colblocks * a.n_ctg, n);
+        int rc = kVariants[f.variant].fn[dti](h->stream, a, grid, dim3(64 * f.npt), f.lds_bytes);
+        if (rc != RN_OK) return rc;
+        rn_record_event(h, 2 + static_cast<int>(i));
+    }
+    int rc = rn_run_head(h, n, d_probs, d_ids);
+    if (rc != RN_OK) return rc;
+    rn_record_event(h, 2 + static_cast<int>(h->stages.size()));
+    return RN_OK;
 }

@@ -93,6 +93,7 @@ struct rn_handle {
     float* d_probs = nullptr;
     int64_t* d_ids = nullptr;
     std::vector<void*> allocs;   // everything to hipFree on destroy
+    void* fused = nullptr;       // plan of the fused 16-bit path (rn_fused.hip)
     // profiling
     bool profiling = false;
     std::vector<hipEvent_t> events;   // [0]=start, [1]=after preprocess, [2+i]=after stage i, last=after head

@@ -1,0 +1,102 @@
+"""GPU parity of the fused 16-bit MFMA path (RN_DTYPE_BF16 / RN_DTYPE_F16) with the
+oracle, through the C ABI.  BASELINE config 3 at parity-test sizes.
+
+Tolerances: 16-bit storage + fp32 accumulate: logits abs <= 0.1,
+ids identical where the fp64 top-2 logit margin > 0.2.  Stage outputs are compared with
+the fp32 oracle taps relative to the tensor's abs-max (bf16 has an 8-bit significand and
+the error compounds over ten stages)."""
+import numpy as np
+import pytest
+
+from oracle import c_oracle
+from roomnet_amd import _capi
+from roomnet_amd.graph import build_graph
+
+pytestmark = pytest.mark.gpu
+
+TOL_LOGITS = 0.1
+MARGIN = 0.2
+STAGE_TOL = {"bf16": 0.04, "f16": 0.006}    # max |err| / absmax of the stage output
+
+
+@pytest.fixture(scope="module", params=["bf16", "f16"])
+def engine(request, weights):
+    e = _capi.Engine(build_graph(6, 224), weights, device=0, dtype=request.param, max_batch=8)
+    e.dtype_name = request.param
+    yield e
+    e.close()
+
+
+def _stage_out_names(g):
+    return ["s%d.%s" % (s.index, "bn2" if s.residual else "bn") for s in g.stages]
+
+
+def test_stage_outputs_vs_oracle(engine, weights, parity_images):
+    idx = [14, 30, 2]
+    ims = parity_images[idx]
+    ref = c_oracle.infer(weights, ims, taps=True)
+    ids, probs = engine.forward_u8(ims)
+    report = []
+    for name in _stage_out_names(engine.graph):
+        got = engine.tap(name, len(idx))
+        want = np.asarray(ref["taps"][name])
+        assert got.shape == want.shape, name
+        rel = float(np.abs(got - want).max() / max(np.abs(want).max(), 1e-6))
+        report.append((name, rel))
+    print(engine.dtype_name, " ".join("%s=%.2e" % r for r in report))
+    for name, rel in report:
+        assert rel <= STAGE_TOL[engine.dtype_name], (name, rel, report)
+
+
+def test_logits_probs_ids_vs_golden(engine, parity_images, golden_parity):
+    ids, probs = engine.forward_u8(parity_images)
+    logits = engine.tap("d3.relu", 8)          # last chunk of 8
+    err = np.abs(logits - golden_parity["logits_f64"][32:40]).max()
+    assert err <= TOL_LOGITS, err
+    safe = golden_parity["top2_margin"] > MARGIN
+    assert safe.sum() >= 25
+    np.testing.assert_array_equal(ids[safe], golden_parity["ids"][safe])
+    np.testing.assert_allclose(probs.sum(1), 1.0, atol=1e-5)
+    # probabilities follow from the logits: generous bound from the logit tolerance
+    assert np.abs(probs - golden_parity["probs_f64"]).max() <= 0.05
+
+
+def test_band_and_batch_invariance(engine, parity_images):
+    """A different batch size changes the band decomposition (rows per workgroup); results
+    must be bit-identical because every output element is computed by the same arithmetic."""
+    ims = parity_images[[3, 17, 26, 31, 36]]
+    ids_b, probs_b = engine.forward_u8(ims)
+    s3_b = engine.tap("s3.bn2", 5)
+    for i in (0, 4):
+        ids_1, probs_1 = engine.forward_u8(ims[i:i + 1])
+        np.testing.assert_array_equal(engine.tap("s3.bn2", 1)[0], s3_b[i])
+        np.testing.assert_array_equal(probs_1[0], probs_b[i])
+        assert ids_1[0] == ids_b[i]
+
+
+def test_against_f32_hip_path(engine, weights, parity_images):
+    f32 = _capi.Engine(build_graph(6, 224), weights, device=0, dtype="f32", max_batch=8)
+    try:
+        ims = parity_images[8:16]
+        engine.forward_u8(ims)
+        f32.forward_u8(ims)
+        assert np.abs(engine.tap("d3.relu", 8) - f32.tap("d3.relu", 8)).max() <= TOL_LOGITS
+    finally:
+        f32.close()
+
+
+def test_rejects_float_input_and_taps(engine, weights):
+    with pytest.raises(_capi.RoomNetLibraryError):
+        engine.forward_f32(np.zeros((1, 224, 224, 3), np.float32))
+    with pytest.raises(_capi.RoomNetLibraryError):
+        engine.tap("s2.conv", 1)
+    with pytest.raises(ValueError):
+        _capi.Engine(build_graph(6, 224), weights, device=0, dtype="bf16", max_batch=2, taps=True)
+
+
+def test_timing(engine, parity_images):
+    engine.set_profiling(True)
+    engine.forward_u8(parity_images[:8])
+    t = engine.timing()
+    engine.set_profiling(False)
+    assert len(t["stage_ms"]) == 10 and all(x > 0 for x in t["stage_ms"])
