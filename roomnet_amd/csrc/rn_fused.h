@@ -1,6 +1,7 @@
 // Fused 16-bit (bf16 / fp16 storage, fp32 accumulate) MFMA execution path.
 #pragma once
 #include "rn_internal.h"
+#include "rn_stage.h"
 
 // Pack weights into MFMA fragment order, choose per-stage launch geometry.
 int rn_fused_prepare(rn_handle* h, const rn_weights* w);
@@ -11,3 +12,15 @@ void rn_fused_release(rn_handle* h);
 // head launcher shared with the unfused path (defined in rn_api.hip)
 int rn_run_head(rn_handle* h, int n, float* d_probs, int64_t* d_ids);
 void rn_record_event(rn_handle* h, int idx);
+
+// ---- register-weights stage kernels (rn_stage_rw.hip)
+struct RwPlan {
+    int variant = -1;
+    int npt = 0;
+    int n_colblocks = 0;
+    int skipcols = 0;
+    size_t lds_bytes = 0;
+};
+bool rn_rw_supported(int cin, int cout, int pool_k, int pool_s, bool res, int out_side, int skip_side,
+                     RwPlan* plan);
+int rn_rw_launch(const RwPlan& p, int dtype, hipStream_t s, const rnk::StageArgs& a, dim3 grid);

@@ -26,68 +26,15 @@
 // Stage 0 (3 input channels, K = 27) is not GEMM-shaped: `stage0_kernel` is a direct
 // VALU kernel that also fuses the uint8 -> [-1,1] pre-processing table.
 #include "rn_fused.h"
+#include "rn_stage.h"
 
 #include <cmath>
 #include <cstring>
+#include <cstdlib>
+
+using namespace rnk;
 
 namespace {
-
-using i32x4 = __attribute__((ext_vector_type(4))) int;
-using f32x16 = __attribute__((ext_vector_type(16))) float;
-using f32x4 = __attribute__((ext_vector_type(4))) float;
-using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
-using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
-
-template <int DT>
-__device__ __forceinline__ f32x16 mfma32(i32x4 a, i32x4 b, f32x16 c) {
-    if constexpr (DT == RN_DTYPE_BF16)
-        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b),
-                                                       c, 0, 0, 0);
-    else
-        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c,
-                                                      0, 0, 0);
-}
-
-template <int DT>
-__device__ __forceinline__ unsigned short to16(float v) {
-    if constexpr (DT == RN_DTYPE_BF16)
-        return __builtin_bit_cast(unsigned short, static_cast<__bf16>(v));
-    else
-        return __builtin_bit_cast(unsigned short, static_cast<_Float16>(v));
-}
-
-template <int DT>
-__device__ __forceinline__ float from16(unsigned short u) {
-    if constexpr (DT == RN_DTYPE_BF16)
-        return __uint_as_float(static_cast<unsigned>(u) << 16);
-    else
-        return static_cast<float>(__builtin_bit_cast(_Float16, u));
-}
-
-template <int DT>
-__device__ __forceinline__ uint2 pack4(float a, float b, float c, float d) {
-    uint2 r;
-    r.x = static_cast<unsigned>(to16<DT>(a)) | (static_cast<unsigned>(to16<DT>(b)) << 16);
-    r.y = static_cast<unsigned>(to16<DT>(c)) | (static_cast<unsigned>(to16<DT>(d)) << 16);
-    return r;
-}
-
-template <int DT>
-__device__ __forceinline__ f32x4 unpack4(uint2 v) {
-    f32x4 r;
-    r[0] = from16<DT>(static_cast<unsigned short>(v.x & 0xffff));
-    r[1] = from16<DT>(static_cast<unsigned short>(v.x >> 16));
-    r[2] = from16<DT>(static_cast<unsigned short>(v.y & 0xffff));
-    r[3] = from16<DT>(static_cast<unsigned short>(v.y >> 16));
-    return r;
-}
-
-// value of lane+1 (DPP wave shift left by one; lane 63 reads 0)
-__device__ __forceinline__ float lane_next(float v) {
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130, 0xf, 0xf, false));
-}
-
-__device__ __forceinline__ float relu6f(float v) { return __builtin_amdgcn_fmed3f(v, 0.f, 6.f); }
 
 // ------------------------------------------------------------------------------ stage 0
 // uint8 BGR [N,S,S,3] -> table -> conv3x3 (3->COUT0) -> ReLU6 -> avg-pool 3x3/1 -> BN -> 16-bit NHWC.
@@ -178,53 +125,6 @@ __global__ __launch_bounds__(256) void stage0_kernel(const uint8_t* __restrict__
 }
 
 // ------------------------------------------------------------------------ MFMA stage
-struct StageArgs {
-    const unsigned short* in;     // [N, H, W, CIN]
-    unsigned short* out;          // [N, Ho, Wo, COUT]
-    const i32x4* wfrag;           // [KC][CT][64] fragments of 8 x 16-bit
-    const float* bn_mean;
-    const float* bn_inv;
-    const float* bn_beta;
-    const unsigned short* skip;   // [N, Ss, Ss, COUT] (residual stages)
-    const float* bn2_mean;
-    const float* bn2_inv;
-    const float* bn2_beta;
-    const int32_t* rlo;           // legacy bilinear tables, [Ho]
-    const int32_t* rhi;
-    const float* rlerp;
-    int H, W;                     // input rows / cols
-    int Ho, Wo;                   // output rows / cols
-    int Ss;                       // skip side
-    int rows_per_band, n_bands, n_colblocks, n_ctg, npt;
-};
-
-template <int CIN>
-struct StageGeom {
-    static constexpr int CP = CIN / 8;                               // 16-byte chunks per pixel
-    static constexpr int K = 9 * CIN;
-    static constexpr int KC = (K + 15) / 16;                         // 16-deep K chunks
-    static constexpr int PIX_PER_BANKROW = CP >= 16 ? 1 : 16 / CP;   // pixels per 256-byte LDS bank row
-    static constexpr int LPT = (34 * CP + 63) / 64;                  // ring-row chunks a thread prefetches
-};
-
-constexpr int NSLOT = 4;   // LDS ring: 3 live input rows + 1 being filled
-
-__host__ __device__ constexpr int tile_nout(int pk, int ps) { return pk ? (32 - pk) / ps + 1 : 32; }
-__host__ __device__ constexpr int tile_stride(int pk, int ps) { return pk ? tile_nout(pk, ps) * ps : 32; }
-
-// chunk swizzle: XOR the 16-byte chunk index inside a pixel with a function of the pixel
-// column so that 16 consecutive pixels reading the same chunk index hit 16 distinct
-// 16-byte slots of the 256-byte LDS bank row.
-template <int CP>
-__device__ __forceinline__ int chunk_swz(int pix) {
-    if constexpr (CP == 1)
-        return 0;
-    else if constexpr (CP >= 16)
-        return pix & 15;
-    else
-        return (pix / (16 / CP)) & (CP - 1);
-}
-
 template <int DT, int CIN, int COUT, int PK, int PS, bool RES, int CTW>
 __global__ __launch_bounds__(512) void stage_mfma_kernel(const StageArgs a) {
     using G = StageGeom<CIN>;
@@ -289,17 +189,14 @@ __global__ __launch_bounds__(512) void stage_mfma_kernel(const StageArgs a) {
         const int q = tid + i * nthreads;
         const int p = q / CP, c8 = q % CP;
         ld_loff[i] = q < nchunks ? (p * CP + (c8 ^ chunk_swz<CP>(p))) * 16 : -1;
-        ld_goff[i] = (q < nchunks && x0c + p < a.W) ? (x0c + p) * CIN + c8 * 8 : -1;
+        // columns past the image edge only feed discarded lanes: clamp instead of branching
+        ld_goff[i] = (q < nchunks ? min(x0c + p, a.W - 1) : 0) * CIN + c8 * 8;
     }
     i32x4 pre[LPT];
     auto fetch_row = [&](int j) {   // input row yc0 + j -> registers
         const unsigned short* row = in_img + static_cast<int64_t>(yc0 + j) * a.W * CIN;
 #pragma unroll
-        for (int i = 0; i < LPT; ++i) {
-            i32x4 v = {0, 0, 0, 0};
-            if (ld_goff[i] >= 0) v = *reinterpret_cast<const i32x4*>(row + ld_goff[i]);
-            pre[i] = v;
-        }
+        for (int i = 0; i < LPT; ++i) pre[i] = *reinterpret_cast<const i32x4*>(row + ld_goff[i]);
     };
     auto store_row = [&](int j) {   // registers -> ring slot j % NSLOT
         char* dst = ring + (j & (NSLOT - 1)) * rowbytes;
@@ -529,6 +426,9 @@ unsigned short f32_to_f16(float f) {
 }
 
 struct FusedStage {
+    bool use_rw = false;         // register-weights kernel (rn_stage_rw.hip) covers this stage
+    RwPlan rw;
+    float* ptab = nullptr;       // folded BN tables for the rw kernel
     int variant = -1;            // index into the dispatch table
     int ctw = 1;                 // cout tiles per workgroup
     int npt = 1;                 // pixel tiles (= waves) per workgroup
@@ -617,6 +517,32 @@ int rn_fused_prepare(rn_handle* h, const rn_weights* w) {
             rn_set_error("16-bit path: no kernel variant for stage %zu (cin %d cout %d pool %d/%d res %d)", i, s.cin,
                          s.cout, s.pool_k, s.pool_s, s.skip_stage >= 0);
             return RN_E_INVALID;
+        }
+        f.use_rw = rn_rw_supported(s.cin, s.cout, s.pool_k, s.pool_s, s.skip_stage >= 0, s.out_side, s.skip_side,
+                                   &f.rw) && !getenv("RN_DISABLE_RW");
+        if (f.use_rw) {
+            // y = S * (inv / k^2) + (beta - mean * inv);  y2 = (y + r) * inv2 + (beta2 - mean2 * inv2)
+            const rn_conv_stage& ws = w->stages[i];
+            std::vector<float> tab(static_cast<size_t>(4) * s.cout, 0.f);
+            for (int c = 0; c < s.cout; ++c) {
+                const float inv = (1.0f / sqrtf(ws.variance[c] + w->bn_epsilon)) * ws.gamma[c];
+                tab[c] = inv / static_cast<float>(s.pool_k * s.pool_k);
+                tab[s.cout + c] = ws.beta[c] - ws.mean[c] * inv;
+                if (s.skip_stage >= 0) {
+                    const float inv2 = (1.0f / sqrtf(ws.variance2[c] + w->bn_epsilon)) * ws.gamma2[c];
+                    tab[2 * s.cout + c] = inv2;
+                    tab[3 * s.cout + c] = ws.beta2[c] - ws.mean2[c] * inv2;
+                }
+            }
+            void* dt = nullptr;
+            hipError_t e2 = hipMalloc(&dt, tab.size() * 4);
+            if (e2 != hipSuccess) {
+                rn_set_error("hipMalloc(ptab) failed: %s", hipGetErrorString(e2));
+                return RN_E_NOMEM;
+            }
+            h->allocs.push_back(dt);
+            RN_HIP(hipMemcpy(dt, tab.data(), tab.size() * 4, hipMemcpyHostToDevice));
+            f.ptab = static_cast<float*>(dt);
         }
         const Variant& k = kVariants[f.variant];
         f.ctw = k.ctw;
@@ -711,9 +637,30 @@ int rn_fused_forward(rn_handle* h, const uint8_t* d_bgr, const float* d_rgb, int
             a.rhi = s.rt.hi;
             a.rlerp = s.rt.lerp;
             a.Ss = s.skip_side;
+            a.rscale = static_cast<float>(s.skip_side) / static_cast<float>(s.out_side);
         }
         a.H = a.W = s.in_side;
         a.Ho = a.Wo = s.out_side;
+        if (f.use_rw) {
+            a.ptab = f.ptab;
+            a.skipcols = f.rw.skipcols;
+            a.n_colblocks = f.rw.n_colblocks;
+            a.npt = f.rw.npt;
+            a.n_ctg = 1;
+            // one 8-wave workgroup per CU is resident: size the grid to whole rounds of the chip
+            const int per_band = n * f.rw.n_colblocks;
+            int bands = (256 + per_band - 1) / per_band;
+            const int max_bands = (s.out_side + 7) / 8;
+            if (bands > max_bands) bands = max_bands;
+            if (bands < 1) bands = 1;
+            a.rows_per_band = (s.out_side + bands - 1) / bands;
+            a.n_bands = (s.out_side + a.rows_per_band - 1) / a.rows_per_band;
+            dim3 grid(a.n_bands * a.n_colblocks, n);
+            int rc = rn_rw_launch(f.rw, h->dtype, h->stream, a, grid);
+            if (rc != RN_OK) return rc;
+            rn_record_event(h, 2 + static_cast<int>(i));
+            continue;
+        }
         const int n_ctg = ((s.cout + 31) / 32) / f.ctw;
         // bands: aim for >= ~2 workgroups per CU across the launch, at least 4 output rows per band
         const int per_band_wgs = n * f.n_colblocks * n_ctg;

@@ -1,0 +1,548 @@
+// "rw" (register-weights) fused stage kernel: the hot stages of the 16-bit path
+// (conv3x3 with Cin <= 32 -> ReLU6 -> avg-pool 4x4 / s -> BN [-> + bilinear(skip) -> BN]).
+//
+// Same row-streaming implicit GEMM as stage_mfma_kernel (rn_fused.hip), restructured
+// around what the counters and the ISA of the first versions showed (profiles/r1_*):
+//   1. the stage is latency-bound, not issue-bound: with ONE input row prefetched per
+//      workgroup only ~15 KB per CU were in flight (Little: ~3.7 B/clk/CU, 35 % of HBM).
+//      -> input rows (and the residual's skip rows) now arrive by LDS-DMA
+//         (global_load_lds_dwordx4, no VGPR staging, no ds_write) into a 6-slot ring with
+//         3 rows in flight, retired by COUNTED s_waitcnt vmcnt(N) and a raw s_barrier that
+//         does not drain the memory pipe (output stores stay in flight too);
+//   2. one wave = one (32-column pixel tile, 32-channel cout tile); its weight fragments
+//      (K/16 x 4 VGPRs) are loaded once into registers: one ds_read_b128 per MFMA;
+//   3. the row loop is unrolled by the ring depth, so every ring access is "lane-constant
+//      VGPR + immediate offset" -- no per-MFMA address arithmetic; the XOR chunk swizzle
+//      that keeps the B-fragment reads bank-conflict free is applied on the DMA's per-lane
+//      SOURCE address (the LDS image of a DMA piece is lane-linear);
+//   4. vertical 4-row pool by pair sums q_i = h_{i-1} + h_i, S_i = q_{i-2} + q_i (two adds
+//      per value, registers renamed by the unroll), horizontal pool by DPP wave shifts
+//      folded into v_add_f32, BN folded to one fma, 16-byte stores via v_permlane32_swap;
+//   5. software pipelining: the MFMA chain of conv row i shares a scheduling region with
+//      the VALU epilogue of row i-1 (two accumulator sets, sched_group_barrier interleave).
+#include "rn_fused.h"
+#include "rn_stage.h"
+
+#include <type_traits>
+#include <utility>
+
+using namespace rnk;
+
+namespace {
+
+template <int P>
+using IC = std::integral_constant<int, P>;
+
+typedef __attribute__((address_space(3))) void* lds_void_ptr;
+
+constexpr int RW_NSLOT = 6;     // ring slots: 3 live input rows + 3 in flight
+constexpr int RW_AHEAD = 5;     // at step s the DMA for input row s + RW_AHEAD is issued
+constexpr int RW_SKIPBUF = 3;   // staged skip-row pairs (residual): 1 being read + 2 in flight
+
+template <int DT, int CIN, int COUT, int PS, bool RES, int NPT>
+struct RwCfg {
+    static constexpr int PK = 4;
+    static constexpr int CP = CIN / 8;
+    static constexpr int KC = (9 * CIN + 15) / 16;
+    static constexpr int CT = COUT / 32;
+    static constexpr int CPO = COUT / 8;                       // 16-byte chunks per output/skip pixel
+    static constexpr int TSTRIDE = tile_stride(PK, PS);
+    static constexpr int NOUT_T = tile_nout(PK, PS);
+    static constexpr int RINGCOLS = (NPT - 1) * TSTRIDE + 34;
+    static constexpr int NTHREADS = 64 * NPT * CT;
+    static constexpr int LPT = (RINGCOLS * CP + NTHREADS - 1) / NTHREADS;   // DMA pieces per wave per row
+    static constexpr int ROWB = LPT * NTHREADS * 16;           // ring row stride (padded to whole pieces)
+    static constexpr int SKIPCOLS_MAX = RINGCOLS + 8;          // residual scale <= ~1.1 (checked on the host)
+    static constexpr int SLPT = RES ? (2 * SKIPCOLS_MAX * CPO + NTHREADS - 1) / NTHREADS : 0;
+    static constexpr int SKIPBUFB = SLPT * NTHREADS * 16;      // one staged pair of skip rows (padded)
+    static constexpr int PTAB_BYTES = 4 * COUT * 4;
+    static constexpr int RING_OFF = PTAB_BYTES;
+    static constexpr int SKIP_OFF = RING_OFF + RW_NSLOT * ROWB;
+    static constexpr int LDS_BYTES = SKIP_OFF + (RES ? RW_SKIPBUF * SKIPBUFB : 0);
+    // steady-state counted wait at the end of step s: everything up to input row s+3 and the
+    // skip pair used by step s+1 has landed; what may stay in flight is what the wave issued
+    // after them (the pieces of this step, plus one more row of input when there is no skip)
+    static constexpr int VMCNT_STEADY = RES ? LPT + SLPT : 2 * LPT;
+    static_assert(COUT % 32 == 0, "rw kernel needs whole 32-channel cout tiles");
+    static_assert(KC * 4 <= 80, "weights do not fit the register budget");
+    static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
+    static_assert(RW_NSLOT % 2 == 0, "pool-ring parity is tied to the unroll");
+    static_assert(VMCNT_STEADY <= 63, "vmcnt field");
+};
+
+// Bare workgroup barrier.  No fence: a fence would make the compiler drain the LDS-DMA queue
+// (vmcnt(0)) at every barrier.  Correctness is by construction: DMA data is retired by the
+// counted s_waitcnt vmcnt(N) in front of it, every ds_read of a step has been consumed by
+// an MFMA / VALU instruction of that step, and there are no ds_writes in the loop.
+__device__ __forceinline__ void raw_barrier() {
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
+// 16-byte-per-lane LDS-DMA piece: LDS destination = wave-uniform `lds` + lane * 16.
+// (Kept in an explicit __device__ function: used directly inside a lambda the builtin makes
+// the host pass drop the kernel's launch stub without a diagnostic.)
+__device__ __forceinline__ void dma16(const void* gsrc, char* lds) {
+    __builtin_amdgcn_global_load_lds(gsrc, (lds_void_ptr)lds, 16, 0, 0);
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    static_assert(N >= 0 && N <= 63, "vmcnt range");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int DT, int CIN, int COUT, int PS, bool RES, int NPT>
+__global__ __launch_bounds__(64 * NPT * (COUT / 32), 1) void stage_rw_kernel(const StageArgs a) {
+    using C = RwCfg<DT, CIN, COUT, PS, RES, NPT>;
+    constexpr int CP = C::CP, KC = C::KC, CT = C::CT, CPO = C::CPO, TSTRIDE = C::TSTRIDE, NOUT_T = C::NOUT_T;
+    constexpr int RINGCOLS = C::RINGCOLS, ROWB = C::ROWB, NTHREADS = C::NTHREADS, LPT = C::LPT, SLPT = C::SLPT;
+    constexpr int PIXB = CIN * 2;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int pt = wave % NPT, ct = wave / NPT;
+    const int r = lane & 31, hh = lane >> 5;
+
+    int bid = blockIdx.x;
+    const int cb = bid % a.n_colblocks;
+    const int band = bid / a.n_colblocks;
+    const int n = blockIdx.y;
+
+    float* const ptab = reinterpret_cast<float*>(smem);
+    char* const ring = smem + C::RING_OFF;
+    char* const skipb = smem + C::SKIP_OFF;
+    const int skipbytes = a.skipcols * COUT * 2;        // bytes per staged skip row
+
+    const int yo0 = band * a.rows_per_band;
+    const int yo1 = min(a.Ho, yo0 + a.rows_per_band);
+    const int nout_rows = yo1 - yo0;
+    const int yc0 = yo0 * PS;
+    const int nconv = (nout_rows - 1) * PS + 4;
+    const int nin = nconv + 2;
+    const int x0c = cb * NPT * TSTRIDE;
+    const int xo_blk0 = x0c / PS;
+
+    // ---- folded BN tables -> LDS
+    for (int i = tid; i < 4 * COUT; i += NTHREADS) ptab[i] = a.ptab[i];
+
+    // ---- this wave's weight fragments -> registers (lane-linear, coalesced)
+    i32x4 wreg[KC];
+#pragma unroll
+    for (int kc = 0; kc < KC; ++kc) wreg[kc] = a.wfrag[(kc * CT + ct) * 64 + lane];
+
+    // ---- input-row DMA: piece i of a row covers ring chunks [i*NTHREADS, (i+1)*NTHREADS); this
+    // lane fills chunk q = tid + i*NTHREADS = (pixel p, slot c') and therefore fetches source
+    // chunk c' ^ swz(p) of pixel p.  Pieces past the row end land in the row's padding; columns
+    // past the image edge are clamped (they only feed discarded lanes).
+    const unsigned short* const in_img = a.in + static_cast<int64_t>(n) * a.H * a.W * CIN;
+    int ld_goff[LPT];
+#pragma unroll
+    for (int i = 0; i < LPT; ++i) {
+        const int q = tid + i * NTHREADS;
+        const int p = q / CP, c8 = q % CP;
+        const int pc = min(x0c + min(p, RINGCOLS - 1), a.W - 1);
+        ld_goff[i] = pc * CIN + (c8 ^ chunk_swz<CP>(p)) * 8;
+    }
+    const int piece_base = wave * 64 * 16;               // LDS byte offset of this wave inside a piece
+    auto issue_row = [&](int j, int slot) {               // input row yc0 + j -> ring slot
+        const unsigned short* row = in_img + static_cast<int64_t>(yc0 + j) * a.W * CIN;
+#pragma unroll
+        for (int i = 0; i < LPT; ++i)
+            dma16(row + ld_goff[i], ring + slot * ROWB + i * NTHREADS * 16 + piece_base);
+    };
+
+    // ---- skip-row DMA (residual stages): the pair of rows lo/hi of one output row
+    int xs0 = 0;
+    int sk_goff[SLPT > 0 ? SLPT : 1];
+    const unsigned short* skip_img = nullptr;
+    if constexpr (RES) {
+        xs0 = a.rlo[min(xo_blk0, a.Wo - 1)];
+        skip_img = a.skip + static_cast<int64_t>(n) * a.Ss * a.Ss * COUT;
+        const int per_row = a.skipcols * CPO;
+#pragma unroll
+        for (int i = 0; i < SLPT; ++i) {
+            const int q = tid + i * NTHREADS;
+            const int row = q >= per_row ? 1 : 0;
+            const int qq = min(q - row * per_row, per_row - 1);
+            const int p = qq / CPO, c8 = qq % CPO;
+            const int pc = min(xs0 + p, a.Ss - 1);
+            sk_goff[i] = (pc * COUT + (c8 ^ chunk_swz<CPO>(p)) * 8) | (row << 30);
+        }
+    }
+    auto issue_skip = [&](int e, int buf) {               // skip rows of local output row e -> buffer
+        if constexpr (RES) {
+            const int yo = yo0 + min(max(e, 0), nout_rows - 1);
+            // TF-1.13 compute_interpolation_weights: src = yo * scale (fp32), lo = int(src), hi = min(lo+1, in-1)
+            const float src = static_cast<float>(yo) * a.rscale;
+            const int ylo = static_cast<int>(src);
+            const int yhi = min(ylo + 1, a.Ss - 1);
+            const unsigned short* r0 = skip_img + static_cast<int64_t>(ylo) * a.Ss * COUT;
+            const unsigned short* r1 = skip_img + static_cast<int64_t>(yhi) * a.Ss * COUT;
+#pragma unroll
+            for (int i = 0; i < SLPT; ++i) {
+                const unsigned short* base = (sk_goff[i] >> 30) ? r1 : r0;
+                dma16(base + (sk_goff[i] & 0x3fffffff), skipb + buf * C::SKIPBUFB + i * NTHREADS * 16 + piece_base);
+            }
+        }
+    };
+
+    // ---- prologue: rows 0 .. RW_AHEAD-1 in flight (nin >= 6 always)
+#pragma unroll
+    for (int j = 0; j < RW_AHEAD; ++j) issue_row(j, j);
+
+    // ---- lane constants of this wave's pixel tile
+    const int xrel0 = pt * TSTRIDE + r;
+    int boff[3][CIN >= 16 ? CIN / 16 : 1];
+    int b8_ky[CIN >= 16 ? 1 : KC], b8_off[CIN >= 16 ? 1 : KC];   // CIN == 8: per K-chunk tap row / offset
+    if constexpr (CIN >= 16) {
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+            for (int cc = 0; cc < CIN / 16; ++cc)
+                boff[kx][cc] = (xrel0 + kx) * PIXB + (((cc * 2 + hh) ^ chunk_swz<CP>(xrel0 + kx)) << 4);
+    } else {
+#pragma unroll
+        for (int kc = 0; kc < KC; ++kc) {
+            int tap = 2 * kc + hh;
+            tap = tap > 8 ? 8 : tap;          // K padded 72 -> 80, zero weights there
+            const int ky = tap / 3, kx = tap - 3 * ky;
+            b8_ky[kc] = ky;
+            b8_off[kc] = (xrel0 + kx) * PIXB;
+        }
+    }
+    const int xc = x0c + xrel0;
+    const int xo = xc / PS;
+    const bool lane_out = (r % PS == 0) && r <= 28 && xo < a.Wo && (xo - xo_blk0) < NPT * NOUT_T;
+    unsigned short* const out_lane =
+        a.out + (static_cast<int64_t>(n) * a.Ho * a.Wo + xo) * COUT + ct * 32 + 8 * hh;   // + yo*Wo*COUT + 8*k
+    const float* const ptab_lane = ptab + ct * 32 + 4 * hh;                                // + 8*g (+ table*COUT)
+
+    int sk_lo[4], sk_hi[4];      // byte offsets inside a staged skip row, per channel group
+    float rx_l = 0.f;
+    if constexpr (RES) {
+        const int xq = min(xo, a.Wo - 1);
+        const int plo = a.rlo[xq] - xs0, phi = a.rhi[xq] - xs0;
+        rx_l = a.rlerp[xq];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int c16 = ct * 4 + g;
+            sk_lo[g] = (plo * CPO + (c16 ^ chunk_swz<CPO>(plo))) * 16 + hh * 8;
+            sk_hi[g] = (phi * CPO + (c16 ^ chunk_swz<CPO>(phi))) * 16 + hh * 8;
+        }
+    }
+
+    // ---- pooling state
+    float hprev[16], q0[16], q1[16];
+#pragma unroll
+    for (int g = 0; g < 16; ++g) hprev[g] = q0[g] = q1[g] = 0.f;
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) acc0[g] = acc1[g] = 0.f;
+
+    wait_vmcnt<0>();
+    lds_barrier();
+
+    // B fragment of K-chunk kc for the conv row whose first input row sits in ring slot P
+    auto b_frag = [&](auto PC, auto KCC) -> i32x4 {
+        constexpr int P = decltype(PC)::value, kc = decltype(KCC)::value;
+        if constexpr (CIN >= 16) {
+            constexpr int tap = kc / (CIN / 16), cc = kc % (CIN / 16);
+            constexpr int ky = tap / 3, kx = tap % 3;
+            return *reinterpret_cast<const i32x4*>(ring + ((P + ky) % RW_NSLOT) * ROWB + boff[kx][cc]);
+        } else {
+            int slot = P + b8_ky[kc];
+            slot = slot >= RW_NSLOT ? slot - RW_NSLOT : slot;
+            return *reinterpret_cast<const i32x4*>(ring + slot * ROWB + b8_off[kc]);
+        }
+    };
+    // MFMA chain of one conv row; B fragments are read BAHEAD K-chunks ahead of their MFMA
+    constexpr int BAHEAD = KC >= 4 ? 3 : 1;
+    auto mma_row = [&](auto PC, f32x16& acc) {
+        const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        i32x4 bq[KC];
+        [&]<int... I>(std::integer_sequence<int, I...>) {
+            ((bq[I] = b_frag(PC, IC<I>{})), ...);
+        }(std::make_integer_sequence<int, BAHEAD>{});
+        [&]<int... I>(std::integer_sequence<int, I...>) {
+            ((bq[I + BAHEAD < KC ? I + BAHEAD : 0] =
+                  (I + BAHEAD < KC ? b_frag(PC, IC<(I + BAHEAD < KC ? I + BAHEAD : 0)>{}) : bq[0]),
+              acc = mfma32<DT>(wreg[I], bq[I], I == 0 ? zero : acc)),
+             ...);
+        }(std::make_integer_sequence<int, KC>{});
+    };
+
+    // epilogue of conv row j (local index); JP = j mod RW_NSLOT (only its parity matters).
+    // Works on one group of 4 consecutive channels at a time (4 independent DPP chains in
+    // lockstep: short live ranges, and the VALU-write -> DPP-read hazard is covered).
+    auto epi_row = [&](auto JPC, const f32x16& acc, int j, int skip_buf) {
+        constexpr int JP = decltype(JPC)::value;
+        constexpr bool emit_phase = PS == 1 || (JP & 1) == 1;
+        const bool emit = j >= 3;
+        const int e = (j - 3) / PS;                  // emitted output row (local)
+        const int yo = yo0 + e;
+        float yl = 0.f;
+        if constexpr (RES) {
+            const float src = static_cast<float>(yo) * a.rscale;
+            yl = src - static_cast<float>(static_cast<int>(src));
+        }
+        const char* sk0 = skipb + skip_buf * C::SKIPBUFB;
+        const char* sk1 = sk0 + skipbytes;
+        uint2 pk[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            float v[4], t[4], u[4], hs[4], S[4];
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) v[jj] = relu6f(acc[4 * g + jj]);
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) t[jj] = v[jj] + lane_next(v[jj]);
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) u[jj] = lane_next(t[jj]);
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) hs[jj] = t[jj] + lane_next(u[jj]);
+            if constexpr (PS == 1) {
+                // q_j = h_{j-1} + h_j ; S_j = q_{j-2} + q_j ; q ring by parity of j
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    const int gi = 4 * g + jj;
+                    const float q = hprev[gi] + hs[jj];
+                    hprev[gi] = hs[jj];
+                    if constexpr ((JP & 1) == 0) {
+                        S[jj] = q0[gi] + q;
+                        q0[gi] = q;
+                    } else {
+                        S[jj] = q1[gi] + q;
+                        q1[gi] = q;
+                    }
+                }
+            } else if constexpr ((JP & 1) == 1) {
+                // stride 2: windows start at even conv rows and end at odd rows j = 2e + 3
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    const int gi = 4 * g + jj;
+                    const float q = hprev[gi] + hs[jj];
+                    S[jj] = q0[gi] + q;
+                    q0[gi] = q;
+                }
+            } else {
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    hprev[4 * g + jj] = hs[jj];
+                    S[jj] = 0.f;
+                }
+            }
+            if constexpr (emit_phase) {
+                // keep the table / skip reads behind the pooled sums: hoisted to the top of the step
+                // they would pin 32+ registers across the whole MFMA chain
+                // (the OFFSET is made opaque, not the pointer, so the access stays a DS read)
+                int pt_off = 8 * g;
+                asm volatile("" : "+v"(pt_off) : "v"(S[0]), "v"(S[3]));
+                const float* pt_g = ptab_lane + pt_off;
+                const f32x4 sc1 = *reinterpret_cast<const f32x4*>(pt_g);
+                const f32x4 sh1 = *reinterpret_cast<const f32x4*>(pt_g + COUT);
+                float y[4];
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) y[jj] = fmaf(S[jj], sc1[jj], sh1[jj]);
+                if constexpr (RES) {
+                    int o_lo = sk_lo[g], o_hi = sk_hi[g];
+                    asm volatile("" : "+v"(o_lo), "+v"(o_hi) : "v"(y[0]));
+                    const f32x4 tl = unpack4<DT>(*reinterpret_cast<const uint2*>(sk0 + o_lo));
+                    const f32x4 tr = unpack4<DT>(*reinterpret_cast<const uint2*>(sk0 + o_hi));
+                    const f32x4 bl = unpack4<DT>(*reinterpret_cast<const uint2*>(sk1 + o_lo));
+                    const f32x4 br = unpack4<DT>(*reinterpret_cast<const uint2*>(sk1 + o_hi));
+                    const f32x4 sc2 = *reinterpret_cast<const f32x4*>(pt_g + 2 * COUT);
+                    const f32x4 sh2 = *reinterpret_cast<const f32x4*>(pt_g + 3 * COUT);
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) {
+                        const float top = tl[jj] + (tr[jj] - tl[jj]) * rx_l;
+                        const float bot = bl[jj] + (br[jj] - bl[jj]) * rx_l;
+                        const float rs = top + (bot - top) * yl;
+                        y[jj] = fmaf(y[jj] + rs, sc2[jj], sh2[jj]);
+                    }
+                }
+                pk[g] = pack4<DT>(y[0], y[1], y[2], y[3]);
+            }
+        }
+        if constexpr (emit_phase) {
+            // widen to 16-byte stores: lower half-wave gets channels 8k..8k+7, upper 8(k+1)..8(k+1)+7
+            unsigned short* orow = out_lane + static_cast<int64_t>(yo) * a.Wo * COUT;
+#pragma unroll
+            for (int k = 0; k < 4; k += 2) {
+                const auto sx = __builtin_amdgcn_permlane32_swap(pk[k].x, pk[k + 1].x, false, false);
+                const auto sy = __builtin_amdgcn_permlane32_swap(pk[k].y, pk[k + 1].y, false, false);
+                uint4 vv;
+                vv.x = sx[0];
+                vv.y = sy[0];
+                vv.z = sx[1];
+                vv.w = sy[1];
+                if (emit && lane_out) *reinterpret_cast<uint4*>(orow + 8 * k) = vv;
+            }
+        }
+    };
+
+    // skip-pair bookkeeping: the pair for local output row e lives in buffer (e + 3k) mod 3
+    int sbuf_issue = 1;          // buffer for e = -2 (issued at step 0 for conv row j = 1)
+    int sbuf_read = 0;           // buffer read by the epilogue of conv row j = 0 (e = -3)
+
+    // one pipeline step s (ring phase P = s mod RW_NSLOT): DMA for row s+RW_AHEAD, MFMAs of conv
+    // row s, epilogue of conv row s-1, counted wait, barrier
+    auto step = [&](auto PC, auto MMAC, auto EPIC, int s) {
+        constexpr int P = decltype(PC)::value;
+        constexpr bool MMA = decltype(MMAC)::value != 0, EPI = decltype(EPIC)::value != 0;
+        const bool have_next = MMA && (s + RW_AHEAD < nin);
+        if constexpr (MMA) {
+            if (have_next) issue_row(s + RW_AHEAD, (P + RW_AHEAD) % RW_NSLOT);
+            if constexpr (RES) {
+                // pair for the epilogue of conv row s+1 (runs in step s+2): e = (s + 1 - 3) / PS
+                static_assert(!RES || PS == 1, "residual variant is stride 1");
+                issue_skip(s - 2, sbuf_issue);
+                sbuf_issue = sbuf_issue == RW_SKIPBUF - 1 ? 0 : sbuf_issue + 1;
+            }
+            if constexpr ((P & 1) == 0)
+                mma_row(PC, acc0);
+            else
+                mma_row(PC, acc1);
+        }
+        if constexpr (EPI) {
+            if constexpr ((P & 1) == 0)
+                epi_row(IC<(P + RW_NSLOT - 1) % RW_NSLOT>{}, acc1, s - 1, sbuf_read);
+            else
+                epi_row(IC<(P + RW_NSLOT - 1) % RW_NSLOT>{}, acc0, s - 1, sbuf_read);
+        }
+        if constexpr (RES && EPI) sbuf_read = sbuf_read == RW_SKIPBUF - 1 ? 0 : sbuf_read + 1;
+        if constexpr (MMA && EPI) {
+            // software pipeline: spread the VALU epilogue of row s-1 through the MFMA chain of row s
+            constexpr int VPG = RES ? 16 : 8;
+#pragma unroll
+            for (int i = 0; i < KC; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     // one MFMA
+                __builtin_amdgcn_sched_group_barrier(0x002, VPG, 0);   // VALU
+            }
+        }
+        if constexpr (MMA) {
+            // retire the DMA of input row s+3 (and of the skip pair the next epilogue reads)
+            if (have_next)
+                wait_vmcnt<C::VMCNT_STEADY>();
+            else
+                wait_vmcnt<0>();
+        }
+        raw_barrier();
+    };
+
+    using T = IC<1>;
+    using F = IC<0>;
+    static_assert(RW_NSLOT == 6, "the step sequence below is written for a 6-slot ring");
+    step(IC<0>{}, T{}, F{}, 0);
+    int s = 1;
+    for (; s + 5 < nconv; s += 6) {
+        step(IC<1>{}, T{}, T{}, s);
+        step(IC<2>{}, T{}, T{}, s + 1);
+        step(IC<3>{}, T{}, T{}, s + 2);
+        step(IC<4>{}, T{}, T{}, s + 3);
+        step(IC<5>{}, T{}, T{}, s + 4);
+        step(IC<0>{}, T{}, T{}, s + 5);
+    }
+    if (s < nconv) {
+        step(IC<1>{}, T{}, T{}, s);
+        ++s;
+    }
+    if (s < nconv) {
+        step(IC<2>{}, T{}, T{}, s);
+        ++s;
+    }
+    if (s < nconv) {
+        step(IC<3>{}, T{}, T{}, s);
+        ++s;
+    }
+    if (s < nconv) {
+        step(IC<4>{}, T{}, T{}, s);
+        ++s;
+    }
+    if (s < nconv) {
+        step(IC<5>{}, T{}, T{}, s);
+        ++s;
+    }
+    switch (s % RW_NSLOT) {
+        case 0: step(IC<0>{}, F{}, T{}, s); break;
+        case 1: step(IC<1>{}, F{}, T{}, s); break;
+        case 2: step(IC<2>{}, F{}, T{}, s); break;
+        case 3: step(IC<3>{}, F{}, T{}, s); break;
+        case 4: step(IC<4>{}, F{}, T{}, s); break;
+        default: step(IC<5>{}, F{}, T{}, s); break;
+    }
+}
+
+template <int DT, int CIN, int COUT, int PS, bool RES, int NPT>
+int launch_rw(hipStream_t s, const StageArgs& a, dim3 grid) {
+    using C = RwCfg<DT, CIN, COUT, PS, RES, NPT>;
+    auto kern = stage_rw_kernel<DT, CIN, COUT, PS, RES, NPT>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        RN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   160 * 1024));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, grid, dim3(C::NTHREADS), C::LDS_BYTES, s, a);
+    RN_CHECK_LAUNCH();
+    return RN_OK;
+}
+
+template <int CIN, int COUT, int PS, bool RES, int NPT>
+int launch_rw_dt(int dtype, hipStream_t s, const StageArgs& a, dim3 grid) {
+    if (dtype == RN_DTYPE_BF16) return launch_rw<RN_DTYPE_BF16, CIN, COUT, PS, RES, NPT>(s, a, grid);
+    return launch_rw<RN_DTYPE_F16, CIN, COUT, PS, RES, NPT>(s, a, grid);
+}
+
+}  // namespace
+
+// Geometry query for the rw kernels.  Returns false when no rw variant covers the stage, so
+// the caller can use the generic kernel.
+bool rn_rw_supported(int cin, int cout, int pool_k, int pool_s, bool res, int out_side, int skip_side,
+                     RwPlan* plan) {
+    if (pool_k != 4 || (pool_s != 1 && pool_s != 2)) return false;
+    int variant = -1;
+    if (cin == 8 && cout == 32 && pool_s == 1 && !res) variant = 0;
+    if (cin == 32 && cout == 32 && pool_s == 1 && !res) variant = 1;
+    if (cin == 32 && cout == 32 && pool_s == 1 && res) variant = 2;
+    if (cin == 32 && cout == 64 && pool_s == 2 && !res) variant = 3;
+    if (variant < 0) return false;
+    const int nout_t = tile_nout(4, pool_s), tstride = tile_stride(4, pool_s);
+    const int tiles = (out_side + nout_t - 1) / nout_t;
+    // 8 waves per workgroup: 8 pixel tiles x 1 cout tile, or 4 pixel tiles x 2 cout tiles;
+    // the residual variant runs 4 tiles (4 waves, one per SIMD, whole register file)
+    int npt = (cout == 64 || res) ? 4 : (tiles > 4 ? 8 : 4);
+    plan->variant = variant;
+    plan->npt = npt;
+    plan->n_colblocks = (tiles + npt - 1) / npt;
+    const int ringcols = (npt - 1) * tstride + 34;
+    plan->skipcols = 0;
+    plan->lds_bytes = 0;   // the kernel's LDS size is a compile-time constant of the variant
+    if (res) {
+        // columns of the skip tensor a column block touches: rlo[first] .. rhi[last]
+        const float scale = static_cast<float>(skip_side) / static_cast<float>(out_side);
+        if (scale > 1.1f) return false;
+        const int cols_out = npt * nout_t;
+        int skipcols = static_cast<int>(cols_out * scale) + 3;
+        if (skipcols > skip_side) skipcols = skip_side;
+        if (skipcols > ringcols + 8) return false;
+        plan->skipcols = skipcols;
+    }
+    return true;
+}
+
+int rn_rw_launch(const RwPlan& p, int dtype, hipStream_t s, const StageArgs& a, dim3 grid) {
+    switch (p.variant * 16 + p.npt) {
+        case 0 * 16 + 4: return launch_rw_dt<8, 32, 1, false, 4>(dtype, s, a, grid);
+        case 0 * 16 + 8: return launch_rw_dt<8, 32, 1, false, 8>(dtype, s, a, grid);
+        case 1 * 16 + 4: return launch_rw_dt<32, 32, 1, false, 4>(dtype, s, a, grid);
+        case 1 * 16 + 8: return launch_rw_dt<32, 32, 1, false, 8>(dtype, s, a, grid);
+        case 2 * 16 + 4: return launch_rw_dt<32, 32, 1, true, 4>(dtype, s, a, grid);
+        case 3 * 16 + 4: return launch_rw_dt<32, 64, 2, false, 4>(dtype, s, a, grid);
+        default:
+            rn_set_error("rw kernel: no instantiation for variant %d npt %d", p.variant, p.npt);
+            return RN_E_INVALID;
+    }
+}
