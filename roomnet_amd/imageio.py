@@ -1,0 +1,66 @@
+"""Image file I/O for the directory driver, standing in for the three OpenCV calls the
+reference makes (``cv2.imread`` ``infer.py:81``, ``cv2.putText`` ``infer.py:89-92``,
+``cv2.imwrite`` ``infer.py:93``).  OpenCV is not installed on the MI355X hosts; Pillow is.
+
+Differences from OpenCV that cannot be removed without its sources/fonts are limited to
+pixels that never reach the network: the overlay text is drawn with Pillow's built-in font
+instead of the Hershey simplex strokes (same anchor, colours, scale rule, anti-aliased).
+"""
+from __future__ import annotations
+
+import os
+from typing import Optional, Tuple
+
+import numpy as np
+
+
+def imread(path: str) -> Optional[np.ndarray]:
+    """BGR uint8 HWC like ``cv2.imread(path)`` (IMREAD_COLOR: 3 channels, alpha dropped,
+    EXIF orientation applied); ``None`` when the file is not a readable image."""
+    try:
+        from PIL import Image, ImageOps
+        with Image.open(path) as im:
+            im = ImageOps.exif_transpose(im)
+            if im.mode in ("RGBA", "LA", "P"):
+                im = im.convert("RGBA").convert("RGB") if im.mode != "P" else im.convert("RGB")
+            elif im.mode != "RGB":
+                im = im.convert("RGB")
+            rgb = np.asarray(im, dtype=np.uint8)
+    except Exception:
+        return None
+    return np.ascontiguousarray(rgb[:, :, ::-1])
+
+
+def imwrite(path: str, im_bgr: np.ndarray) -> bool:
+    """``cv2.imwrite``: format from the extension (JPEG quality 95 like OpenCV's default)."""
+    from PIL import Image
+    ext = os.path.splitext(path)[1].lower()
+    img = Image.fromarray(np.ascontiguousarray(im_bgr[:, :, ::-1]))
+    try:
+        if ext in (".jpg", ".jpeg", ".jpe"):
+            img.save(path, format="JPEG", quality=95)
+        elif ext == ".png":
+            img.save(path, format="PNG", compress_level=1)
+        elif ext == ".bmp":
+            img.save(path, format="BMP")
+        else:
+            img.save(path)
+    except Exception:
+        return False
+    return True
+
+
+def put_text(im_bgr: np.ndarray, text: str, org: Tuple[int, int], font_scale: float,
+             color_bgr: Tuple[int, int, int]) -> None:
+    """In-place overlay like ``cv2.putText(im, text, org, FONT_HERSHEY_SIMPLEX, font_scale,
+    color, 1, LINE_AA)``: ``org`` is the bottom-left corner of the text."""
+    from PIL import Image, ImageDraw, ImageFont
+    size = max(6, int(round(30.0 * font_scale)))      # Hershey simplex is ~30 px tall at scale 1
+    try:
+        font = ImageFont.load_default(size=size)
+    except TypeError:                                  # very old Pillow: fixed-size bitmap font
+        font = ImageFont.load_default()
+    img = Image.fromarray(np.ascontiguousarray(im_bgr[:, :, ::-1]))
+    draw = ImageDraw.Draw(img)
+    draw.text((org[0], org[1]), text, fill=(color_bgr[2], color_bgr[1], color_bgr[0]), font=font, anchor="ls")
+    im_bgr[:, :, :] = np.asarray(img, dtype=np.uint8)[:, :, ::-1]

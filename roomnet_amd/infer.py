@@ -1,0 +1,153 @@
+"""Drop-in for the reference's inference driver ``infer.py`` (``infer.py:1-110``):
+``CLASS_LABELS``, the module constants, ``force_makedir``, ``read_fpaths``,
+``groundtruth_validation``, ``classify_im_dir`` and the ``__main__`` block, running on the
+MI355X ``RoomNet`` of this package instead of TensorFlow.
+
+``classify_im_dir(nn, imgs_dir, overlay=True)`` keeps the reference's observable behaviour:
+one ``<imgs_dir>_classified/<label>/`` directory per class, each image written there with
+the two overlay lines (or copied when ``overlay=False``), one printed line per image, and a
+``<imgs_dir>_classified_results.xls`` workbook (sheet ``classification_results``, header
+``IMAGE_NAME | PREDICTED_LABEL``, rows ``name | label | str(conf)``); it returns the
+workbook path.  The reference classifies strictly one image per ``sess.run``; here decoded
+images are grouped into batches for the GPU (``batch_size``), which does not change any
+result because the graph has no cross-image coupling (inference-mode BN).
+"""
+from __future__ import annotations
+
+from glob import glob
+import os
+import shutil
+
+import numpy as np
+
+from . import xls
+from .imageio import imread, imwrite, put_text
+from .imageops import resize_linear_u8
+from .network import RoomNet
+
+CLASS_LABELS = ['Backyard', 'Bathroom', 'Bedroom', 'Frontyard', 'Kitchen', 'LivingRoom']
+
+INPUT_MODEL_PATH = './final_model/roomnet'
+INPUT_IMAGES_DIR = './test_images/set2/images'
+IMG_SIDE = 224
+
+INPUT_IMG_PATH_LIST_FILE = 'val_list.txt'
+
+
+def read_fpaths(list_fpath):
+    """infer.py:31-38."""
+    with open(list_fpath, 'r') as f:
+        data = f.readlines()
+    fpath_components = [fpath_set.strip().split(' ') for fpath_set in data]
+    im_paths = [' '.join(fpath_component[:-1]) for fpath_component in fpath_components]
+    class_id = [int(fpath_component[-1]) for fpath_component in fpath_components]
+    n = len(class_id)
+    return im_paths, class_id, n
+
+
+def _prepare(nn, im):
+    """The host half of ``RoomNet.infer_optimized`` (network.py:149-152)."""
+    im = nn.center_crop(im)
+    h, w, _ = im.shape
+    if h != nn.im_side or w != nn.im_side:
+        im = resize_linear_u8(np.ascontiguousarray(im), nn.im_side, nn.im_side)
+    return np.ascontiguousarray(im)
+
+
+def _infer_files(nn, fpaths, batch_size):
+    """Yield ``(index, image_bgr, idx, conf)`` per readable file, running the GPU in batches."""
+    pending = []
+
+    def flush():
+        if not pending:
+            return []
+        batch = np.stack([p[2] for p in pending], 0)
+        outs = nn.infer(batch)
+        ids, probs = outs if isinstance(outs, tuple) else (outs, None)
+        res = [(p[0], p[1], int(ids[k]), (float(probs[k][ids[k]]) if probs is not None else float('nan')))
+               for k, p in enumerate(pending)]
+        pending.clear()
+        return res
+
+    for i, fpath in enumerate(fpaths):
+        im = imread(fpath)
+        if im is None:
+            # the reference crashes here (cv2.imread returns None, infer.py:81-82); report and go on
+            print(fpath, '---> unreadable image, skipped')
+            continue
+        pending.append((i, im, _prepare(nn, im)))
+        if len(pending) >= batch_size:
+            for r in flush():
+                yield r
+    for r in flush():
+        yield r
+
+
+def groundtruth_validation(nn, list_fpath=None, batch_size=64):
+    """infer.py:41-57, with the list file it reads made an argument (the reference's global is
+    commented out, infer.py:28).  Prints and returns accuracy and per-class precision / recall /
+    f-score, computed like ``train.py:146-152``."""
+    from sklearn.metrics import accuracy_score, precision_recall_fscore_support
+    fpaths, labels, num_fpaths = read_fpaths(list_fpath or INPUT_IMG_PATH_LIST_FILE)
+    print('Inferring Images...')
+    y_preds, y_truths = [], []
+    for i, _im, idx, _conf in _infer_files(nn, fpaths, batch_size):
+        y_preds.append(idx)
+        y_truths.append(labels[i])
+    acc = accuracy_score(y_truths, y_preds)
+    prec, rec, fsc, supp = precision_recall_fscore_support(y_truths, y_preds, zero_division=0)
+    performance_stats = {'accuracy': float(acc),
+                         'precisions': list(map(float, list(prec))),
+                         'recalls': list(map(float, list(rec))),
+                         'f-scores': list(map(float, list(fsc)))}
+    print(performance_stats)
+    return performance_stats
+
+
+def force_makedir(dir):
+    """infer.py:60-62."""
+    if not os.path.isdir(dir):
+        os.makedirs(dir)
+
+
+def classify_im_dir(nn, imgs_dir, overlay=True, batch_size=64):
+    """infer.py:65-100."""
+    print('Classifying images in', imgs_dir)
+    all_im_paths = glob(imgs_dir + '/*')
+    out_dir = imgs_dir + '_classified'
+    xl_fpath = out_dir + '_results.xls'
+    class_dirs = [out_dir + os.sep + CLASS_LABELS[i] for i in range(len(CLASS_LABELS))]
+    for dir in class_dirs:
+        force_makedir(dir)
+    print('Beginning inference..')
+    excel_file = xls.Workbook()
+    sheet = excel_file.add_sheet('classification_results')
+    sheet.write(0, 0, 'IMAGE_NAME')
+    sheet.write(0, 1, 'PREDICTED_LABEL')
+    for i, im, idx, pred_conf in _infer_files(nn, all_im_paths, batch_size):
+        fpath = all_im_paths[i]
+        pred_label = CLASS_LABELS[idx]
+        out_fpath_dir = out_dir + os.sep + pred_label
+        print(fpath, '--->', pred_label, pred_conf)
+        if overlay:
+            h, w, _ = im.shape
+            put_text(im, "Predicted Class: " + pred_label, (int(.5 * w), int(.90 * h)), (h / 720.) * .85, (0, 255, 0))
+            put_text(im, "Confidence: " + str(round(pred_conf * 100, 2)) + " %", (int(.5 * w), int(.95 * h)),
+                     (h / 720.) * .85, (255, 0, 0))
+            imwrite(out_fpath_dir + os.sep + fpath.split(os.sep)[-1], im)
+        else:
+            shutil.copy(fpath, out_fpath_dir)
+        sheet.write(i + 1, 0, fpath.split(os.sep)[-1])
+        sheet.write(i + 1, 1, pred_label)
+        sheet.write(i + 1, 2, str(np.float32(pred_conf)))
+    excel_file.save(xl_fpath)
+    return xl_fpath
+
+
+if __name__ == '__main__':
+    nn = RoomNet(num_classes=len(CLASS_LABELS), im_side=IMG_SIDE, compute_bn_mean_var=False,
+                 optimized_inference=True)
+    nn.load(INPUT_MODEL_PATH)
+
+    # stats = groundtruth_validation(nn)
+    xl_out_path = classify_im_dir(nn, INPUT_IMAGES_DIR)

@@ -1,0 +1,214 @@
+"""CPU tests of the host-side pieces around the hot path: OpenCV-style resize restatement,
+xls writer, image I/O, list-file parsing, checkpoint save/load semantics of RoomNet."""
+import os
+
+import numpy as np
+import pytest
+
+from roomnet_amd import imageio, imageops, xls
+from xls_reader import read_xls
+
+
+# ------------------------------------------------------------------ resize (cv2.resize INTER_LINEAR, uint8)
+def _brute_force_linear(src, dw, dh):
+    """Scalar restatement of OpenCV's 8-bit bilinear resize (11-bit fixed-point coefficients)."""
+    sh, sw, cn = src.shape
+    sx_scale, sy_scale = 1.0 / (dw / sw), 1.0 / (dh / sh)
+    out = np.zeros((dh, dw, cn), np.uint8)
+
+    def coef(d, scale, ssize, clamp):
+        f = np.float32((d + 0.5) * scale - 0.5)
+        s = int(np.floor(f))
+        f = np.float32(f - np.float32(s))
+        if clamp:
+            if s < 0:
+                f, s = np.float32(0), 0
+            if s >= ssize - 1:
+                f, s = np.float32(0), ssize - 1
+        c0 = int(np.rint(np.float32(np.float32(1) - f) * np.float32(2048)))
+        c1 = int(np.rint(f * np.float32(2048)))
+        return s, c0, c1
+
+    for dy in range(dh):
+        sy, b0, b1 = coef(dy, sy_scale, sh, False)
+        y0, y1 = min(max(sy, 0), sh - 1), min(max(sy + 1, 0), sh - 1)
+        for dx in range(dw):
+            sx, a0, a1 = coef(dx, sx_scale, sw, True)
+            sx1 = min(sx + 1, sw - 1)
+            for c in range(cn):
+                r0 = int(src[y0, sx, c]) * a0 + int(src[y0, sx1, c]) * a1
+                r1 = int(src[y1, sx, c]) * a0 + int(src[y1, sx1, c]) * a1
+                out[dy, dx, c] = (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2
+    return out
+
+
+@pytest.mark.parametrize("shape,dst", [((37, 53, 3), (24, 24)), ((20, 20, 3), (33, 33)), ((50, 31, 1), (17, 40))])
+def test_resize_matches_scalar_restatement(shape, dst):
+    rng = np.random.default_rng(sum(shape))
+    src = rng.integers(0, 256, shape, dtype=np.uint8)
+    got = imageops.resize_linear_u8(src, dst[0], dst[1])
+    np.testing.assert_array_equal(got, _brute_force_linear(src, dst[0], dst[1]))
+
+
+def test_resize_properties():
+    rng = np.random.default_rng(5)
+    src = rng.integers(0, 256, (48, 48, 3), dtype=np.uint8)
+    same = imageops.resize_linear_u8(src, 48, 48)
+    np.testing.assert_array_equal(same, src)
+    assert same is not src
+    flat = np.full((31, 57, 3), 77, np.uint8)
+    assert (imageops.resize_linear_u8(flat, 224, 224) == 77).all()        # constants are preserved
+    half = imageops.resize_linear_u8(src, 24, 24)                          # exact 2x: 2x2 box average
+    s = src.astype(np.int32)
+    box = (s[0::2, 0::2] + s[0::2, 1::2] + s[1::2, 0::2] + s[1::2, 1::2] + 2) >> 2
+    np.testing.assert_array_equal(half, box.astype(np.uint8))
+    gray = imageops.resize_linear_u8(src[:, :, 0], 10, 12)
+    assert gray.shape == (12, 10)
+    with pytest.raises(TypeError):
+        imageops.resize_linear_u8(src.astype(np.float32), 8, 8)
+    up = imageops.resize_linear_u8(src, 96, 96)
+    assert up.min() >= src.min() and up.max() <= src.max()                  # convex combination
+
+
+# ------------------------------------------------------------------ xls writer
+def test_xls_round_trip(tmp_path):
+    wb = xls.Workbook()
+    sh = wb.add_sheet("classification_results")
+    sh.write(0, 0, "IMAGE_NAME")
+    sh.write(0, 1, "PREDICTED_LABEL")
+    rows = [("a b.jpg", "Kitchen", "0.9312"), ("ünï.png", "Bedroom", "0.5"), ("c.png", "Kitchen", "1.0")]
+    for i, (a, b, c) in enumerate(rows):
+        sh.write(i + 1, 0, a)
+        sh.write(i + 1, 1, b)
+        sh.write(i + 1, 2, c)
+    sh.write(5, 0, 12.5)
+    p = str(tmp_path / "out.xls")
+    wb.save(p)
+    got = read_xls(p)
+    assert list(got) == ["classification_results"]
+    cells = got["classification_results"]
+    assert cells[(0, 0)] == "IMAGE_NAME" and cells[(0, 1)] == "PREDICTED_LABEL"
+    for i, row in enumerate(rows):
+        assert tuple(cells[(i + 1, k)] for k in range(3)) == row
+    assert cells[(5, 0)] == 12.5
+    assert os.path.getsize(p) % 512 == 0
+    with pytest.raises(Exception):
+        sh.write(0, 0, "again")                                             # xlwt refuses overwrites too
+
+
+def test_xls_many_rows_and_sheets(tmp_path):
+    wb = xls.Workbook()
+    s1 = wb.add_sheet("one")
+    s2 = wb.add_sheet("two")
+    for i in range(3000):
+        s1.write(i, 0, "file_%05d.jpg" % i)
+        s1.write(i, 1, "label%d" % (i % 6))
+    s2.write(0, 0, "x")
+    p = str(tmp_path / "big.xls")
+    wb.save(p)
+    got = read_xls(p)
+    assert got["one"][(2999, 0)] == "file_02999.jpg" and got["one"][(1234, 1)] == "label4"
+    assert got["two"] == {(0, 0): "x"}
+    with pytest.raises(Exception):
+        wb.add_sheet("ONE")
+    with pytest.raises(ValueError):
+        wb.add_sheet("bad/name")
+
+
+# ------------------------------------------------------------------ image I/O
+def test_imread_imwrite_bgr_round_trip(tmp_path):
+    rng = np.random.default_rng(3)
+    im = rng.integers(0, 256, (40, 60, 3), dtype=np.uint8)
+    p = str(tmp_path / "x.png")
+    assert imageio.imwrite(p, im)
+    back = imageio.imread(p)
+    np.testing.assert_array_equal(back, im)                                 # PNG is lossless, BGR order kept
+    from PIL import Image
+    assert tuple(Image.open(p).getpixel((5, 7))) == tuple(int(v) for v in im[7, 5, ::-1])
+    Image.fromarray(im[:, :, 0]).save(str(tmp_path / "g.png"))               # grayscale -> 3 equal channels
+    g = imageio.imread(str(tmp_path / "g.png"))
+    assert g.shape == (40, 60, 3) and (g[..., 0] == g[..., 2]).all()
+    rgba = np.dstack([im[:, :, ::-1], np.full((40, 60), 128, np.uint8)])
+    Image.fromarray(rgba, "RGBA").save(str(tmp_path / "a.png"))
+    np.testing.assert_array_equal(imageio.imread(str(tmp_path / "a.png")), im)   # alpha dropped
+    (tmp_path / "junk.jpg").write_bytes(b"not an image")
+    assert imageio.imread(str(tmp_path / "junk.jpg")) is None
+    assert imageio.imread(str(tmp_path / "missing.png")) is None
+    jp = str(tmp_path / "x.jpg")
+    assert imageio.imwrite(jp, im) and imageio.imread(jp).shape == im.shape
+
+
+def test_put_text_draws_in_the_requested_colour():
+    im = np.zeros((720, 1280, 3), np.uint8)
+    imageio.put_text(im, "Predicted Class: Kitchen", (640, 648), (720 / 720.) * .85, (0, 255, 0))
+    assert im[..., 1].max() == 255 and im[..., 0].max() == 0 and im[..., 2].max() == 0
+    ys, xs = np.nonzero(im[..., 1])
+    assert xs.min() >= 640 and ys.max() <= 660 and ys.min() >= 600          # anchored at org (bottom-left)
+
+
+# ------------------------------------------------------------------ list files
+def test_read_fpaths(tmp_path):
+    pytest.importorskip("ctypes")
+    from roomnet_amd import _capi
+    if not os.path.isfile(_capi.LIB_PATH):
+        pytest.skip("library not built")
+    from roomnet_amd.infer import read_fpaths, CLASS_LABELS, IMG_SIDE
+    p = tmp_path / "list.txt"
+    p.write_text("C:\\data\\living room\\a b.jpg 5\nrel/x.png 0\n")
+    paths, ids, n = read_fpaths(str(p))
+    assert paths == ["C:\\data\\living room\\a b.jpg", "rel/x.png"] and ids == [5, 0] and n == 2
+    assert CLASS_LABELS == ['Backyard', 'Bathroom', 'Bedroom', 'Frontyard', 'Kitchen', 'LivingRoom']
+    assert IMG_SIDE == 224
+
+
+# ------------------------------------------------------------------ RoomNet persistence semantics (no GPU needed)
+def test_roomnet_init_load_save_semantics(tmp_path, weights, capsys, monkeypatch):
+    from roomnet_amd import _capi
+    if not os.path.isfile(_capi.LIB_PATH):
+        pytest.skip("library not built")
+    from roomnet_amd.network import RoomNet
+    from roomnet_amd import tf_bundle
+    from conftest import MODEL_PREFIX
+    nn = RoomNet(num_classes=6, im_side=224, compute_bn_mean_var=False, optimized_inference=True)
+    assert nn.sess is None and nn.num_classes == 6 and nn.im_side == 224
+    nn.load(MODEL_PREFIX)
+    assert "Model restored from" in capsys.readouterr().out
+    for k, v in weights.items():
+        np.testing.assert_array_equal(nn.sess.variables[k], v)
+    # save() in optimized mode writes ./roomnet.{index,data-...} like the reference (network.py:94-97)
+    monkeypatch.chdir(tmp_path)
+    nn.save()
+    assert "Model Saved in optimized inference mode" in capsys.readouterr().out
+    r = tf_bundle.BundleReader(str(tmp_path / "roomnet"))
+    assert sorted(r.keys()) == sorted(weights)
+    # load(None): newest step wins (network.py:108-118)
+    os.makedirs("all_trained_models/trained_models")
+    for step, scale in ((100, 1.0), (2500, 2.0), (900, 3.0)):
+        w2 = {k: (v * scale).astype(np.float32) for k, v in weights.items()}
+        tf_bundle.write_bundle("all_trained_models/trained_models/roomnet--0.5--%d" % step, w2)
+    nn2 = RoomNet(num_classes=6, im_side=224, compute_bn_mean_var=False, optimized_inference=True)
+    nn2.load()
+    assert nn2.step == 2500
+    np.testing.assert_array_equal(nn2.sess.variables["conv2d/kernel"], weights["conv2d/kernel"] * 2.0)
+    # training-mode restorer skips the dense blocks (restore_excluded_vars, network.py:242)
+    nn3 = RoomNet(num_classes=6, im_side=224, compute_bn_mean_var=False)
+    nn3.load(MODEL_PREFIX)
+    np.testing.assert_array_equal(nn3.sess.variables["conv2d_9/kernel"], weights["conv2d_9/kernel"])
+    assert not np.array_equal(nn3.sess.variables["dense/kernel"], weights["dense/kernel"])
+    # nothing to restore from
+    monkeypatch.chdir(tmp_path / "all_trained_models")
+    nn4 = RoomNet(num_classes=6, im_side=224, compute_bn_mean_var=False, optimized_inference=True)
+    nn4.load()
+    assert "No model found to restore from, initializing random weights" in capsys.readouterr().out
+    # wrong im_side for the checkpoint: dense/kernel shape mismatch, like TF's restore error
+    nn5 = RoomNet(num_classes=6, im_side=600, compute_bn_mean_var=False, optimized_inference=True)
+    with pytest.raises(ValueError):
+        nn5.load(MODEL_PREFIX)
+    with pytest.raises(IOError):
+        nn.load(str(tmp_path / "does_not_exist"))
+    with pytest.raises(NotImplementedError):
+        RoomNet(num_classes=6, im_side=224)            # compute_bn_mean_var=True is the training path
+    with pytest.raises(NotImplementedError):
+        nn.train_step(None, None)
+    x = np.arange(4 * 7 * 3).reshape(4, 7, 3)
+    np.testing.assert_array_equal(nn.center_crop(x), x[:, 1:5, :])

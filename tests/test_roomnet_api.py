@@ -1,0 +1,117 @@
+"""GPU tests of the drop-in Python surface (BASELINE config 1: the classify_im_dir driver on
+8 x 224x224 images) against the oracle restating the same reference calls."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import MODEL_PREFIX
+from oracle import c_oracle, roomnet_ref as R
+from roomnet_amd import imageio
+from roomnet_amd.imageops import resize_linear_u8
+from xls_reader import read_xls
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def nn():
+    from roomnet_amd.network import RoomNet
+    net = RoomNet(num_classes=6, im_side=224, compute_bn_mean_var=False, optimized_inference=True, max_batch=16)
+    net.load(MODEL_PREFIX)
+    yield net
+    net.sess.close()
+
+
+def test_infer_batch_matches_oracle(nn, weights, parity_images):
+    ims = parity_images[[1, 9, 14, 22, 30, 38]]
+    ids, probs = nn.infer(ims)
+    ref = c_oracle.infer(weights, ims)
+    assert ids.dtype == np.int64 and ids.shape == (6,) and probs.dtype == np.float32 and probs.shape == (6, 6)
+    np.testing.assert_allclose(probs, ref["probs"], atol=1e-5, rtol=0)
+    np.testing.assert_array_equal(ids, ref["ids"])
+    # float input goes through the reference's float64 expression
+    ids_f, probs_f = nn.infer(ims.astype(np.float64))
+    np.testing.assert_array_equal(probs_f, probs)
+    with pytest.raises(ValueError):
+        nn.infer(ims[:, :200])
+
+
+def test_infer_optimized_shapes_and_resize_path(nn, weights, parity_images):
+    im = parity_images[22]
+    idx, conf = nn.infer_optimized(im)
+    assert idx.shape == (1,) and idx.dtype == np.int64 and conf.shape == (1, 6) and conf.dtype == np.float32
+    ref = c_oracle.infer(weights, im[None])
+    np.testing.assert_allclose(conf, ref["probs"], atol=1e-5, rtol=0)
+    # non-square, non-224 input: centre crop + cv2-style bilinear resize on the host (network.py:149-152)
+    rng = np.random.default_rng(11)
+    big = (np.clip(np.add.outer(np.linspace(0, 200, 300), np.linspace(0, 55, 431))[..., None] +
+                   rng.integers(0, 40, (300, 431, 3)), 0, 255)).astype(np.uint8)
+    idx2, conf2 = nn.infer_optimized(big)
+    cropped = R.center_crop(big)
+    assert cropped.shape == (300, 300, 3)
+    prepared = resize_linear_u8(np.ascontiguousarray(cropped), 224, 224)
+    ref2 = c_oracle.infer(weights, prepared[None])
+    np.testing.assert_allclose(conf2, ref2["probs"], atol=1e-5, rtol=0)
+    assert idx2[0] == ref2["ids"][0]
+
+
+def test_training_mode_infer_returns_ids_only(weights, parity_images):
+    from roomnet_amd.network import RoomNet
+    net = RoomNet(num_classes=6, im_side=224, compute_bn_mean_var=False, max_batch=4)
+    net.load(MODEL_PREFIX)
+    net.set_variables({k: v for k, v in weights.items() if k.startswith("dense") or "normalization_1" in k})
+    out = net.infer(parity_images[[14, 30]])
+    assert isinstance(out, np.ndarray) and out.dtype == np.int64 and out.shape == (2,)
+    np.testing.assert_array_equal(out, c_oracle.infer(weights, parity_images[[14, 30]])["ids"])
+    net.sess.close()
+
+
+def test_classify_im_dir_end_to_end(nn, weights, parity_images, tmp_path, capsys):
+    from roomnet_amd.infer import CLASS_LABELS, classify_im_dir
+    d = tmp_path / "images"
+    d.mkdir()
+    pick = [1, 9, 14, 17, 22, 27, 30, 38]
+    for k, i in enumerate(pick):
+        assert imageio.imwrite(str(d / ("img_%02d.png" % k)), parity_images[i])
+    (d / "notes.txt").write_text("not an image")          # the reference would crash here; we skip it
+    ref = c_oracle.infer(weights, parity_images[pick])
+    xl = classify_im_dir(nn, str(d), overlay=True, batch_size=3)
+    assert xl == str(d) + "_classified_results.xls" and os.path.isfile(xl)
+    out = capsys.readouterr().out
+    assert "Classifying images in" in out and "Beginning inference.." in out and "unreadable image" in out
+    cells = read_xls(xl)["classification_results"]
+    assert cells[(0, 0)] == "IMAGE_NAME" and cells[(0, 1)] == "PREDICTED_LABEL"
+    rows = {cells[(r, 0)]: (cells[(r, 1)], float(cells[(r, 2)])) for r in {r for r, _ in cells} if r > 0}
+    assert len(rows) == 8
+    for k in range(8):
+        name = "img_%02d.png" % k
+        label, conf = rows[name]
+        assert label == CLASS_LABELS[ref["ids"][k]]
+        assert abs(conf - ref["probs"][k, ref["ids"][k]]) <= 1e-5
+        assert (name + " ---> " + label) in out.replace(str(d) + os.sep, "")
+        written = str(d) + "_classified" + os.sep + label + os.sep + name
+        assert os.path.isfile(written)
+        im = imageio.imread(written)
+        assert im.shape == (224, 224, 3) and (im != parity_images[pick[k]]).any()     # overlay drawn
+    for lab in CLASS_LABELS:
+        assert os.path.isdir(str(d) + "_classified" + os.sep + lab)
+    # overlay=False copies the files untouched
+    d2 = tmp_path / "copyset"
+    d2.mkdir()
+    imageio.imwrite(str(d2 / "a.png"), parity_images[14])
+    classify_im_dir(nn, str(d2), overlay=False)
+    lab = CLASS_LABELS[c_oracle.infer(weights, parity_images[14:15])["ids"][0]]
+    copied = str(d2) + "_classified" + os.sep + lab + os.sep + "a.png"
+    assert open(copied, "rb").read() == open(str(d2 / "a.png"), "rb").read()
+
+
+def test_bf16_model_through_the_python_surface(weights, parity_images, golden_parity):
+    from roomnet_amd.network import RoomNet
+    net = RoomNet(num_classes=6, im_side=224, compute_bn_mean_var=False, optimized_inference=True,
+                  dtype="bf16", max_batch=8)
+    net.load(MODEL_PREFIX)
+    ids, probs = net.infer(parity_images[:8])
+    safe = golden_parity["top2_margin"][:8] > 0.2
+    np.testing.assert_array_equal(ids[safe], golden_parity["ids"][:8][safe])
+    net.sess.close()
