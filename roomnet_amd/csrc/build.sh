@@ -8,6 +8,16 @@ mkdir -p "$OUT"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 FLAGS=(--offload-arch=gfx950 -O3 -std=c++20 -fno-slp-vectorize -fPIC -shared -fvisibility=hidden
        -I"$ROOT/include" -I"$HERE" -Wall -Wno-unused-function -DRN_BUILDING)
-"$HIPCC" "${FLAGS[@]}" "$HERE"/rn_api.hip "$HERE"/rn_kernels_f32.hip "$HERE"/rn_fused.hip "$HERE"/rn_stage_rw.hip \
+# objects are built separately so that per-file scheduler options can be applied
+OBJ="$ROOT/build/obj"
+mkdir -p "$OBJ"
+CFLAGS=("${FLAGS[@]/-shared/}")
+for f in rn_api rn_kernels_f32 rn_fused; do
+    "$HIPCC" "${CFLAGS[@]}" -c "$HERE/$f.hip" -o "$OBJ/$f.o" &
+done
+# (RN_RW_FLAGS: per-file scheduler experiments; max-ilp measured slower)
+"$HIPCC" "${CFLAGS[@]}" ${RN_RW_FLAGS:-} -c "$HERE/rn_stage_rw.hip" -o "$OBJ/rn_stage_rw.o" &
+wait
+"$HIPCC" --offload-arch=gfx950 -shared -fPIC "$OBJ"/rn_api.o "$OBJ"/rn_kernels_f32.o "$OBJ"/rn_fused.o "$OBJ"/rn_stage_rw.o \
     ${RN_EXTRA_FLAGS:-} -o "$OUT/libroomnet_hip.so"
 echo "built $OUT/libroomnet_hip.so"

@@ -526,7 +526,7 @@ int rn_fused_prepare(rn_handle* h, const rn_weights* w) {
             std::vector<float> tab(static_cast<size_t>(4) * s.cout, 0.f);
             for (int c = 0; c < s.cout; ++c) {
                 const float inv = (1.0f / sqrtf(ws.variance[c] + w->bn_epsilon)) * ws.gamma[c];
-                tab[c] = inv / static_cast<float>(s.pool_k * s.pool_k);
+                tab[c] = s.pool_k ? inv / static_cast<float>(s.pool_k * s.pool_k) : inv;
                 tab[s.cout + c] = ws.beta[c] - ws.mean[c] * inv;
                 if (s.skip_stage >= 0) {
                     const float inv2 = (1.0f / sqrtf(ws.variance2[c] + w->bn_epsilon)) * ws.gamma2[c];
@@ -654,6 +654,7 @@ int rn_fused_forward(rn_handle* h, const uint8_t* d_bgr, const float* d_rgb, int
             if (bands > max_bands) bands = max_bands;
             if (bands < 1) bands = 1;
             a.rows_per_band = (s.out_side + bands - 1) / bands;
+            if (s.pool_k == 0 && a.rows_per_band < 4) a.rows_per_band = 4;   // ring prologue depth
             a.n_bands = (s.out_side + a.rows_per_band - 1) / a.rows_per_band;
             dim3 grid(a.n_bands * a.n_colblocks, n);
             int rc = rn_rw_launch(f.rw, h->dtype, h->stream, a, grid);

@@ -39,12 +39,12 @@ constexpr int RW_NSLOT = 6;     // ring slots: 3 live input rows + 3 in flight
 constexpr int RW_AHEAD = 5;     // at step s the DMA for input row s + RW_AHEAD is issued
 constexpr int RW_SKIPBUF = 3;   // staged skip-row pairs (residual): 1 being read + 2 in flight
 
-template <int DT, int CIN, int COUT, int PS, bool RES, int NPT>
+template <int DT, int CIN, int COUT, int PK, int PS, bool RES, int NPT>
 struct RwCfg {
-    static constexpr int PK = 4;
     static constexpr int CP = CIN / 8;
     static constexpr int KC = (9 * CIN + 15) / 16;
-    static constexpr int CT = COUT / 32;
+    static constexpr int CT = (COUT + 31) / 32;
+    static constexpr int NG = COUT >= 32 ? 4 : COUT / 8;   // 4-channel groups per lane half-row
     static constexpr int CPO = COUT / 8;                       // 16-byte chunks per output/skip pixel
     static constexpr int TSTRIDE = tile_stride(PK, PS);
     static constexpr int NOUT_T = tile_nout(PK, PS);
@@ -62,9 +62,16 @@ struct RwCfg {
     // steady-state counted wait at the end of step s: everything up to input row s+3 and the
     // skip pair used by step s+1 has landed; what may stay in flight is what the wave issued
     // after them (the pieces of this step, plus one more row of input when there is no skip)
-    static constexpr int VMCNT_STEADY = RES ? LPT + SLPT : 2 * LPT;
-    static_assert(COUT % 32 == 0, "rw kernel needs whole 32-channel cout tiles");
-    static_assert(KC * 4 <= 80, "weights do not fit the register budget");
+    // (residual with pool stride 2 issues a skip pair on even steps only: per-phase counts)
+    static constexpr int vmcnt_steady(int phase) {
+        if (!RES) return 2 * LPT;
+        if (PS == 1) return LPT + SLPT;
+        return (phase & 1) == 0 ? 2 * LPT + 2 * SLPT : LPT;
+    }
+    static constexpr int VMCNT_STEADY = 2 * LPT + 2 * SLPT;   // upper bound (field-width check)
+    static_assert(COUT % 32 == 0 || COUT == 16, "cout must be whole 32-channel tiles (or one half tile)");
+    static_assert(PK == 0 || PK == 4, "pool window 4 or none");
+    static_assert(KC * 4 <= 80 || NTHREADS <= 256, "weights need the whole register file: <= 1 wave per SIMD");
     static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
     static_assert(RW_NSLOT % 2 == 0, "pool-ring parity is tied to the unroll");
     static_assert(VMCNT_STEADY <= 63, "vmcnt field");
@@ -93,12 +100,12 @@ __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int DT, int CIN, int COUT, int PS, bool RES, int NPT>
-__global__ __launch_bounds__(64 * NPT * (COUT / 32), 1) void stage_rw_kernel(const StageArgs a) {
-    using C = RwCfg<DT, CIN, COUT, PS, RES, NPT>;
+template <int DT, int CIN, int COUT, int PK, int PS, bool RES, int NPT>
+__global__ __launch_bounds__(64 * NPT * ((COUT + 31) / 32), 1) void stage_rw_kernel(const StageArgs a) {
+    using C = RwCfg<DT, CIN, COUT, PK, PS, RES, NPT>;
     constexpr int CP = C::CP, KC = C::KC, CT = C::CT, CPO = C::CPO, TSTRIDE = C::TSTRIDE, NOUT_T = C::NOUT_T;
     constexpr int RINGCOLS = C::RINGCOLS, ROWB = C::ROWB, NTHREADS = C::NTHREADS, LPT = C::LPT, SLPT = C::SLPT;
-    constexpr int PIXB = CIN * 2;
+    constexpr int PIXB = CIN * 2, NG = C::NG;
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -120,11 +127,11 @@ __global__ __launch_bounds__(64 * NPT * (COUT / 32), 1) void stage_rw_kernel(con
     const int yo0 = band * a.rows_per_band;
     const int yo1 = min(a.Ho, yo0 + a.rows_per_band);
     const int nout_rows = yo1 - yo0;
-    const int yc0 = yo0 * PS;
-    const int nconv = (nout_rows - 1) * PS + 4;
+    const int yc0 = PK ? yo0 * PS : yo0;
+    const int nconv = PK ? (nout_rows - 1) * PS + 4 : nout_rows;
     const int nin = nconv + 2;
     const int x0c = cb * NPT * TSTRIDE;
-    const int xo_blk0 = x0c / PS;
+    const int xo_blk0 = PK ? x0c / PS : x0c;
 
     // ---- folded BN tables -> LDS
     for (int i = tid; i < 4 * COUT; i += NTHREADS) ptab[i] = a.ptab[i];
@@ -190,9 +197,9 @@ __global__ __launch_bounds__(64 * NPT * (COUT / 32), 1) void stage_rw_kernel(con
         }
     };
 
-    // ---- prologue: rows 0 .. RW_AHEAD-1 in flight (nin >= 6 always)
+    // ---- prologue: rows 0 .. RW_AHEAD-1 in flight (clamped: a no-pool band can be shorter)
 #pragma unroll
-    for (int j = 0; j < RW_AHEAD; ++j) issue_row(j, j);
+    for (int j = 0; j < RW_AHEAD; ++j) issue_row(min(j, nin - 1), j);
 
     // ---- lane constants of this wave's pixel tile
     const int xrel0 = pt * TSTRIDE + r;
@@ -215,8 +222,8 @@ __global__ __launch_bounds__(64 * NPT * (COUT / 32), 1) void stage_rw_kernel(con
         }
     }
     const int xc = x0c + xrel0;
-    const int xo = xc / PS;
-    const bool lane_out = (r % PS == 0) && r <= 28 && xo < a.Wo && (xo - xo_blk0) < NPT * NOUT_T;
+    const int xo = PK ? xc / PS : xc;
+    const bool lane_out = (PK ? ((r % PS == 0) && r <= 32 - PK) : true) && xo < a.Wo && (xo - xo_blk0) < NPT * NOUT_T;
     unsigned short* const out_lane =
         a.out + (static_cast<int64_t>(n) * a.Ho * a.Wo + xo) * COUT + ct * 32 + 8 * hh;   // + yo*Wo*COUT + 8*k
     const float* const ptab_lane = ptab + ct * 32 + 4 * hh;                                // + 8*g (+ table*COUT)
@@ -280,9 +287,9 @@ __global__ __launch_bounds__(64 * NPT * (COUT / 32), 1) void stage_rw_kernel(con
     // lockstep: short live ranges, and the VALU-write -> DPP-read hazard is covered).
     auto epi_row = [&](auto JPC, const f32x16& acc, int j, int skip_buf) {
         constexpr int JP = decltype(JPC)::value;
-        constexpr bool emit_phase = PS == 1 || (JP & 1) == 1;
-        const bool emit = j >= 3;
-        const int e = (j - 3) / PS;                  // emitted output row (local)
+        constexpr bool emit_phase = PK == 0 || PS == 1 || (JP & 1) == 1;
+        const bool emit = PK ? j >= 3 : true;
+        const int e = PK ? (j - 3) / PS : j;         // emitted output row (local)
         const int yo = yo0 + e;
         float yl = 0.f;
         if constexpr (RES) {
@@ -293,17 +300,22 @@ __global__ __launch_bounds__(64 * NPT * (COUT / 32), 1) void stage_rw_kernel(con
         const char* sk1 = sk0 + skipbytes;
         uint2 pk[4];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
+        for (int g = 0; g < NG; ++g) {
             float v[4], t[4], u[4], hs[4], S[4];
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj) v[jj] = relu6f(acc[4 * g + jj]);
+            if constexpr (PK == 4) {
 #pragma unroll
-            for (int jj = 0; jj < 4; ++jj) t[jj] = v[jj] + lane_next(v[jj]);
+                for (int jj = 0; jj < 4; ++jj) t[jj] = v[jj] + lane_next(v[jj]);
 #pragma unroll
-            for (int jj = 0; jj < 4; ++jj) u[jj] = lane_next(t[jj]);
+                for (int jj = 0; jj < 4; ++jj) u[jj] = lane_next(t[jj]);
 #pragma unroll
-            for (int jj = 0; jj < 4; ++jj) hs[jj] = t[jj] + lane_next(u[jj]);
-            if constexpr (PS == 1) {
+                for (int jj = 0; jj < 4; ++jj) hs[jj] = t[jj] + lane_next(u[jj]);
+            }
+            if constexpr (PK == 0) {
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) S[jj] = v[jj];
+            } else if constexpr (PS == 1) {
                 // q_j = h_{j-1} + h_j ; S_j = q_{j-2} + q_j ; q ring by parity of j
 #pragma unroll
                 for (int jj = 0; jj < 4; ++jj) {
@@ -370,7 +382,7 @@ __global__ __launch_bounds__(64 * NPT * (COUT / 32), 1) void stage_rw_kernel(con
             // widen to 16-byte stores: lower half-wave gets channels 8k..8k+7, upper 8(k+1)..8(k+1)+7
             unsigned short* orow = out_lane + static_cast<int64_t>(yo) * a.Wo * COUT;
 #pragma unroll
-            for (int k = 0; k < 4; k += 2) {
+            for (int k = 0; k < NG; k += 2) {
                 const auto sx = __builtin_amdgcn_permlane32_swap(pk[k].x, pk[k + 1].x, false, false);
                 const auto sy = __builtin_amdgcn_permlane32_swap(pk[k].y, pk[k + 1].y, false, false);
                 uint4 vv;
@@ -384,8 +396,10 @@ __global__ __launch_bounds__(64 * NPT * (COUT / 32), 1) void stage_rw_kernel(con
     };
 
     // skip-pair bookkeeping: the pair for local output row e lives in buffer (e + 3k) mod 3
-    int sbuf_issue = 1;          // buffer for e = -2 (issued at step 0 for conv row j = 1)
-    int sbuf_read = 0;           // buffer read by the epilogue of conv row j = 0 (e = -3)
+    // PS = 1: first issue (step 0, conv row 1, e = -2) -> buffer 1; first read (row 0, e = -3) -> 0
+    // PS = 2: first issue (step 0, conv row 1, e = -1) -> buffer 2; first emit-phase read (row 1) -> 2
+    int sbuf_issue = PS == 1 ? 1 : 2;
+    int sbuf_read = PS == 1 ? 0 : 2;
 
     // one pipeline step s (ring phase P = s mod RW_NSLOT): DMA for row s+RW_AHEAD, MFMAs of conv
     // row s, epilogue of conv row s-1, counted wait, barrier
@@ -395,10 +409,11 @@ __global__ __launch_bounds__(64 * NPT * (COUT / 32), 1) void stage_rw_kernel(con
         const bool have_next = MMA && (s + RW_AHEAD < nin);
         if constexpr (MMA) {
             if (have_next) issue_row(s + RW_AHEAD, (P + RW_AHEAD) % RW_NSLOT);
-            if constexpr (RES) {
+            if constexpr (RES && (PS == 1 || (P & 1) == 0)) {
                 // pair for the epilogue of conv row s+1 (runs in step s+2): e = (s + 1 - 3) / PS
-                static_assert(!RES || PS == 1, "residual variant is stride 1");
-                issue_skip(s - 2, sbuf_issue);
+                // (stride 2: only odd conv rows emit, so pairs are issued on even steps)
+                static_assert(!RES || PK == 4, "residual variant pools");
+                issue_skip((s - 2) / PS, sbuf_issue);
                 sbuf_issue = sbuf_issue == RW_SKIPBUF - 1 ? 0 : sbuf_issue + 1;
             }
             if constexpr ((P & 1) == 0)
@@ -412,7 +427,9 @@ __global__ __launch_bounds__(64 * NPT * (COUT / 32), 1) void stage_rw_kernel(con
             else
                 epi_row(IC<(P + RW_NSLOT - 1) % RW_NSLOT>{}, acc0, s - 1, sbuf_read);
         }
-        if constexpr (RES && EPI) sbuf_read = sbuf_read == RW_SKIPBUF - 1 ? 0 : sbuf_read + 1;
+        // the epilogue of this step handled conv row s-1 (phase parity (P+1)&1): rotate after an emit phase
+        if constexpr (RES && EPI && (PS == 1 || ((P + 1) & 1) == 1))
+            sbuf_read = sbuf_read == RW_SKIPBUF - 1 ? 0 : sbuf_read + 1;
         if constexpr (MMA && EPI) {
             // software pipeline: spread the VALU epilogue of row s-1 through the MFMA chain of row s
             constexpr int VPG = RES ? 16 : 8;
@@ -425,7 +442,7 @@ __global__ __launch_bounds__(64 * NPT * (COUT / 32), 1) void stage_rw_kernel(con
         if constexpr (MMA) {
             // retire the DMA of input row s+3 (and of the skip pair the next epilogue reads)
             if (have_next)
-                wait_vmcnt<C::VMCNT_STEADY>();
+                wait_vmcnt<C::vmcnt_steady(P)>();
             else
                 wait_vmcnt<0>();
         }
@@ -475,10 +492,10 @@ __global__ __launch_bounds__(64 * NPT * (COUT / 32), 1) void stage_rw_kernel(con
     }
 }
 
-template <int DT, int CIN, int COUT, int PS, bool RES, int NPT>
+template <int DT, int CIN, int COUT, int PK, int PS, bool RES, int NPT>
 int launch_rw(hipStream_t s, const StageArgs& a, dim3 grid) {
-    using C = RwCfg<DT, CIN, COUT, PS, RES, NPT>;
-    auto kern = stage_rw_kernel<DT, CIN, COUT, PS, RES, NPT>;
+    using C = RwCfg<DT, CIN, COUT, PK, PS, RES, NPT>;
+    auto kern = stage_rw_kernel<DT, CIN, COUT, PK, PS, RES, NPT>;
     static bool attr_set = false;
     if (!attr_set) {
         RN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -490,10 +507,10 @@ int launch_rw(hipStream_t s, const StageArgs& a, dim3 grid) {
     return RN_OK;
 }
 
-template <int CIN, int COUT, int PS, bool RES, int NPT>
+template <int CIN, int COUT, int PK, int PS, bool RES, int NPT>
 int launch_rw_dt(int dtype, hipStream_t s, const StageArgs& a, dim3 grid) {
-    if (dtype == RN_DTYPE_BF16) return launch_rw<RN_DTYPE_BF16, CIN, COUT, PS, RES, NPT>(s, a, grid);
-    return launch_rw<RN_DTYPE_F16, CIN, COUT, PS, RES, NPT>(s, a, grid);
+    if (dtype == RN_DTYPE_BF16) return launch_rw<RN_DTYPE_BF16, CIN, COUT, PK, PS, RES, NPT>(s, a, grid);
+    return launch_rw<RN_DTYPE_F16, CIN, COUT, PK, PS, RES, NPT>(s, a, grid);
 }
 
 }  // namespace
@@ -502,18 +519,21 @@ int launch_rw_dt(int dtype, hipStream_t s, const StageArgs& a, dim3 grid) {
 // the caller can use the generic kernel.
 bool rn_rw_supported(int cin, int cout, int pool_k, int pool_s, bool res, int out_side, int skip_side,
                      RwPlan* plan) {
-    if (pool_k != 4 || (pool_s != 1 && pool_s != 2)) return false;
-    int variant = -1;
-    if (cin == 8 && cout == 32 && pool_s == 1 && !res) variant = 0;
-    if (cin == 32 && cout == 32 && pool_s == 1 && !res) variant = 1;
-    if (cin == 32 && cout == 32 && pool_s == 1 && res) variant = 2;
-    if (cin == 32 && cout == 64 && pool_s == 2 && !res) variant = 3;
-    if (variant < 0) return false;
-    const int nout_t = tile_nout(4, pool_s), tstride = tile_stride(4, pool_s);
+    if (pool_k != 4 && pool_k != 0) return false;
+    if (pool_k == 4 && pool_s != 1 && pool_s != 2) return false;
+    const int ps = pool_k ? pool_s : 1;
+    int variant = -1, npt = 0;
+    const int nout_t = tile_nout(pool_k, ps), tstride = tile_stride(pool_k, ps);
     const int tiles = (out_side + nout_t - 1) / nout_t;
-    // 8 waves per workgroup: 8 pixel tiles x 1 cout tile, or 4 pixel tiles x 2 cout tiles;
-    // the residual variant runs 4 tiles (4 waves, one per SIMD, whole register file)
-    int npt = (cout == 64 || res) ? 4 : (tiles > 4 ? 8 : 4);
+    // waves per workgroup = npt x cout tiles: 8 waves (two per SIMD, <= 256 registers) where the
+    // weights are small, 4 or 2 waves (one per SIMD, whole register file) for K >= 576 / residual
+    if (cin == 8 && cout == 32 && pool_k == 4 && ps == 1 && !res) variant = 0, npt = tiles > 4 ? 8 : 4;
+    if (cin == 32 && cout == 32 && pool_k == 4 && ps == 1 && !res) variant = 1, npt = tiles > 4 ? 8 : 4;
+    if (cin == 32 && cout == 32 && pool_k == 4 && ps == 1 && res) variant = 2, npt = 4;
+    if (cin == 32 && cout == 64 && pool_k == 4 && ps == 2 && !res) variant = 3, npt = 4;
+    if (cin == 64 && cout == 64 && pool_k == 4 && ps == 2 && res) variant = 4, npt = 2;
+    if (cin == 64 && cout == 128 && pool_k == 0 && !res) variant = 5, npt = 1;
+    if (variant < 0) return false;
     plan->variant = variant;
     plan->npt = npt;
     plan->n_colblocks = (tiles + npt - 1) / npt;
@@ -523,11 +543,10 @@ bool rn_rw_supported(int cin, int cout, int pool_k, int pool_s, bool res, int ou
     if (res) {
         // columns of the skip tensor a column block touches: rlo[first] .. rhi[last]
         const float scale = static_cast<float>(skip_side) / static_cast<float>(out_side);
-        if (scale > 1.1f) return false;
         const int cols_out = npt * nout_t;
         int skipcols = static_cast<int>(cols_out * scale) + 3;
         if (skipcols > skip_side) skipcols = skip_side;
-        if (skipcols > ringcols + 8) return false;
+        if (skipcols > ringcols + 8) return false;      // SKIPCOLS_MAX of the kernel
         plan->skipcols = skipcols;
     }
     return true;
@@ -535,12 +554,14 @@ bool rn_rw_supported(int cin, int cout, int pool_k, int pool_s, bool res, int ou
 
 int rn_rw_launch(const RwPlan& p, int dtype, hipStream_t s, const StageArgs& a, dim3 grid) {
     switch (p.variant * 16 + p.npt) {
-        case 0 * 16 + 4: return launch_rw_dt<8, 32, 1, false, 4>(dtype, s, a, grid);
-        case 0 * 16 + 8: return launch_rw_dt<8, 32, 1, false, 8>(dtype, s, a, grid);
-        case 1 * 16 + 4: return launch_rw_dt<32, 32, 1, false, 4>(dtype, s, a, grid);
-        case 1 * 16 + 8: return launch_rw_dt<32, 32, 1, false, 8>(dtype, s, a, grid);
-        case 2 * 16 + 4: return launch_rw_dt<32, 32, 1, true, 4>(dtype, s, a, grid);
-        case 3 * 16 + 4: return launch_rw_dt<32, 64, 2, false, 4>(dtype, s, a, grid);
+        case 0 * 16 + 4: return launch_rw_dt<8, 32, 4, 1, false, 4>(dtype, s, a, grid);
+        case 0 * 16 + 8: return launch_rw_dt<8, 32, 4, 1, false, 8>(dtype, s, a, grid);
+        case 1 * 16 + 4: return launch_rw_dt<32, 32, 4, 1, false, 4>(dtype, s, a, grid);
+        case 1 * 16 + 8: return launch_rw_dt<32, 32, 4, 1, false, 8>(dtype, s, a, grid);
+        case 2 * 16 + 4: return launch_rw_dt<32, 32, 4, 1, true, 4>(dtype, s, a, grid);
+        case 3 * 16 + 4: return launch_rw_dt<32, 64, 4, 2, false, 4>(dtype, s, a, grid);
+        case 4 * 16 + 2: return launch_rw_dt<64, 64, 4, 2, true, 2>(dtype, s, a, grid);
+        case 5 * 16 + 1: return launch_rw_dt<64, 128, 0, 1, false, 1>(dtype, s, a, grid);
         default:
             rn_set_error("rw kernel: no instantiation for variant %d npt %d", p.variant, p.npt);
             return RN_E_INVALID;
