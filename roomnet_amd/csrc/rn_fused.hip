@@ -37,90 +37,132 @@ using namespace rnk;
 namespace {
 
 // ------------------------------------------------------------------------------ stage 0
-// uint8 BGR [N,S,S,3] -> table -> conv3x3 (3->COUT0) -> ReLU6 -> avg-pool 3x3/1 -> BN -> 16-bit NHWC.
-// Output tile 32 x 8 pixels per 256-thread workgroup.
-constexpr int S0_TW = 32, S0_TH = 8, S0_CO = 8;
+// uint8 BGR [N,S,S,3] -> table -> conv3x3 (3 -> 8) -> ReLU6 -> avg-pool 3x3/1 -> BN -> 16-bit NHWC.
+//
+// Row streaming on the matrix cores with the im2col built entirely in registers:
+//   * K is laid out as (ky, kx in 0..3, c in 0..3) = 48 (kx = 3 and c = 3 are zero weights), i.e.
+//     ONE 16-deep MFMA K-chunk per input row ky.  For v_mfma_f32_32x32x16 the B operand of lane
+//     (r, h) is then: h = 0: pixels r and r+1 (4 x 16-bit each), h = 1: pixel r+2 and zeros.
+//   * lane (r, h) loads ITS pixel x0 + r + 2h (3 bytes), maps it through the 256-entry table
+//     (LDS, 16-bit) and packs (R,G | B,0); the lower half-wave gets pixel r+1 from its
+//     neighbour lane with a DPP shift.  The fragments of the last 3 input rows stay in 12 VGPRs.
+//   * D[cout][pixel]: only rows 0..7 are real, so a lane owns 4 channels of one conv pixel in 4
+//     accumulator registers: ReLU6, 3-wide horizontal sum by DPP, 3-row vertical sum in a
+//     register ring, one fma for BN, one 8-byte store.  No LDS traffic besides the table.
+// A wave owns 32 conv columns (29 output columns, tiles overlap by 3) and walks down a band of
+// rows; a workgroup is up to 8 such waves side by side.
+// The MFMA inputs of this stage are ALWAYS fp16 (table and weights), whatever the storage type
+// of the activations: bf16's 8-bit significand cannot represent the 256 input levels (it costs
+// about one bit of image depth and the error is amplified ~10x by the following BN gains;
+// measured: stage-2 error 0.5 % -> 3.9 % of abs-max), fp16's 11 bits can.
+constexpr int S0_CO = 8;
+constexpr int S0_TSTRIDE = 29;      // output columns per 32-column tile: 32 - (3 - 1) - 1
+constexpr int S0_AHEAD = 4;         // input rows prefetched (bytes in registers)
+
+struct Stage0Args {
+    const uint8_t* bgr;             // [N, S, S, 3]
+    const unsigned short* lut16;    // 256 entries, storage dtype
+    const i32x4* wfrag;             // [3 (ky)][64 lanes] A fragments, 8 x 16-bit
+    const float* ptab;              // [2][8] folded BN: scale (inv / 9), shift
+    unsigned short* out;            // [N, So, So, 8]
+    int S, So;
+    int rows_per_band, n_bands, n_colblocks, npt;
+};
 
 template <int DT>
-__global__ __launch_bounds__(256) void stage0_kernel(const uint8_t* __restrict__ bgr,
-                                                     const float* __restrict__ lut,
-                                                     const float* __restrict__ w,   // [3][3][3][8] HWIO
-                                                     const float* __restrict__ bn_mean,
-                                                     const float* __restrict__ bn_inv,
-                                                     const float* __restrict__ bn_beta,
-                                                     unsigned short* __restrict__ out, int S, int So) {
-    constexpr int CW = S0_TW + 2, CH = S0_TH + 2;     // conv tile 34 x 10
-    constexpr int IW = CW + 2, IH = CH + 2;           // input tile 36 x 12
-    __shared__ float s_in[3][IH][IW];
-    __shared__ __attribute__((aligned(16))) float s_conv[CH][CW][S0_CO];
-    const int n = blockIdx.z;
-    const int ox0 = blockIdx.x * S0_TW, oy0 = blockIdx.y * S0_TH;
+__global__ __launch_bounds__(512) void stage0_kernel(const Stage0Args a) {
+    __shared__ unsigned short s_lut[256];
     const int tid = threadIdx.x;
-    const uint8_t* img = bgr + static_cast<int64_t>(n) * S * S * 3;
-    for (int p = tid; p < IW * IH; p += 256) {
-        const int ix = p % IW, iy = p / IW;
-        const int gx = ox0 + ix, gy = oy0 + iy;
-        float r = 0.f, g = 0.f, b = 0.f;
-        if (gx < S && gy < S) {
-            const uint8_t* px = img + (static_cast<int64_t>(gy) * S + gx) * 3;
-            b = lut[px[0]];
-            g = lut[px[1]];
-            r = lut[px[2]];
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, hh = lane >> 5;
+    const int cb = blockIdx.x % a.n_colblocks;
+    const int band = blockIdx.x / a.n_colblocks;
+    const int n = blockIdx.y;
+    for (int i = tid; i < 256; i += blockDim.x) s_lut[i] = a.lut16[i];
+
+    const int yo0 = band * a.rows_per_band;
+    const int yo1 = min(a.So, yo0 + a.rows_per_band);
+    const int nconv = (yo1 - yo0) + 2;                 // conv rows of the band (pool 3, stride 1)
+    const int nin = nconv + 2;                         // input rows
+    const int xt0 = (cb * a.npt + wave) * S0_TSTRIDE;  // first conv / input column of this wave's tile
+    const int px = min(xt0 + r + 2 * hh, a.S - 1);     // this lane's input column (clamped at the edge)
+    const uint8_t* src = a.bgr + (static_cast<int64_t>(n) * a.S * a.S + static_cast<int64_t>(yo0) * a.S + px) * 3;
+    const int row_bytes = a.S * 3;
+
+    i32x4 wreg[3];
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) wreg[ky] = a.wfrag[ky * 64 + lane];
+    const f32x4 scale = *reinterpret_cast<const f32x4*>(a.ptab + 4 * hh);
+    const f32x4 shift = *reinterpret_cast<const f32x4*>(a.ptab + 8 + 4 * hh);
+    const int xo = xt0 + r;
+    const bool lane_out = r < S0_TSTRIDE && xo < a.So && (xo - cb * a.npt * S0_TSTRIDE) < a.npt * S0_TSTRIDE;
+    unsigned short* out_lane = a.out + (static_cast<int64_t>(n) * a.So * a.So + xo) * S0_CO + 4 * hh;
+    const unsigned nb_mask = hh ? 0u : 0xffffffffu;    // the upper half-wave's second pixel slot is zero
+
+    // prefetch queue of raw bytes
+    unsigned pb[S0_AHEAD], pg[S0_AHEAD], pr[S0_AHEAD];
+#pragma unroll
+    for (int i = 0; i < S0_AHEAD; ++i) {
+        const uint8_t* p = src + static_cast<int64_t>(min(i, nin - 1)) * row_bytes;
+        pb[i] = p[0];
+        pg[i] = p[1];
+        pr[i] = p[2];
+    }
+    __syncthreads();
+
+    i32x4 bfr[3];                                      // B fragments of the 3 live input rows
+    float h1[4], h2[4];                                // horizontal sums of the two previous conv rows
+#pragma unroll
+    for (int j = 0; j < 4; ++j) h1[j] = h2[j] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) bfr[i] = i32x4{0, 0, 0, 0};
+
+    // consume the oldest prefetched row into a B fragment, refill the queue slot
+    auto next_frag = [&](int jrow) -> i32x4 {
+        const unsigned cr = s_lut[pr[0]], cg = s_lut[pg[0]], cbl = s_lut[pb[0]];
+        const int d0 = static_cast<int>(cr | (cg << 16)), d1 = static_cast<int>(cbl);
+#pragma unroll
+        for (int i = 0; i + 1 < S0_AHEAD; ++i) {
+            pb[i] = pb[i + 1];
+            pg[i] = pg[i + 1];
+            pr[i] = pr[i + 1];
         }
-        s_in[0][iy][ix] = r;
-        s_in[1][iy][ix] = g;
-        s_in[2][iy][ix] = b;
-    }
-    __syncthreads();
-    for (int p = tid; p < CW * CH; p += 256) {
-        const int cx = p % CW, cy = p / CW;
-        float acc[S0_CO];
+        const uint8_t* p = src + static_cast<int64_t>(min(jrow + S0_AHEAD, nin - 1)) * row_bytes;
+        pb[S0_AHEAD - 1] = p[0];
+        pg[S0_AHEAD - 1] = p[1];
+        pr[S0_AHEAD - 1] = p[2];
+        i32x4 f;
+        f[0] = d0;
+        f[1] = d1;
+        f[2] = static_cast<int>(static_cast<unsigned>(__builtin_amdgcn_update_dpp(0, d0, 0x130, 0xf, 0xf, true)) & nb_mask);
+        f[3] = static_cast<int>(static_cast<unsigned>(__builtin_amdgcn_update_dpp(0, d1, 0x130, 0xf, 0xf, true)) & nb_mask);
+        return f;
+    };
+    bfr[0] = next_frag(0);
+    bfr[1] = next_frag(1);
+
+    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int it = 0; it < nconv; ++it) {
+        bfr[2] = next_frag(it + 2);
+        f32x16 acc = mfma32<RN_DTYPE_F16>(wreg[0], bfr[0], zero);
+        acc = mfma32<RN_DTYPE_F16>(wreg[1], bfr[1], acc);
+        acc = mfma32<RN_DTYPE_F16>(wreg[2], bfr[2], acc);
+        bfr[0] = bfr[1];
+        bfr[1] = bfr[2];
+        float y[4];
 #pragma unroll
-        for (int o = 0; o < S0_CO; ++o) acc[o] = 0.f;
-#pragma unroll
-        for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-            for (int kx = 0; kx < 3; ++kx)
-#pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    const float v = s_in[c][cy + ky][cx + kx];
-                    const float* wr = w + ((ky * 3 + kx) * 3 + c) * S0_CO;
-#pragma unroll
-                    for (int o = 0; o < S0_CO; ++o) acc[o] = fmaf(v, wr[o], acc[o]);
-                }
-#pragma unroll
-        for (int o = 0; o < S0_CO; ++o) s_conv[cy][cx][o] = relu6f(acc[o]);
-    }
-    __syncthreads();
-    const int tx = tid % S0_TW, ty = tid / S0_TW;
-    const int ox = ox0 + tx, oy = oy0 + ty;
-    if (ox < So && oy < So) {
-        float acc[S0_CO];
-#pragma unroll
-        for (int o = 0; o < S0_CO; ++o) acc[o] = 0.f;
-#pragma unroll
-        for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-            for (int kx = 0; kx < 3; ++kx) {
-                const f32x4 a = *reinterpret_cast<const f32x4*>(&s_conv[ty + ky][tx + kx][0]);
-                const f32x4 b = *reinterpret_cast<const f32x4*>(&s_conv[ty + ky][tx + kx][4]);
-#pragma unroll
-                for (int o = 0; o < 4; ++o) {
-                    acc[o] += a[o];
-                    acc[4 + o] += b[o];
-                }
-            }
-        float y[S0_CO];
-#pragma unroll
-        for (int o = 0; o < S0_CO; ++o) y[o] = (acc[o] / 9.0f - bn_mean[o]) * bn_inv[o] + bn_beta[o];
-        const uint2 lo = pack4<DT>(y[0], y[1], y[2], y[3]);
-        const uint2 hi = pack4<DT>(y[4], y[5], y[6], y[7]);
-        uint4 v;
-        v.x = lo.x;
-        v.y = lo.y;
-        v.z = hi.x;
-        v.w = hi.y;
-        *reinterpret_cast<uint4*>(out + ((static_cast<int64_t>(n) * So + oy) * So + ox) * S0_CO) = v;
+        for (int j = 0; j < 4; ++j) {
+            const float v = relu6f(acc[j]);
+            const float v1 = lane_next(v);
+            const float hs = (v + v1) + lane_next(v1);
+            y[j] = fmaf((h2[j] + h1[j]) + hs, scale[j], shift[j]);
+            h2[j] = h1[j];
+            h1[j] = hs;
+        }
+        if (it >= 2 && lane_out)
+            *reinterpret_cast<uint2*>(out_lane + static_cast<int64_t>(yo0 + it - 2) * a.So * S0_CO) =
+                pack4<DT>(y[0], y[1], y[2], y[3]);
     }
 }
 
@@ -481,6 +523,10 @@ constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 
 struct FusedState {
     std::vector<FusedStage> st;
+    // stage 0
+    unsigned short* s0_lut16 = nullptr;
+    i32x4* s0_wfrag = nullptr;
+    float* s0_ptab = nullptr;
 };
 
 }  // namespace
@@ -501,6 +547,48 @@ int rn_fused_prepare(rn_handle* h, const rn_weights* w) {
         rn_set_error("16-bit path: stage 0 must be conv(3->8) + pool 3/1 (got %d->%d pool %d/%d)", h->stages[0].cin,
                      h->stages[0].cout, h->stages[0].pool_k, h->stages[0].pool_s);
         return RN_E_INVALID;
+    }
+    {
+        // stage-0 tables: 16-bit pre-processing table, A fragments with K = (ky, kx<4, c<4), folded BN
+        auto cvt = [&](float v) { return f32_to_f16(v); };   // stage-0 MFMA inputs are always fp16
+        std::vector<unsigned short> lut(256);
+        for (int v = 0; v < 256; ++v)
+            lut[v] = cvt(static_cast<float>(((static_cast<double>(v) / 255.) * 2) - 1));
+        std::vector<unsigned short> frag(3 * 64 * 8, 0);
+        const float* w0 = w->stages[0].kernel;       // [ky][kx][c][cout]
+        for (int ky = 0; ky < 3; ++ky)
+            for (int l = 0; l < 64; ++l)
+                for (int j = 0; j < 8; ++j) {
+                    const int kk = 8 * (l >> 5) + j, kx = kk / 4, c = kk % 4, co = l & 31;
+                    float v = 0.f;
+                    if (kx < 3 && c < 3 && co < S0_CO) v = w0[((ky * 3 + kx) * 3 + c) * S0_CO + co];
+                    frag[(ky * 64 + l) * 8 + j] = cvt(v);
+                }
+        const rn_conv_stage& ws = w->stages[0];
+        std::vector<float> tab(16);
+        for (int c = 0; c < S0_CO; ++c) {
+            const float inv = (1.0f / sqrtf(ws.variance[c] + w->bn_epsilon)) * ws.gamma[c];
+            tab[c] = inv / 9.0f;
+            tab[8 + c] = ws.beta[c] - ws.mean[c] * inv;
+        }
+        void* d = nullptr;
+        auto up = [&](const void* src, size_t bytes, void** out) -> int {
+            hipError_t e = hipMalloc(out, bytes);
+            if (e != hipSuccess) {
+                rn_set_error("hipMalloc(stage 0 tables) failed: %s", hipGetErrorString(e));
+                return RN_E_NOMEM;
+            }
+            h->allocs.push_back(*out);
+            RN_HIP(hipMemcpy(*out, src, bytes, hipMemcpyHostToDevice));
+            return RN_OK;
+        };
+        int rc;
+        if ((rc = up(lut.data(), lut.size() * 2, &d)) != RN_OK) return rc;
+        fs->s0_lut16 = static_cast<unsigned short*>(d);
+        if ((rc = up(frag.data(), frag.size() * 2, &d)) != RN_OK) return rc;
+        fs->s0_wfrag = static_cast<i32x4*>(d);
+        if ((rc = up(tab.data(), tab.size() * 4, &d)) != RN_OK) return rc;
+        fs->s0_ptab = static_cast<float*>(d);
     }
     for (size_t i = 1; i < h->stages.size(); ++i) {
         StagePlan& s = h->stages[i];
@@ -600,14 +688,30 @@ int rn_fused_forward(rn_handle* h, const uint8_t* d_bgr, const float* d_rgb, int
     // stage 0
     {
         const StagePlan& s = h->stages[0];
-        unsigned short* out = static_cast<unsigned short*>(h->nodes[s.node_bn].ptr);
-        dim3 grid((s.out_side + S0_TW - 1) / S0_TW, (s.out_side + S0_TH - 1) / S0_TH, n);
+        Stage0Args a0{};
+        a0.bgr = d_bgr;
+        a0.lut16 = fs->s0_lut16;
+        a0.wfrag = fs->s0_wfrag;
+        a0.ptab = fs->s0_ptab;
+        a0.out = static_cast<unsigned short*>(h->nodes[s.node_bn].ptr);
+        a0.S = s.in_side;
+        a0.So = s.out_side;
+        const int tiles = (s.out_side + S0_TSTRIDE - 1) / S0_TSTRIDE;
+        a0.npt = tiles >= 8 ? 8 : tiles;
+        a0.n_colblocks = (tiles + a0.npt - 1) / a0.npt;
+        // ~4 workgroups of 8 waves per CU across the launch, at least 8 output rows per band
+        const int per_band = n * a0.n_colblocks;
+        int bands = (1024 + per_band - 1) / per_band;
+        const int max_bands = (s.out_side + 7) / 8;
+        if (bands > max_bands) bands = max_bands;
+        if (bands < 1) bands = 1;
+        a0.rows_per_band = (s.out_side + bands - 1) / bands;
+        a0.n_bands = (s.out_side + a0.rows_per_band - 1) / a0.rows_per_band;
+        dim3 grid(a0.n_bands * a0.n_colblocks, n);
         if (dti == 0)
-            hipLaunchKernelGGL(stage0_kernel<RN_DTYPE_BF16>, grid, dim3(256), 0, h->stream, d_bgr, h->lut, s.w_f32,
-                               s.bn.mean, s.bn.inv, s.bn.beta, out, s.in_side, s.out_side);
+            hipLaunchKernelGGL(stage0_kernel<RN_DTYPE_BF16>, grid, dim3(64 * a0.npt), 0, h->stream, a0);
         else
-            hipLaunchKernelGGL(stage0_kernel<RN_DTYPE_F16>, grid, dim3(256), 0, h->stream, d_bgr, h->lut, s.w_f32,
-                               s.bn.mean, s.bn.inv, s.bn.beta, out, s.in_side, s.out_side);
+            hipLaunchKernelGGL(stage0_kernel<RN_DTYPE_F16>, grid, dim3(64 * a0.npt), 0, h->stream, a0);
         RN_CHECK_LAUNCH();
         rn_record_event(h, 2);
     }
