@@ -23,6 +23,7 @@
 #include "rn_fused.h"
 #include "rn_stage.h"
 
+#include <algorithm>
 #include <type_traits>
 #include <utility>
 
@@ -228,19 +229,62 @@ __global__ __launch_bounds__(64 * NPT * ((COUT + 31) / 32), 1) void stage_rw_ker
         a.out + (static_cast<int64_t>(n) * a.Ho * a.Wo + xo) * COUT + ct * 32 + 8 * hh;   // + yo*Wo*COUT + 8*k
     const float* const ptab_lane = ptab + ct * 32 + 4 * hh;                                // + 8*g (+ table*COUT)
 
-    int sk_lo[4], sk_hi[4];      // byte offsets inside a staged skip row, per channel group
-    float rx_l = 0.f;
+    // ---- residual on the matrix cores: R[cout][x_out] = Skip^T[cout][x_in] * Wx[x_in][x_out]
+    // (Wx = the legacy-bilinear interpolation matrix of this tile: two non-zeros per column).
+    // K = 32 skip columns starting at the tile's first source column; A fragments come from
+    // the staged [x_in][cout] skip rows with the transposed read ds_read_b64_tr_b16; the
+    // weights are lane constants, split hi + lo into two 16-bit operands so the interpolation
+    // keeps ~16 bits (one bf16 operand would quantise the lerp weights to 8 bits).
+    int a_off[4];                // byte offsets of the 4 transposed reads (2 K-chunks x 2 halves)
+    i32x4 bw_h[2], bw_l[2];
     if constexpr (RES) {
+        const int xo_t0 = min((x0c + pt * TSTRIDE) / PS, a.Wo - 1);
+        const int xs_t = a.rlo[xo_t0] - xs0;                 // K origin inside the staged block
         const int xq = min(xo, a.Wo - 1);
         const int plo = a.rlo[xq] - xs0, phi = a.rhi[xq] - xs0;
-        rx_l = a.rlerp[xq];
+        const float xl = a.rlerp[xq];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int c16 = ct * 4 + g;
-            sk_lo[g] = (plo * CPO + (c16 ^ chunk_swz<CPO>(plo))) * 16 + hh * 8;
-            sk_hi[g] = (phi * CPO + (c16 ^ chunk_swz<CPO>(phi))) * 16 + hh * 8;
+        for (int c = 0; c < 2; ++c) {
+            unsigned short wh[8], wl[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int xin = xs_t + 16 * c + 8 * hh + j;
+                float w = 0.f;
+                if (xin == plo) w += 1.0f - xl;
+                if (xin == phi) w += xl;
+                wh[j] = to16<DT>(w);
+                wl[j] = to16<DT>(w - from16<DT>(wh[j]));
+            }
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                bw_h[c][d] = static_cast<int>(static_cast<unsigned>(wh[2 * d]) | (static_cast<unsigned>(wh[2 * d + 1]) << 16));
+                bw_l[c][d] = static_cast<int>(static_cast<unsigned>(wl[2 * d]) | (static_cast<unsigned>(wl[2 * d + 1]) << 16));
+            }
         }
+        // transposed read: lane 4q+p of a 16-lane group addresses row q, columns 4p..4p+3 of a
+        // 4-row x 16-column block and receives column (lane & 15) of the 4 rows
+        const int grp = lane >> 4, li = lane & 15, q = li >> 2, pp = li & 3;
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int pix = min(max(xs_t + 16 * c + 8 * (grp >> 1) + 4 * t + q, 0), a.skipcols - 1);
+                const int ch = ct * 4 + 2 * (grp & 1) + (pp >> 1);
+                a_off[2 * c + t] = (pix * CPO + (ch ^ chunk_swz<CPO>(pix))) * 16 + (pp & 1) * 8;
+            }
     }
+    // The transposed reads go through inline asm on purpose: for an LDS load with a typed
+    // address-space-3 pointer hipcc's waitcnt pass cannot prove the read does not alias the
+    // in-flight LDS-DMA writes and inserts s_waitcnt vmcnt(0) in front of it, draining the whole
+    // prefetch queue every row.  The skip pair read here was retired by the counted wait of the
+    // previous step.  The asm loads are waited for by skip_wait() (names every destination).
+    using i32x2 = __attribute__((ext_vector_type(2))) int;
+    auto tr_read = [&](const char* p) -> i32x2 {
+        i32x2 v;
+        const unsigned addr = static_cast<unsigned>(reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) const char*)p));
+        asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(addr));
+        return v;
+    };
 
     // ---- pooling state
     float hprev[16], q0[16], q1[16];
@@ -298,6 +342,26 @@ __global__ __launch_bounds__(64 * NPT * ((COUT + 31) / 32), 1) void stage_rw_ker
         }
         const char* sk0 = skipb + skip_buf * C::SKIPBUFB;
         const char* sk1 = sk0 + skipbytes;
+        f32x16 r_lo, r_hi;
+        if constexpr (RES && emit_phase) {
+            const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            i32x2 t0 = tr_read(sk0 + a_off[0]), t1 = tr_read(sk0 + a_off[1]);
+            i32x2 t2 = tr_read(sk0 + a_off[2]), t3 = tr_read(sk0 + a_off[3]);
+            i32x2 t4 = tr_read(sk1 + a_off[0]), t5 = tr_read(sk1 + a_off[1]);
+            i32x2 t6 = tr_read(sk1 + a_off[2]), t7 = tr_read(sk1 + a_off[3]);
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+v"(t0), "+v"(t1), "+v"(t2), "+v"(t3), "+v"(t4), "+v"(t5), "+v"(t6), "+v"(t7));
+            const i32x4 al0 = {t0[0], t0[1], t1[0], t1[1]}, al1 = {t2[0], t2[1], t3[0], t3[1]};
+            const i32x4 ah0 = {t4[0], t4[1], t5[0], t5[1]}, ah1 = {t6[0], t6[1], t7[0], t7[1]};
+            r_lo = mfma32<DT>(al0, bw_h[0], zero);
+            r_hi = mfma32<DT>(ah0, bw_h[0], zero);
+            r_lo = mfma32<DT>(al0, bw_l[0], r_lo);
+            r_hi = mfma32<DT>(ah0, bw_l[0], r_hi);
+            r_lo = mfma32<DT>(al1, bw_h[1], r_lo);
+            r_hi = mfma32<DT>(ah1, bw_h[1], r_hi);
+            r_lo = mfma32<DT>(al1, bw_l[1], r_lo);
+            r_hi = mfma32<DT>(ah1, bw_l[1], r_hi);
+        }
         uint2 pk[4];
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
@@ -359,19 +423,12 @@ __global__ __launch_bounds__(64 * NPT * ((COUT + 31) / 32), 1) void stage_rw_ker
 #pragma unroll
                 for (int jj = 0; jj < 4; ++jj) y[jj] = fmaf(S[jj], sc1[jj], sh1[jj]);
                 if constexpr (RES) {
-                    int o_lo = sk_lo[g], o_hi = sk_hi[g];
-                    asm volatile("" : "+v"(o_lo), "+v"(o_hi) : "v"(y[0]));
-                    const f32x4 tl = unpack4<DT>(*reinterpret_cast<const uint2*>(sk0 + o_lo));
-                    const f32x4 tr = unpack4<DT>(*reinterpret_cast<const uint2*>(sk0 + o_hi));
-                    const f32x4 bl = unpack4<DT>(*reinterpret_cast<const uint2*>(sk1 + o_lo));
-                    const f32x4 br = unpack4<DT>(*reinterpret_cast<const uint2*>(sk1 + o_hi));
                     const f32x4 sc2 = *reinterpret_cast<const f32x4*>(pt_g + 2 * COUT);
                     const f32x4 sh2 = *reinterpret_cast<const f32x4*>(pt_g + 3 * COUT);
 #pragma unroll
                     for (int jj = 0; jj < 4; ++jj) {
-                        const float top = tl[jj] + (tr[jj] - tl[jj]) * rx_l;
-                        const float bot = bl[jj] + (br[jj] - bl[jj]) * rx_l;
-                        const float rs = top + (bot - top) * yl;
+                        const float lo = r_lo[4 * g + jj];
+                        const float rs = lo + (r_hi[4 * g + jj] - lo) * yl;
                         y[jj] = fmaf(y[jj] + rs, sc2[jj], sh2[jj]);
                     }
                 }
@@ -432,7 +489,7 @@ __global__ __launch_bounds__(64 * NPT * ((COUT + 31) / 32), 1) void stage_rw_ker
             sbuf_read = sbuf_read == RW_SKIPBUF - 1 ? 0 : sbuf_read + 1;
         if constexpr (MMA && EPI) {
             // software pipeline: spread the VALU epilogue of row s-1 through the MFMA chain of row s
-            constexpr int VPG = RES ? 16 : 8;
+            constexpr int VPG = RES ? 10 : 8;
 #pragma unroll
             for (int i = 0; i < KC; ++i) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     // one MFMA
@@ -548,6 +605,15 @@ bool rn_rw_supported(int cin, int cout, int pool_k, int pool_s, bool res, int ou
         if (skipcols > skip_side) skipcols = skip_side;
         if (skipcols > ringcols + 8) return false;      // SKIPCOLS_MAX of the kernel
         plan->skipcols = skipcols;
+        // the MFMA residual covers K = 32 source columns per tile: every valid lane's hi column
+        // must lie within 31 of the tile's first lo column (same fp32 arithmetic as the tables)
+        auto lo_of = [&](int i) { return static_cast<int>(static_cast<float>(i) * scale); };
+        for (int t = 0; t < tiles; ++t) {
+            const int first = t * nout_t;
+            const int last = std::min(out_side - 1, first + nout_t - 1);
+            const int hi_last = std::min(lo_of(last) + 1, skip_side - 1);
+            if (hi_last - lo_of(first) > 31) return false;
+        }
     }
     return true;
 }
