@@ -15,8 +15,10 @@ CFLAGS=("${FLAGS[@]/-shared/}")
 for f in rn_api rn_kernels_f32 rn_fused; do
     "$HIPCC" "${CFLAGS[@]}" -c "$HERE/$f.hip" -o "$OBJ/$f.o" &
 done
-# (RN_RW_FLAGS: per-file scheduler experiments; max-ilp measured slower)
-"$HIPCC" "${CFLAGS[@]}" ${RN_RW_FLAGS:-} -c "$HERE/rn_stage_rw.hip" -o "$OBJ/rn_stage_rw.o" &
+# MFMA results stay in VGPRs: the epilogue reads every accumulator with the VALU, and AGPR
+# accumulators cost one v_accvgpr_read each (64 per row in the residual variant).
+# (max-ilp scheduling was measured slower)
+"$HIPCC" "${CFLAGS[@]}" ${RN_RW_FLAGS:--mllvm -amdgpu-mfma-vgpr-form} -c "$HERE/rn_stage_rw.hip" -o "$OBJ/rn_stage_rw.o" &
 wait
 "$HIPCC" --offload-arch=gfx950 -shared -fPIC "$OBJ"/rn_api.o "$OBJ"/rn_kernels_f32.o "$OBJ"/rn_fused.o "$OBJ"/rn_stage_rw.o \
     ${RN_EXTRA_FLAGS:-} -o "$OUT/libroomnet_hip.so"

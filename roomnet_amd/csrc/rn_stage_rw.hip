@@ -146,18 +146,21 @@ __global__ __launch_bounds__(64 * NPT * ((COUT + 31) / 32), 1) void stage_rw_ker
     // lane fills chunk q = tid + i*NTHREADS = (pixel p, slot c') and therefore fetches source
     // chunk c' ^ swz(p) of pixel p.  Pieces past the row end land in the row's padding; columns
     // past the image edge are clamped (they only feed discarded lanes).
-    const unsigned short* const in_img = a.in + static_cast<int64_t>(n) * a.H * a.W * CIN;
-    int ld_goff[LPT];
+    // (addresses are "uniform row base + lane-constant unsigned byte offset": the global_load_lds
+    //  saddr form, no per-row VALU address arithmetic)
+    const char* const in_img = reinterpret_cast<const char*>(a.in + static_cast<int64_t>(n) * a.H * a.W * CIN);
+    const int64_t in_row_bytes = static_cast<int64_t>(a.W) * CIN * 2;
+    unsigned ld_goff[LPT];
 #pragma unroll
     for (int i = 0; i < LPT; ++i) {
         const int q = tid + i * NTHREADS;
         const int p = q / CP, c8 = q % CP;
         const int pc = min(x0c + min(p, RINGCOLS - 1), a.W - 1);
-        ld_goff[i] = pc * CIN + (c8 ^ chunk_swz<CP>(p)) * 8;
+        ld_goff[i] = static_cast<unsigned>((pc * CIN + (c8 ^ chunk_swz<CP>(p)) * 8) * 2);
     }
     const int piece_base = wave * 64 * 16;               // LDS byte offset of this wave inside a piece
     auto issue_row = [&](int j, int slot) {               // input row yc0 + j -> ring slot
-        const unsigned short* row = in_img + static_cast<int64_t>(yc0 + j) * a.W * CIN;
+        const char* row = in_img + static_cast<int64_t>(yc0 + j) * in_row_bytes;
 #pragma unroll
         for (int i = 0; i < LPT; ++i)
             dma16(row + ld_goff[i], ring + slot * ROWB + i * NTHREADS * 16 + piece_base);
@@ -165,11 +168,13 @@ __global__ __launch_bounds__(64 * NPT * ((COUT + 31) / 32), 1) void stage_rw_ker
 
     // ---- skip-row DMA (residual stages): the pair of rows lo/hi of one output row
     int xs0 = 0;
-    int sk_goff[SLPT > 0 ? SLPT : 1];
-    const unsigned short* skip_img = nullptr;
+    unsigned sk_goff[SLPT > 0 ? SLPT : 1];     // byte offset inside a skip row
+    bool sk_hi[SLPT > 0 ? SLPT : 1];           // this lane's chunk of piece i belongs to the hi row
+    const char* skip_img = nullptr;
+    const int64_t skip_row_bytes = static_cast<int64_t>(a.Ss) * COUT * 2;
     if constexpr (RES) {
         xs0 = a.rlo[min(xo_blk0, a.Wo - 1)];
-        skip_img = a.skip + static_cast<int64_t>(n) * a.Ss * a.Ss * COUT;
+        skip_img = reinterpret_cast<const char*>(a.skip + static_cast<int64_t>(n) * a.Ss * a.Ss * COUT);
         const int per_row = a.skipcols * CPO;
 #pragma unroll
         for (int i = 0; i < SLPT; ++i) {
@@ -178,7 +183,8 @@ __global__ __launch_bounds__(64 * NPT * ((COUT + 31) / 32), 1) void stage_rw_ker
             const int qq = min(q - row * per_row, per_row - 1);
             const int p = qq / CPO, c8 = qq % CPO;
             const int pc = min(xs0 + p, a.Ss - 1);
-            sk_goff[i] = (pc * COUT + (c8 ^ chunk_swz<CPO>(p)) * 8) | (row << 30);
+            sk_goff[i] = static_cast<unsigned>((pc * COUT + (c8 ^ chunk_swz<CPO>(p)) * 8) * 2);
+            sk_hi[i] = row != 0;
         }
     }
     auto issue_skip = [&](int e, int buf) {               // skip rows of local output row e -> buffer
@@ -188,13 +194,13 @@ __global__ __launch_bounds__(64 * NPT * ((COUT + 31) / 32), 1) void stage_rw_ker
             const float src = static_cast<float>(yo) * a.rscale;
             const int ylo = static_cast<int>(src);
             const int yhi = min(ylo + 1, a.Ss - 1);
-            const unsigned short* r0 = skip_img + static_cast<int64_t>(ylo) * a.Ss * COUT;
-            const unsigned short* r1 = skip_img + static_cast<int64_t>(yhi) * a.Ss * COUT;
+            // uniform base = lo row; lanes of the hi row add the (uniform) row distance
+            const char* r0 = skip_img + static_cast<int64_t>(ylo) * skip_row_bytes;
+            const unsigned hi_delta = static_cast<unsigned>((yhi - ylo) * skip_row_bytes);
 #pragma unroll
-            for (int i = 0; i < SLPT; ++i) {
-                const unsigned short* base = (sk_goff[i] >> 30) ? r1 : r0;
-                dma16(base + (sk_goff[i] & 0x3fffffff), skipb + buf * C::SKIPBUFB + i * NTHREADS * 16 + piece_base);
-            }
+            for (int i = 0; i < SLPT; ++i)
+                dma16(r0 + (sk_goff[i] + (sk_hi[i] ? hi_delta : 0u)),
+                      skipb + buf * C::SKIPBUFB + i * NTHREADS * 16 + piece_base);
         }
     };
 
