@@ -636,12 +636,17 @@ int rn_fused_prepare(rn_handle* h, const rn_weights* w) {
         f.ctw = k.ctw;
         const int tstride = tile_stride(s.pool_k, s.pool_s), nout_t = tile_nout(s.pool_k, s.pool_s);
         const int tiles = (s.out_side + nout_t - 1) / nout_t;
-        f.npt = tiles >= 8 ? 8 : tiles;
-        f.n_colblocks = (tiles + f.npt - 1) / f.npt;
         const int kc = (9 * s.cin + 15) / 16;
-        const int ringcols = (f.npt - 1) * tstride + 34;
-        f.lds_bytes = static_cast<size_t>(kc) * f.ctw * 1024 + static_cast<size_t>(NSLOT) * ringcols * s.cin * 2;
-        if (f.lds_bytes > 160 * 1024) {
+        // generic kernel: as many pixel tiles per workgroup as fit the LDS next to the weights
+        f.npt = tiles >= 8 ? 8 : tiles;
+        for (;;) {
+            const int ringcols = (f.npt - 1) * tstride + 34;
+            f.lds_bytes = static_cast<size_t>(kc) * f.ctw * 1024 + static_cast<size_t>(NSLOT) * ringcols * s.cin * 2;
+            if (f.lds_bytes <= 160 * 1024 || f.npt == 1) break;
+            --f.npt;
+        }
+        f.n_colblocks = (tiles + f.npt - 1) / f.npt;
+        if (!f.use_rw && f.lds_bytes > 160 * 1024) {
             rn_set_error("16-bit path: stage %zu needs %zu bytes of LDS", i, f.lds_bytes);
             return RN_E_INVALID;
         }
@@ -746,6 +751,7 @@ int rn_fused_forward(rn_handle* h, const uint8_t* d_bgr, const float* d_rgb, int
         a.H = a.W = s.in_side;
         a.Ho = a.Wo = s.out_side;
         if (f.use_rw) {
+            if (const char* dbg = getenv("RN_DEBUG_FLAGS")) a.dbg_flags = atoi(dbg);
             a.ptab = f.ptab;
             a.skipcols = f.rw.skipcols;
             a.n_colblocks = f.rw.n_colblocks;

@@ -106,6 +106,7 @@ struct StageArgs {
     int rows_per_band, n_bands, n_colblocks, n_ctg, npt;
     const float* ptab;            // folded BN tables [4][COUT]: scale1, shift1, scale2, shift2 (rw kernels)
     int skipcols;                 // skip-row columns staged in LDS per workgroup (rw residual kernels)
+    int dbg_flags;                // timing experiments only: bit 0 = skip output stores, bit 1 = skip MFMAs
     float rscale;                 // residual resize scale = float(Ss) / float(Ho), fp32 as TF computes it
 };
 

@@ -36,12 +36,15 @@ using IC = std::integral_constant<int, P>;
 
 typedef __attribute__((address_space(3))) void* lds_void_ptr;
 
-constexpr int RW_NSLOT = 6;     // ring slots: 3 live input rows + 3 in flight
-constexpr int RW_AHEAD = 5;     // at step s the DMA for input row s + RW_AHEAD is issued
 constexpr int RW_SKIPBUF = 3;   // staged skip-row pairs (residual): 1 being read + 2 in flight
 
 template <int DT, int CIN, int COUT, int PK, int PS, bool RES, int NPT>
 struct RwCfg {
+    // Ring depth: at step s the DMA for input row s + AHEAD is issued; NSLOT = AHEAD + 1 slots
+    // (3 live rows + AHEAD - 2 in flight).  Rows of the 8-channel stage are only ~3.8 KB, so it
+    // keeps 9 of them in flight to cover the HBM latency (Little's law), the others 3.
+    static constexpr int AHEAD = CIN == 8 ? 11 : 5;
+    static constexpr int NSLOT = AHEAD + 1;
     static constexpr int CP = CIN / 8;
     static constexpr int KC = (9 * CIN + 15) / 16;
     static constexpr int CT = (COUT + 31) / 32;
@@ -58,23 +61,32 @@ struct RwCfg {
     static constexpr int SKIPBUFB = SLPT * NTHREADS * 16;      // one staged pair of skip rows (padded)
     static constexpr int PTAB_BYTES = 4 * COUT * 4;
     static constexpr int RING_OFF = PTAB_BYTES;
-    static constexpr int SKIP_OFF = RING_OFF + RW_NSLOT * ROWB;
-    static constexpr int LDS_BYTES = SKIP_OFF + (RES ? RW_SKIPBUF * SKIPBUFB : 0);
+    static constexpr int SKIP_OFF = RING_OFF + NSLOT * ROWB;
+    // output staging (one 32-channel cout tile only): each wave transposes its tile-row
+    // [pixel][64 B] through LDS so that the global stores are lane-linear (1 KB contiguous per
+    // instruction) instead of 16 B per lane at a 64-byte stride
+    // (measured: +23 % on the 8->32 stage whose row has 5 MFMAs and is store-dominated; -20 % on the
+    //  32->32 stages, where the serial write/read/wait/store tail cannot hide behind the MFMA chain)
+    static constexpr bool STAGE_OUT = COUT == 32 && CIN == 8;
+    static constexpr int STAGE_WAVE_B = 32 * 64;
+    static constexpr int STAGE_OFF = SKIP_OFF + (RES ? RW_SKIPBUF * SKIPBUFB : 0);
+    static constexpr int LDS_BYTES = STAGE_OFF + (STAGE_OUT ? NPT * CT * STAGE_WAVE_B : 0);
     // steady-state counted wait at the end of step s: everything up to input row s+3 and the
     // skip pair used by step s+1 has landed; what may stay in flight is what the wave issued
     // after them (the pieces of this step, plus one more row of input when there is no skip)
     // (residual with pool stride 2 issues a skip pair on even steps only: per-phase counts)
     static constexpr int vmcnt_steady(int phase) {
-        if (!RES) return 2 * LPT;
+        if (!RES) return (AHEAD - 3) * LPT;
         if (PS == 1) return LPT + SLPT;
         return (phase & 1) == 0 ? 2 * LPT + 2 * SLPT : LPT;
     }
-    static constexpr int VMCNT_STEADY = 2 * LPT + 2 * SLPT;   // upper bound (field-width check)
+    static constexpr int VMCNT_STEADY = (RES ? 2 * LPT + 2 * SLPT : (AHEAD - 3) * LPT);   // upper bound (field-width check)
+    static_assert(!RES || AHEAD == 5, "the residual wait counts are derived for AHEAD = 5");
     static_assert(COUT % 32 == 0 || COUT == 16, "cout must be whole 32-channel tiles (or one half tile)");
     static_assert(PK == 0 || PK == 4, "pool window 4 or none");
     static_assert(KC * 4 <= 80 || NTHREADS <= 256, "weights need the whole register file: <= 1 wave per SIMD");
     static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
-    static_assert(RW_NSLOT % 2 == 0, "pool-ring parity is tied to the unroll");
+    static_assert(NSLOT % 2 == 0, "pool-ring parity is tied to the unroll");
     static_assert(VMCNT_STEADY <= 63, "vmcnt field");
 };
 
@@ -107,6 +119,7 @@ __global__ __launch_bounds__(64 * NPT * ((COUT + 31) / 32), 1) void stage_rw_ker
     constexpr int CP = C::CP, KC = C::KC, CT = C::CT, CPO = C::CPO, TSTRIDE = C::TSTRIDE, NOUT_T = C::NOUT_T;
     constexpr int RINGCOLS = C::RINGCOLS, ROWB = C::ROWB, NTHREADS = C::NTHREADS, LPT = C::LPT, SLPT = C::SLPT;
     constexpr int PIXB = CIN * 2, NG = C::NG;
+    constexpr int RW_NSLOT = C::NSLOT, RW_AHEAD = C::AHEAD;
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -159,7 +172,7 @@ __global__ __launch_bounds__(64 * NPT * ((COUT + 31) / 32), 1) void stage_rw_ker
         ld_goff[i] = static_cast<unsigned>((pc * CIN + (c8 ^ chunk_swz<CP>(p)) * 8) * 2);
     }
     const int piece_base = wave * 64 * 16;               // LDS byte offset of this wave inside a piece
-    auto issue_row = [&](int j, int slot) {               // input row yc0 + j -> ring slot
+    auto issue_row = [&](int j, int slot) __attribute__((always_inline)) {               // input row yc0 + j -> ring slot
         const char* row = in_img + static_cast<int64_t>(yc0 + j) * in_row_bytes;
 #pragma unroll
         for (int i = 0; i < LPT; ++i)
@@ -187,7 +200,7 @@ __global__ __launch_bounds__(64 * NPT * ((COUT + 31) / 32), 1) void stage_rw_ker
             sk_hi[i] = row != 0;
         }
     }
-    auto issue_skip = [&](int e, int buf) {               // skip rows of local output row e -> buffer
+    auto issue_skip = [&](int e, int buf) __attribute__((always_inline)) {               // skip rows of local output row e -> buffer
         if constexpr (RES) {
             const int yo = yo0 + min(max(e, 0), nout_rows - 1);
             // TF-1.13 compute_interpolation_weights: src = yo * scale (fp32), lo = int(src), hi = min(lo+1, in-1)
@@ -234,6 +247,26 @@ __global__ __launch_bounds__(64 * NPT * ((COUT + 31) / 32), 1) void stage_rw_ker
     unsigned short* const out_lane =
         a.out + (static_cast<int64_t>(n) * a.Ho * a.Wo + xo) * COUT + ct * 32 + 8 * hh;   // + yo*Wo*COUT + 8*k
     const float* const ptab_lane = ptab + ct * 32 + 4 * hh;                                // + 8*g (+ table*COUT)
+    // staging: this lane's output pixel index inside the tile, number of valid pixels of the tile
+    const int pr = PK ? r / PS : r;
+    const int xo_t0s = PK ? (x0c + pt * TSTRIDE) / PS : (x0c + pt * TSTRIDE);     // first output column of the tile
+    const int nvalid = max(0, min(NOUT_T, min(a.Wo, xo_blk0 + NPT * NOUT_T) - xo_t0s)); // wave-uniform
+    // LDS byte addresses (as 32-bit LDS offsets, used by inline-asm DS ops):
+    //   write: after the half-wave swap this lane holds 16-byte chunk (2k + hh) of pixel pr, stored at
+    //          pixel*64 + ((chunk ^ swz) << 4); the k = 1 address is the k = 0 address ^ 32
+    //   read : lane-linear chunk g = lane + 64k of the tile-row; the k = 1 address is + 1024
+    unsigned st_w0 = 0, st_r0 = 0;
+    if constexpr (C::STAGE_OUT) {
+        const unsigned stage_base = static_cast<unsigned>(reinterpret_cast<uintptr_t>(
+            (__attribute__((address_space(3))) char*)(smem + C::STAGE_OFF + wave * C::STAGE_WAVE_B)));
+        st_w0 = stage_base + pr * 64 + ((hh ^ ((pr >> 1) & 3)) << 4);
+        const int gp = lane >> 2, gc = lane & 3;
+        st_r0 = stage_base + gp * 64 + ((gc ^ ((gp >> 1) & 3)) << 4);
+    }
+    // uniform base of the tile's output + lane-linear byte offset (saddr-form stores)
+    char* const out_tile_base = reinterpret_cast<char*>(a.out + (static_cast<int64_t>(n) * a.Ho * a.Wo + xo_t0s) * COUT);
+    const unsigned lane16 = static_cast<unsigned>(lane) * 16u;
+    const int64_t out_row_bytes = static_cast<int64_t>(a.Wo) * COUT * 2;
 
     // ---- residual on the matrix cores: R[cout][x_out] = Skip^T[cout][x_in] * Wx[x_in][x_out]
     // (Wx = the legacy-bilinear interpolation matrix of this tile: two non-zeros per column).
@@ -285,7 +318,7 @@ __global__ __launch_bounds__(64 * NPT * ((COUT + 31) / 32), 1) void stage_rw_ker
     // prefetch queue every row.  The skip pair read here was retired by the counted wait of the
     // previous step.  The asm loads are waited for by skip_wait() (names every destination).
     using i32x2 = __attribute__((ext_vector_type(2))) int;
-    auto tr_read = [&](const char* p) -> i32x2 {
+    auto tr_read = [&](const char* p) __attribute__((always_inline)) -> i32x2 {
         i32x2 v;
         const unsigned addr = static_cast<unsigned>(reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) const char*)p));
         asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(addr));
@@ -304,7 +337,7 @@ __global__ __launch_bounds__(64 * NPT * ((COUT + 31) / 32), 1) void stage_rw_ker
     lds_barrier();
 
     // B fragment of K-chunk kc for the conv row whose first input row sits in ring slot P
-    auto b_frag = [&](auto PC, auto KCC) -> i32x4 {
+    auto b_frag = [&](auto PC, auto KCC) __attribute__((always_inline)) -> i32x4 {
         constexpr int P = decltype(PC)::value, kc = decltype(KCC)::value;
         if constexpr (CIN >= 16) {
             constexpr int tap = kc / (CIN / 16), cc = kc % (CIN / 16);
@@ -318,7 +351,7 @@ __global__ __launch_bounds__(64 * NPT * ((COUT + 31) / 32), 1) void stage_rw_ker
     };
     // MFMA chain of one conv row; B fragments are read BAHEAD K-chunks ahead of their MFMA
     constexpr int BAHEAD = KC >= 4 ? 3 : 1;
-    auto mma_row = [&](auto PC, f32x16& acc) {
+    auto mma_row = [&](auto PC, f32x16& acc) __attribute__((always_inline)) {
         const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         i32x4 bq[KC];
         [&]<int... I>(std::integer_sequence<int, I...>) {
@@ -335,7 +368,7 @@ __global__ __launch_bounds__(64 * NPT * ((COUT + 31) / 32), 1) void stage_rw_ker
     // epilogue of conv row j (local index); JP = j mod RW_NSLOT (only its parity matters).
     // Works on one group of 4 consecutive channels at a time (4 independent DPP chains in
     // lockstep: short live ranges, and the VALU-write -> DPP-read hazard is covered).
-    auto epi_row = [&](auto JPC, const f32x16& acc, int j, int skip_buf) {
+    auto epi_row = [&](auto JPC, const f32x16& acc, int j, int skip_buf) __attribute__((always_inline)) {
         constexpr int JP = decltype(JPC)::value;
         constexpr bool emit_phase = PK == 0 || PS == 1 || (JP & 1) == 1;
         const bool emit = PK ? j >= 3 : true;
@@ -442,18 +475,38 @@ __global__ __launch_bounds__(64 * NPT * ((COUT + 31) / 32), 1) void stage_rw_ker
             }
         }
         if constexpr (emit_phase) {
-            // widen to 16-byte stores: lower half-wave gets channels 8k..8k+7, upper 8(k+1)..8(k+1)+7
-            unsigned short* orow = out_lane + static_cast<int64_t>(yo) * a.Wo * COUT;
+            // half-wave swap: lower half-wave gets channels 8k..8k+7, upper 8(k+1)..8(k+1)+7
+            i32x4 vv[2];
 #pragma unroll
             for (int k = 0; k < NG; k += 2) {
                 const auto sx = __builtin_amdgcn_permlane32_swap(pk[k].x, pk[k + 1].x, false, false);
                 const auto sy = __builtin_amdgcn_permlane32_swap(pk[k].y, pk[k + 1].y, false, false);
-                uint4 vv;
-                vv.x = sx[0];
-                vv.y = sy[0];
-                vv.z = sx[1];
-                vv.w = sy[1];
-                if (emit && lane_out) *reinterpret_cast<uint4*>(orow + 8 * k) = vv;
+                vv[k / 2][0] = static_cast<int>(sx[0]);
+                vv[k / 2][1] = static_cast<int>(sy[0]);
+                vv[k / 2][2] = static_cast<int>(sx[1]);
+                vv[k / 2][3] = static_cast<int>(sy[1]);
+            }
+            if constexpr (C::STAGE_OUT) {
+                // transpose through the wave's staging tile, then lane-linear 16-byte stores.
+                // LDS operations of one wave execute in order: no barrier needed.  Inline asm keeps
+                // hipcc from guarding these DS ops with vmcnt(0) against the in-flight LDS-DMA.
+                if (lane_out) {
+                    asm volatile("ds_write_b128 %0, %1\n\ts_nop 1" ::"v"(st_w0), "v"(vv[0]) : "memory");
+                    asm volatile("ds_write_b128 %0, %1\n\ts_nop 1" ::"v"(st_w0 ^ 32u), "v"(vv[1]) : "memory");
+                }
+                i32x4 o0, o1;
+                asm volatile("ds_read_b128 %0, %1" : "=v"(o0) : "v"(st_r0) : "memory");
+                asm volatile("ds_read_b128 %0, %1 offset:1024" : "=v"(o1) : "v"(st_r0) : "memory");
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(o0), "+v"(o1));
+                char* orow = out_tile_base + static_cast<int64_t>(yo) * out_row_bytes;
+                const bool st = emit && !(a.dbg_flags & 1);
+                if (st && lane < 4 * nvalid) *reinterpret_cast<i32x4*>(orow + lane16) = o0;
+                if (st && lane + 64 < 4 * nvalid) *reinterpret_cast<i32x4*>(orow + (lane16 + 1024u)) = o1;
+            } else {
+                unsigned short* orow = out_lane + static_cast<int64_t>(yo) * a.Wo * COUT;
+#pragma unroll
+                for (int k = 0; k < NG; k += 2)
+                    if (emit && lane_out && !(a.dbg_flags & 1)) *reinterpret_cast<i32x4*>(orow + 8 * k) = vv[k / 2];
             }
         }
     };
@@ -466,7 +519,7 @@ __global__ __launch_bounds__(64 * NPT * ((COUT + 31) / 32), 1) void stage_rw_ker
 
     // one pipeline step s (ring phase P = s mod RW_NSLOT): DMA for row s+RW_AHEAD, MFMAs of conv
     // row s, epilogue of conv row s-1, counted wait, barrier
-    auto step = [&](auto PC, auto MMAC, auto EPIC, int s) {
+    auto step = [&](auto PC, auto MMAC, auto EPIC, int s) __attribute__((always_inline)) {
         constexpr int P = decltype(PC)::value;
         constexpr bool MMA = decltype(MMAC)::value != 0, EPI = decltype(EPIC)::value != 0;
         const bool have_next = MMA && (s + RW_AHEAD < nin);
@@ -514,45 +567,22 @@ __global__ __launch_bounds__(64 * NPT * ((COUT + 31) / 32), 1) void stage_rw_ker
 
     using T = IC<1>;
     using F = IC<0>;
-    static_assert(RW_NSLOT == 6, "the step sequence below is written for a 6-slot ring");
     step(IC<0>{}, T{}, F{}, 0);
     int s = 1;
-    for (; s + 5 < nconv; s += 6) {
-        step(IC<1>{}, T{}, T{}, s);
-        step(IC<2>{}, T{}, T{}, s + 1);
-        step(IC<3>{}, T{}, T{}, s + 2);
-        step(IC<4>{}, T{}, T{}, s + 3);
-        step(IC<5>{}, T{}, T{}, s + 4);
-        step(IC<0>{}, T{}, T{}, s + 5);
+    // steady state: NSLOT steps per trip, ring phases 1, 2, ..., NSLOT-1, 0
+    for (; s + RW_NSLOT - 1 < nconv; s += RW_NSLOT) {
+        [&]<int... I>(std::integer_sequence<int, I...>) {
+            (step(IC<(1 + I) % RW_NSLOT>{}, T{}, T{}, s + I), ...);
+        }(std::make_integer_sequence<int, RW_NSLOT>{});
     }
-    if (s < nconv) {
-        step(IC<1>{}, T{}, T{}, s);
-        ++s;
-    }
-    if (s < nconv) {
-        step(IC<2>{}, T{}, T{}, s);
-        ++s;
-    }
-    if (s < nconv) {
-        step(IC<3>{}, T{}, T{}, s);
-        ++s;
-    }
-    if (s < nconv) {
-        step(IC<4>{}, T{}, T{}, s);
-        ++s;
-    }
-    if (s < nconv) {
-        step(IC<5>{}, T{}, T{}, s);
-        ++s;
-    }
-    switch (s % RW_NSLOT) {
-        case 0: step(IC<0>{}, F{}, T{}, s); break;
-        case 1: step(IC<1>{}, F{}, T{}, s); break;
-        case 2: step(IC<2>{}, F{}, T{}, s); break;
-        case 3: step(IC<3>{}, F{}, T{}, s); break;
-        case 4: step(IC<4>{}, F{}, T{}, s); break;
-        default: step(IC<5>{}, F{}, T{}, s); break;
-    }
+    // remainder (s = 1 mod NSLOT here): phases 1, 2, ... while rows are left
+    [&]<int... I>(std::integer_sequence<int, I...>) {
+        ((s < nconv ? (step(IC<1 + I>{}, T{}, T{}, s), ++s, 0) : 0), ...);
+    }(std::make_integer_sequence<int, RW_NSLOT - 1>{});
+    // drain: epilogue of the last conv row
+    [&]<int... I>(std::integer_sequence<int, I...>) {
+        ((s % RW_NSLOT == I ? (step(IC<I>{}, F{}, T{}, s), 0) : 0), ...);
+    }(std::make_integer_sequence<int, RW_NSLOT>{});
 }
 
 template <int DT, int CIN, int COUT, int PK, int PS, bool RES, int NPT>

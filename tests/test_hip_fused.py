@@ -100,3 +100,36 @@ def test_timing(engine, parity_images):
     t = engine.timing()
     engine.set_profiling(False)
     assert len(t["stage_ms"]) == 10 and all(x > 0 for x in t["stage_ms"])
+
+
+# ------------------------------------------------------------------ 600x600 variant (BASELINE config 5)
+@pytest.mark.parametrize("dtype,tol", [("f16", 0.1), ("bf16", 0.1), ("f32", 1e-4)])
+def test_600_variant_vs_golden(weights, dtype, tol):
+    """Large-activation variant: conv/BN weights from the checkpoint, seeded synthetic dense/kernel
+    (the shipped one only fits 224).  Exercises column blocks and multi-band launches."""
+    import os
+    from conftest import GOLDEN
+    from oracle import roomnet_ref as R
+    from roomnet_amd.synth import parity_batch
+    g = np.load(os.path.join(GOLDEN, "parity_600.npz"))
+    w = dict(weights)
+    w["dense/kernel"] = R.synth_dense_kernel_600()
+    ims = parity_batch(600, seed=1)[g["image_indices"]]
+    e = _capi.Engine(build_graph(6, 600), w, device=0, dtype=dtype, max_batch=4)
+    try:
+        ids, probs = e.forward_u8(ims)
+        logits = e.tap("d3.relu", 4)
+        assert np.abs(logits - g["logits_f64"]).max() <= tol
+        safe = g["top2_margin"] > (1e-3 if dtype == "f32" else MARGIN)
+        np.testing.assert_array_equal(ids[safe], g["ids"][safe])
+        if dtype != "f32":
+            # stage outputs against the C oracle for one image
+            ref = c_oracle.infer(w, ims[1:2], taps=True)
+            e.forward_u8(ims[1:2])
+            for s in e.graph.stages:
+                name = "s%d.%s" % (s.index, "bn2" if s.residual else "bn")
+                got, want = e.tap(name, 1), np.asarray(ref["taps"][name])
+                rel = float(np.abs(got - want).max() / max(np.abs(want).max(), 1e-6))
+                assert rel <= STAGE_TOL[dtype] * 1.5, (name, rel)
+    finally:
+        e.close()
