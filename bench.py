@@ -47,6 +47,24 @@ def stage_bytes_per_image(graph, elem_bytes):
     return out
 
 
+def measured_traffic(stage, batch, side, dtype):
+    """HBM bytes per launch of `stage` from the committed rocprofv3 PMC passes (profiles/), or None
+    when no profile matches this configuration.  bench.py cannot profile itself: the counters are
+    collected by running this same command under `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE`."""
+    path = os.path.join(ROOT, "profiles", "r1_g_hbm_traffic.json")
+    try:
+        with open(path) as f:
+            t = json.load(f)
+    except (OSError, ValueError):
+        return None
+    if (t.get("batch"), t.get("im_side"), t.get("dtype")) != (batch, side, dtype):
+        return None
+    for st in t.get("stages", []):
+        if st.get("stage") == stage:
+            return int(st["traffic_bytes"])
+    return None
+
+
 def cpu_baseline(weights, side, budget_s=20.0):
     """Time the plain-C oracle on a bounded sample (rank 0, N=1 only)."""
     from oracle import c_oracle
@@ -192,7 +210,7 @@ def main():
                        "images_per_gpu": B, "global_batch": world * B, "im_side": args.side,
                        "parallelism": "dp%d" % world},
             "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK, "traffic": None,
+                         "frac": achieved / HBM_PEAK, "traffic": measured_traffic(dom, B, args.side, args.dtype),
                          "kernel": "stage_mfma_kernel stage %d (%d->%d ch)" % (dom, graph.stages[dom].cin,
                                                                               graph.stages[dom].cout)
                                    if dom > 0 and args.dtype != "f32" else "stage %d" % dom,

@@ -337,6 +337,7 @@ __global__ __launch_bounds__(64 * NPT * ((COUT + 31) / 32), 1) void stage_rw_ker
     lds_barrier();
 
     // B fragment of K-chunk kc for the conv row whose first input row sits in ring slot P
+    // (compiler-visible load; used by the 8-channel variant whose tap row is lane dependent)
     auto b_frag = [&](auto PC, auto KCC) __attribute__((always_inline)) -> i32x4 {
         constexpr int P = decltype(PC)::value, kc = decltype(KCC)::value;
         if constexpr (CIN >= 16) {
@@ -349,20 +350,61 @@ __global__ __launch_bounds__(64 * NPT * ((COUT + 31) / 32), 1) void stage_rw_ker
             return *reinterpret_cast<const i32x4*>(ring + slot * ROWB + b8_off[kc]);
         }
     };
-    // MFMA chain of one conv row; B fragments are read BAHEAD K-chunks ahead of their MFMA
-    constexpr int BAHEAD = KC >= 4 ? 3 : 1;
+    // Explicit B-fragment pipeline (CIN >= 16): hipcc keeps these LDS reads only ONE K-chunk ahead
+    // of their MFMA and waits lgkmcnt(0) in front of every MFMA, which exposes the LDS latency 18
+    // times per row.  Here the reads are inline asm, BAHEAD chunks ahead, retired by counted
+    // s_waitcnt lgkmcnt(N) (LDS returns in order; any compiler-issued DS op in between only makes
+    // the count conservative).  Ring offsets beyond the 16-bit DS immediate use a second base.
+    constexpr int BAHEAD = KC >= 6 ? 4 : 1;
+    constexpr int SLOT_SPLIT = 65535 / ROWB >= RW_NSLOT ? RW_NSLOT : 65535 / ROWB;   // slots reachable from base 0
+    unsigned bbase0[3][CIN >= 16 ? CIN / 16 : 1], bbase1[3][CIN >= 16 ? CIN / 16 : 1];
+    if constexpr (CIN >= 16) {
+        const unsigned ring_lds = static_cast<unsigned>(reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) char*)ring));
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+            for (int cc = 0; cc < CIN / 16; ++cc) {
+                bbase0[kx][cc] = ring_lds + static_cast<unsigned>(boff[kx][cc]);
+                bbase1[kx][cc] = bbase0[kx][cc] + static_cast<unsigned>(SLOT_SPLIT * ROWB);
+            }
+    }
+    auto b_read_asm = [&](auto PC, auto KCC) __attribute__((always_inline)) -> i32x4 {
+        constexpr int P = decltype(PC)::value, kc = decltype(KCC)::value;
+        constexpr int tap = kc / (CIN / 16), cc = kc % (CIN / 16);
+        constexpr int ky = tap / 3, kx = tap % 3;
+        constexpr int slot = (P + ky) % RW_NSLOT;
+        i32x4 v;
+        if constexpr (slot < SLOT_SPLIT)
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(bbase0[kx][cc]), "n"(slot * ROWB));
+        else
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(bbase1[kx][cc]), "n"((slot - SLOT_SPLIT) * ROWB));
+        return v;
+    };
+    // MFMA chain of one conv row
     auto mma_row = [&](auto PC, f32x16& acc) __attribute__((always_inline)) {
         const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         i32x4 bq[KC];
-        [&]<int... I>(std::integer_sequence<int, I...>) {
-            ((bq[I] = b_frag(PC, IC<I>{})), ...);
-        }(std::make_integer_sequence<int, BAHEAD>{});
-        [&]<int... I>(std::integer_sequence<int, I...>) {
-            ((bq[I + BAHEAD < KC ? I + BAHEAD : 0] =
-                  (I + BAHEAD < KC ? b_frag(PC, IC<(I + BAHEAD < KC ? I + BAHEAD : 0)>{}) : bq[0]),
-              acc = mfma32<DT>(wreg[I], bq[I], I == 0 ? zero : acc)),
-             ...);
-        }(std::make_integer_sequence<int, KC>{});
+        if constexpr (CIN >= 16) {
+            [&]<int... I>(std::integer_sequence<int, I...>) {
+                ((bq[I] = b_read_asm(PC, IC<I>{})), ...);
+            }(std::make_integer_sequence<int, BAHEAD>{});
+            [&]<int... I>(std::integer_sequence<int, I...>) {
+                (([&] {
+                     if constexpr (I + BAHEAD < KC) bq[I + BAHEAD] = b_read_asm(PC, IC<(I + BAHEAD < KC ? I + BAHEAD : 0)>{});
+                     constexpr int newer = (KC - 1 - I) < BAHEAD ? (KC - 1 - I) : BAHEAD;   // my reads issued after chunk I
+                     asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(bq[I]) : "n"(newer));
+                     acc = mfma32<DT>(wreg[I], bq[I], I == 0 ? zero : acc);
+                 }()),
+                 ...);
+            }(std::make_integer_sequence<int, KC>{});
+        } else {
+            bq[0] = b_frag(PC, IC<0>{});
+            [&]<int... I>(std::integer_sequence<int, I...>) {
+                ((bq[I + 1 < KC ? I + 1 : 0] = (I + 1 < KC ? b_frag(PC, IC<(I + 1 < KC ? I + 1 : 0)>{}) : bq[0]),
+                  acc = mfma32<DT>(wreg[I], bq[I], I == 0 ? zero : acc)),
+                 ...);
+            }(std::make_integer_sequence<int, KC>{});
+        }
     };
 
     // epilogue of conv row j (local index); JP = j mod RW_NSLOT (only its parity matters).
