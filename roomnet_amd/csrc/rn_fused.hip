@@ -767,8 +767,35 @@ int rn_fused_forward(rn_handle* h, const uint8_t* d_bgr, const float* d_rgb, int
             if (s.pool_k == 0 && a.rows_per_band < 4) a.rows_per_band = 4;   // ring prologue depth
             a.n_bands = (s.out_side + a.rows_per_band - 1) / a.rows_per_band;
             dim3 grid(a.n_bands * a.n_colblocks, n);
+#ifdef RN_STAMPS
+            // diagnostic build: per-wave phase cycle sums, printed per stage after the launch
+            static unsigned long long* stamp_host = nullptr;
+            const size_t nwaves = static_cast<size_t>(grid.x) * grid.y * 16;
+            if (!stamp_host) (void)hipHostMalloc(reinterpret_cast<void**>(&stamp_host), 64u << 20, 0);
+            std::memset(stamp_host, 0, nwaves * 32);
+            a.stamp_buf = stamp_host;
+#endif
             int rc = rn_rw_launch(f.rw, h->dtype, h->stream, a, grid);
             if (rc != RN_OK) return rc;
+#ifdef RN_STAMPS
+            (void)hipStreamSynchronize(h->stream);
+            {
+                double w = 0, d = 0, b = 0, rows = 0, ch = 0;
+                size_t cnt = 0;
+                for (size_t k = 0; k < nwaves; ++k)
+                    if (stamp_host[k * 4 + 3]) {
+                        w += stamp_host[k * 4];
+                        d += stamp_host[k * 4 + 1];
+                        b += static_cast<double>(stamp_host[k * 4 + 2] & 0xffffffffull);
+                        ch += static_cast<double>(stamp_host[k * 4 + 2] >> 32);
+                        rows += stamp_host[k * 4 + 3];
+                        ++cnt;
+                    }
+                if (cnt)
+                    fprintf(stderr, "[stamps] stage %zu: waves %zu, cycles/step: work %.0f (MFMA chain alone %.0f)  dma-wait %.0f  barrier %.0f  (steps/wave %.0f)\n",
+                            i, cnt, w / rows, ch / rows, d / rows, b / rows, rows / cnt);
+            }
+#endif
             rn_record_event(h, 2 + static_cast<int>(i));
             continue;
         }

@@ -107,6 +107,7 @@ struct StageArgs {
     const float* ptab;            // folded BN tables [4][COUT]: scale1, shift1, scale2, shift2 (rw kernels)
     int skipcols;                 // skip-row columns staged in LDS per workgroup (rw residual kernels)
     int dbg_flags;                // timing experiments only: bit 0 = skip output stores, bit 1 = skip MFMAs
+    unsigned long long* stamp_buf; // diagnostic build (-DRN_STAMPS) only: per-wave phase cycle sums
     float rscale;                 // residual resize scale = float(Ss) / float(Ho), fp32 as TF computes it
 };
 

@@ -68,6 +68,12 @@ struct RwCfg {
     // (measured: +23 % on the 8->32 stage whose row has 5 MFMAs and is store-dominated; -20 % on the
     //  32->32 stages, where the serial write/read/wait/store tail cannot hide behind the MFMA chain)
     static constexpr bool STAGE_OUT = COUT == 32 && CIN == 8;
+    // folded-BN tables: persistent registers where the register file has room (one wave per SIMD, or the
+    // small 8-channel stage); otherwise one batched LDS read at the start of every epilogue
+    static constexpr bool PTAB_REGS = NTHREADS <= 256 || CIN == 8;
+    // ... except the 8-wave 32->32 variant, which sits at the 256-register cap: it reads each group's
+    // table entries late (right before use) so they never pin registers across the MFMA chain
+    static constexpr bool PTAB_LATE = !PTAB_REGS && CIN == 32 && COUT == 32;
     static constexpr int STAGE_WAVE_B = 32 * 64;
     static constexpr int STAGE_OFF = SKIP_OFF + (RES ? RW_SKIPBUF * SKIPBUFB : 0);
     static constexpr int LDS_BYTES = STAGE_OFF + (STAGE_OUT ? NPT * CT * STAGE_WAVE_B : 0);
@@ -106,6 +112,18 @@ __device__ __forceinline__ void raw_barrier() {
 __device__ __forceinline__ void dma16(const void* gsrc, char* lds) {
     __builtin_amdgcn_global_load_lds(gsrc, (lds_void_ptr)lds, 16, 0, 0);
 }
+
+#ifdef RN_STAMPS
+// In-kernel stamps (diagnostic build only; never in the shipped library): s_memtime + its own wait
+// in ONE asm statement, fenced by sched_barrier so the segments hold what they are named for.
+__device__ __forceinline__ unsigned long long stamp() {
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
+#endif
 
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
@@ -247,6 +265,19 @@ __global__ __launch_bounds__(64 * NPT * ((COUT + 31) / 32), 1) void stage_rw_ker
     unsigned short* const out_lane =
         a.out + (static_cast<int64_t>(n) * a.Ho * a.Wo + xo) * COUT + ct * 32 + 8 * hh;   // + yo*Wo*COUT + 8*k
     const float* const ptab_lane = ptab + ct * 32 + 4 * hh;                                // + 8*g (+ table*COUT)
+    f32x4 sc1r[NG], sh1r[NG], sc2r[NG], sh2r[NG];
+    if constexpr (C::PTAB_REGS) {
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            const float* gp = a.ptab + ct * 32 + 4 * hh + 8 * g;
+            sc1r[g] = *reinterpret_cast<const f32x4*>(gp);
+            sh1r[g] = *reinterpret_cast<const f32x4*>(gp + COUT);
+            if constexpr (RES) {
+                sc2r[g] = *reinterpret_cast<const f32x4*>(gp + 2 * COUT);
+                sh2r[g] = *reinterpret_cast<const f32x4*>(gp + 3 * COUT);
+            }
+        }
+    }
     // staging: this lane's output pixel index inside the tile, number of valid pixels of the tile
     const int pr = PK ? r / PS : r;
     const int xo_t0s = PK ? (x0c + pt * TSTRIDE) / PS : (x0c + pt * TSTRIDE);     // first output column of the tile
@@ -443,6 +474,29 @@ __global__ __launch_bounds__(64 * NPT * ((COUT + 31) / 32), 1) void stage_rw_ker
             r_lo = mfma32<DT>(al1, bw_l[1], r_lo);
             r_hi = mfma32<DT>(ah1, bw_l[1], r_hi);
         }
+        f32x4 sc1v[NG], sh1v[NG], sc2v[NG], sh2v[NG];
+        if constexpr (emit_phase) {
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                if constexpr (C::PTAB_REGS) {
+                    sc1v[g] = sc1r[g];
+                    sh1v[g] = sh1r[g];
+                    if constexpr (RES) {
+                        sc2v[g] = sc2r[g];
+                        sh2v[g] = sh2r[g];
+                    }
+                } else if constexpr (!C::PTAB_LATE) {
+                    // one batch of LDS reads (a single wait) instead of a read + wait per channel group
+                    const float* pt_g = ptab_lane + 8 * g;
+                    sc1v[g] = *reinterpret_cast<const f32x4*>(pt_g);
+                    sh1v[g] = *reinterpret_cast<const f32x4*>(pt_g + COUT);
+                    if constexpr (RES) {
+                        sc2v[g] = *reinterpret_cast<const f32x4*>(pt_g + 2 * COUT);
+                        sh2v[g] = *reinterpret_cast<const f32x4*>(pt_g + 3 * COUT);
+                    }
+                }
+            }
+        }
         uint2 pk[4];
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
@@ -492,20 +546,24 @@ __global__ __launch_bounds__(64 * NPT * ((COUT + 31) / 32), 1) void stage_rw_ker
                 }
             }
             if constexpr (emit_phase) {
-                // keep the table / skip reads behind the pooled sums: hoisted to the top of the step
-                // they would pin 32+ registers across the whole MFMA chain
-                // (the OFFSET is made opaque, not the pointer, so the access stays a DS read)
-                int pt_off = 8 * g;
-                asm volatile("" : "+v"(pt_off) : "v"(S[0]), "v"(S[3]));
-                const float* pt_g = ptab_lane + pt_off;
-                const f32x4 sc1 = *reinterpret_cast<const f32x4*>(pt_g);
-                const f32x4 sh1 = *reinterpret_cast<const f32x4*>(pt_g + COUT);
+                if constexpr (C::PTAB_LATE) {
+                    // (the OFFSET is made opaque, not the pointer, so the access stays a DS read)
+                    int pt_off = 8 * g;
+                    asm volatile("" : "+v"(pt_off) : "v"(S[0]), "v"(S[3]));
+                    const float* pt_g = ptab_lane + pt_off;
+                    sc1v[g] = *reinterpret_cast<const f32x4*>(pt_g);
+                    sh1v[g] = *reinterpret_cast<const f32x4*>(pt_g + COUT);
+                    if constexpr (RES) {
+                        sc2v[g] = *reinterpret_cast<const f32x4*>(pt_g + 2 * COUT);
+                        sh2v[g] = *reinterpret_cast<const f32x4*>(pt_g + 3 * COUT);
+                    }
+                }
+                const f32x4 sc1 = sc1v[g], sh1 = sh1v[g];
                 float y[4];
 #pragma unroll
                 for (int jj = 0; jj < 4; ++jj) y[jj] = fmaf(S[jj], sc1[jj], sh1[jj]);
                 if constexpr (RES) {
-                    const f32x4 sc2 = *reinterpret_cast<const f32x4*>(pt_g + 2 * COUT);
-                    const f32x4 sh2 = *reinterpret_cast<const f32x4*>(pt_g + 3 * COUT);
+                    const f32x4 sc2 = sc2v[g], sh2 = sh2v[g];
 #pragma unroll
                     for (int jj = 0; jj < 4; ++jj) {
                         const float lo = r_lo[4 * g + jj];
@@ -561,8 +619,14 @@ __global__ __launch_bounds__(64 * NPT * ((COUT + 31) / 32), 1) void stage_rw_ker
 
     // one pipeline step s (ring phase P = s mod RW_NSLOT): DMA for row s+RW_AHEAD, MFMAs of conv
     // row s, epilogue of conv row s-1, counted wait, barrier
+#ifdef RN_STAMPS
+    unsigned long long st_work = 0, st_dma = 0, st_bar = 0, st_chain = 0;
+#endif
     auto step = [&](auto PC, auto MMAC, auto EPIC, int s) __attribute__((always_inline)) {
         constexpr int P = decltype(PC)::value;
+#ifdef RN_STAMPS
+        const unsigned long long ts0 = stamp();
+#endif
         constexpr bool MMA = decltype(MMAC)::value != 0, EPI = decltype(EPIC)::value != 0;
         const bool have_next = MMA && (s + RW_AHEAD < nin);
         if constexpr (MMA) {
@@ -574,10 +638,16 @@ __global__ __launch_bounds__(64 * NPT * ((COUT + 31) / 32), 1) void stage_rw_ker
                 issue_skip((s - 2) / PS, sbuf_issue);
                 sbuf_issue = sbuf_issue == RW_SKIPBUF - 1 ? 0 : sbuf_issue + 1;
             }
+#ifdef RN_STAMPS
+            const unsigned long long tc0 = stamp();
+#endif
             if constexpr ((P & 1) == 0)
                 mma_row(PC, acc0);
             else
                 mma_row(PC, acc1);
+#ifdef RN_STAMPS
+            st_chain += stamp() - tc0;
+#endif
         }
         if constexpr (EPI) {
             if constexpr ((P & 1) == 0)
@@ -597,6 +667,9 @@ __global__ __launch_bounds__(64 * NPT * ((COUT + 31) / 32), 1) void stage_rw_ker
                 __builtin_amdgcn_sched_group_barrier(0x002, VPG, 0);   // VALU
             }
         }
+#ifdef RN_STAMPS
+        const unsigned long long ts1 = stamp();
+#endif
         if constexpr (MMA) {
             // retire the DMA of input row s+3 (and of the skip pair the next epilogue reads)
             if (have_next)
@@ -604,7 +677,16 @@ __global__ __launch_bounds__(64 * NPT * ((COUT + 31) / 32), 1) void stage_rw_ker
             else
                 wait_vmcnt<0>();
         }
+#ifdef RN_STAMPS
+        const unsigned long long ts2 = stamp();
+#endif
         raw_barrier();
+#ifdef RN_STAMPS
+        const unsigned long long ts3 = stamp();
+        st_work += ts1 - ts0;
+        st_dma += ts2 - ts1;
+        st_bar += ts3 - ts2;
+#endif
     };
 
     using T = IC<1>;
@@ -625,6 +707,15 @@ __global__ __launch_bounds__(64 * NPT * ((COUT + 31) / 32), 1) void stage_rw_ker
     [&]<int... I>(std::integer_sequence<int, I...>) {
         ((s % RW_NSLOT == I ? (step(IC<I>{}, F{}, T{}, s), 0) : 0), ...);
     }(std::make_integer_sequence<int, RW_NSLOT>{});
+#ifdef RN_STAMPS
+    if (a.stamp_buf && lane == 0) {
+        const int64_t w = (static_cast<int64_t>(blockIdx.y) * gridDim.x + blockIdx.x) * (NTHREADS / 64) + wave;
+        a.stamp_buf[w * 4 + 0] = st_work;
+        a.stamp_buf[w * 4 + 1] = st_dma;
+        a.stamp_buf[w * 4 + 2] = st_bar | (st_chain << 32);
+        a.stamp_buf[w * 4 + 3] = static_cast<unsigned long long>(nconv);
+    }
+#endif
 }
 
 template <int DT, int CIN, int COUT, int PK, int PS, bool RES, int NPT>
