@@ -52,16 +52,26 @@ struct RwCfg {
     static constexpr int CPO = COUT / 8;                       // 16-byte chunks per output/skip pixel
     static constexpr int TSTRIDE = tile_stride(PK, PS);
     static constexpr int NOUT_T = tile_nout(PK, PS);
-    static constexpr int RINGCOLS = (NPT - 1) * TSTRIDE + 34;
     static constexpr int NTHREADS = 64 * NPT * CT;
-    static constexpr int LPT = (RINGCOLS * CP + NTHREADS - 1) / NTHREADS;   // DMA pieces per wave per row
-    static constexpr int ROWB = LPT * NTHREADS * 16;           // ring row stride (padded to whole pieces)
+    // PRIV: every wave owns a private ring holding just its own 34-column input tile and fetches
+    // it itself.  No wave ever reads another wave's LDS data, so the row loop needs NO workgroup
+    // barrier: waves drift apart and the two waves sharing a SIMD overlap MFMA with epilogue
+    // instead of colliding in lockstep (stamps: the barrier alone cost ~20 % of a step).  The 5
+    // halo columns neighbouring tiles re-fetch come from L2, not HBM.  (Residual variants keep the
+    // workgroup-shared ring: their staged skip rows are shared too.)
+    static constexpr bool PRIV = !RES;
+    static constexpr int RINGCOLS = PRIV ? 34 : (NPT - 1) * TSTRIDE + 34;
+    static constexpr int LOADERS = PRIV ? 64 : NTHREADS;       // lanes cooperating on one ring row
+    static constexpr int NRINGS = PRIV ? NPT * CT : 1;
+    static constexpr int LPT = (RINGCOLS * CP + LOADERS - 1) / LOADERS;     // DMA pieces per wave per row
+    // shared ring: row stride padded to whole pieces; private ring: exact (the last piece is lane-masked)
+    static constexpr int ROWB = PRIV ? RINGCOLS * CIN * 2 : LPT * NTHREADS * 16;
     static constexpr int SKIPCOLS_MAX = RINGCOLS + 8;          // residual scale <= ~1.1 (checked on the host)
     static constexpr int SLPT = RES ? (2 * SKIPCOLS_MAX * CPO + NTHREADS - 1) / NTHREADS : 0;
     static constexpr int SKIPBUFB = SLPT * NTHREADS * 16;      // one staged pair of skip rows (padded)
     static constexpr int PTAB_BYTES = 4 * COUT * 4;
     static constexpr int RING_OFF = PTAB_BYTES;
-    static constexpr int SKIP_OFF = RING_OFF + NSLOT * ROWB;
+    static constexpr int SKIP_OFF = RING_OFF + NRINGS * NSLOT * ROWB;
     // output staging (one 32-channel cout tile only): each wave transposes its tile-row
     // [pixel][64 B] through LDS so that the global stores are lane-linear (1 KB contiguous per
     // instruction) instead of 16 B per lane at a 64-byte stride
@@ -93,6 +103,7 @@ struct RwCfg {
     static_assert(KC * 4 <= 80 || NTHREADS <= 256, "weights need the whole register file: <= 1 wave per SIMD");
     static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
     static_assert(NSLOT % 2 == 0, "pool-ring parity is tied to the unroll");
+    static_assert(!PRIV || (LPT - 1) * 64 < RINGCOLS * CP, "every DMA piece must have at least one active lane");
     static_assert(VMCNT_STEADY <= 63, "vmcnt field");
 };
 
@@ -152,7 +163,7 @@ __global__ __launch_bounds__(64 * NPT * ((COUT + 31) / 32), 1) void stage_rw_ker
     const int n = blockIdx.y;
 
     float* const ptab = reinterpret_cast<float*>(smem);
-    char* const ring = smem + C::RING_OFF;
+    char* const ring = smem + C::RING_OFF + (C::PRIV ? wave * (C::NSLOT * C::ROWB) : 0);
     char* const skipb = smem + C::SKIP_OFF;
     const int skipbytes = a.skipcols * COUT * 2;        // bytes per staged skip row
 
@@ -182,19 +193,27 @@ __global__ __launch_bounds__(64 * NPT * ((COUT + 31) / 32), 1) void stage_rw_ker
     const char* const in_img = reinterpret_cast<const char*>(a.in + static_cast<int64_t>(n) * a.H * a.W * CIN);
     const int64_t in_row_bytes = static_cast<int64_t>(a.W) * CIN * 2;
     unsigned ld_goff[LPT];
+    bool ld_ok[LPT];
+    const int x_ring0 = C::PRIV ? x0c + pt * TSTRIDE : x0c;            // image column of ring column 0
 #pragma unroll
     for (int i = 0; i < LPT; ++i) {
-        const int q = tid + i * NTHREADS;
+        const int q = (C::PRIV ? lane : tid) + i * C::LOADERS;
         const int p = q / CP, c8 = q % CP;
-        const int pc = min(x0c + min(p, RINGCOLS - 1), a.W - 1);
+        const int pc = min(x_ring0 + min(p, RINGCOLS - 1), a.W - 1);
         ld_goff[i] = static_cast<unsigned>((pc * CIN + (c8 ^ chunk_swz<CP>(p)) * 8) * 2);
+        ld_ok[i] = !C::PRIV || q < RINGCOLS * CP;                        // private ring: mask the tail lanes
     }
-    const int piece_base = wave * 64 * 16;               // LDS byte offset of this wave inside a piece
+    const int piece_base = C::PRIV ? 0 : wave * 64 * 16;   // LDS byte offset of this wave inside a piece
     auto issue_row = [&](int j, int slot) __attribute__((always_inline)) {               // input row yc0 + j -> ring slot
         const char* row = in_img + static_cast<int64_t>(yc0 + j) * in_row_bytes;
 #pragma unroll
-        for (int i = 0; i < LPT; ++i)
-            dma16(row + ld_goff[i], ring + slot * ROWB + i * NTHREADS * 16 + piece_base);
+        for (int i = 0; i < LPT; ++i) {
+            if constexpr (C::PRIV) {
+                if (ld_ok[i]) dma16(row + ld_goff[i], ring + slot * ROWB + i * 64 * 16);
+            } else {
+                dma16(row + ld_goff[i], ring + slot * ROWB + i * NTHREADS * 16 + piece_base);
+            }
+        }
     };
 
     // ---- skip-row DMA (residual stages): the pair of rows lo/hi of one output row
@@ -240,7 +259,7 @@ __global__ __launch_bounds__(64 * NPT * ((COUT + 31) / 32), 1) void stage_rw_ker
     for (int j = 0; j < RW_AHEAD; ++j) issue_row(min(j, nin - 1), j);
 
     // ---- lane constants of this wave's pixel tile
-    const int xrel0 = pt * TSTRIDE + r;
+    const int xrel0 = (C::PRIV ? 0 : pt * TSTRIDE) + r;      // ring column of conv column (tap kx = 0)
     int boff[3][CIN >= 16 ? CIN / 16 : 1];
     int b8_ky[CIN >= 16 ? 1 : KC], b8_off[CIN >= 16 ? 1 : KC];   // CIN == 8: per K-chunk tap row / offset
     if constexpr (CIN >= 16) {
@@ -259,7 +278,7 @@ __global__ __launch_bounds__(64 * NPT * ((COUT + 31) / 32), 1) void stage_rw_ker
             b8_off[kc] = (xrel0 + kx) * PIXB;
         }
     }
-    const int xc = x0c + xrel0;
+    const int xc = x0c + pt * TSTRIDE + r;
     const int xo = PK ? xc / PS : xc;
     const bool lane_out = (PK ? ((r % PS == 0) && r <= 32 - PK) : true) && xo < a.Wo && (xo - xo_blk0) < NPT * NOUT_T;
     unsigned short* const out_lane =
@@ -680,7 +699,7 @@ __global__ __launch_bounds__(64 * NPT * ((COUT + 31) / 32), 1) void stage_rw_ker
 #ifdef RN_STAMPS
         const unsigned long long ts2 = stamp();
 #endif
-        raw_barrier();
+        if constexpr (!C::PRIV) raw_barrier();
 #ifdef RN_STAMPS
         const unsigned long long ts3 = stamp();
         st_work += ts1 - ts0;
