@@ -38,7 +38,7 @@ typedef __attribute__((address_space(3))) void* lds_void_ptr;
 
 constexpr int RW_SKIPBUF = 3;   // staged skip-row pairs (residual): 1 being read + 2 in flight
 
-template <int DT, int CIN, int COUT, int PK, int PS, bool RES, int NPT>
+template <int DT, int CIN, int COUT, int PK, int PS, bool RES, int NPT, int KS = 1>
 struct RwCfg {
     // Ring depth: at step s the DMA for input row s + AHEAD is issued; NSLOT = AHEAD + 1 slots
     // (3 live rows + AHEAD - 2 in flight).  Rows of the 8-channel stage are only ~3.8 KB, so it
@@ -52,14 +52,17 @@ struct RwCfg {
     static constexpr int CPO = COUT / 8;                       // 16-byte chunks per output/skip pixel
     static constexpr int TSTRIDE = tile_stride(PK, PS);
     static constexpr int NOUT_T = tile_nout(PK, PS);
-    static constexpr int NTHREADS = 64 * NPT * CT;
+    // KS = 3: the K dimension is split by kernel row over three waves per pixel tile (each keeps one
+    // kernel row's weight fragments in registers); partial accumulators meet in LDS (K = 1152 stage)
+    static constexpr int NTHREADS = 64 * NPT * CT * KS;
+    static constexpr int KCW = KC / KS;                        // K-chunks per wave
     // PRIV: every wave owns a private ring holding just its own 34-column input tile and fetches
     // it itself.  No wave ever reads another wave's LDS data, so the row loop needs NO workgroup
     // barrier: waves drift apart and the two waves sharing a SIMD overlap MFMA with epilogue
     // instead of colliding in lockstep (stamps: the barrier alone cost ~20 % of a step).  The 5
     // halo columns neighbouring tiles re-fetch come from L2, not HBM.  (Residual variants keep the
     // workgroup-shared ring: their staged skip rows are shared too.)
-    static constexpr bool PRIV = !RES;
+    static constexpr bool PRIV = !RES && KS == 1;
     static constexpr int RINGCOLS = PRIV ? 34 : (NPT - 1) * TSTRIDE + 34;
     static constexpr int LOADERS = PRIV ? 64 : NTHREADS;       // lanes cooperating on one ring row
     static constexpr int NRINGS = PRIV ? NPT * CT : 1;
@@ -86,7 +89,9 @@ struct RwCfg {
     static constexpr bool PTAB_LATE = !PTAB_REGS && CIN == 32 && COUT == 32;
     static constexpr int STAGE_WAVE_B = 32 * 64;
     static constexpr int STAGE_OFF = SKIP_OFF + (RES ? RW_SKIPBUF * SKIPBUFB : 0);
-    static constexpr int LDS_BYTES = STAGE_OFF + (STAGE_OUT ? NPT * CT * STAGE_WAVE_B : 0);
+    static constexpr int PART_OFF = STAGE_OFF + (STAGE_OUT ? NPT * CT * STAGE_WAVE_B : 0);
+    static constexpr int PART_B = 16 * 64 * 4;                 // one wave's partial accumulator tile
+    static constexpr int LDS_BYTES = PART_OFF + (KS > 1 ? 2 * NPT * CT * (KS - 1) * PART_B : 0);
     // steady-state counted wait at the end of step s: everything up to input row s+3 and the
     // skip pair used by step s+1 has landed; what may stay in flight is what the wave issued
     // after them (the pieces of this step, plus one more row of input when there is no skip)
@@ -100,7 +105,8 @@ struct RwCfg {
     static_assert(!RES || AHEAD == 5, "the residual wait counts are derived for AHEAD = 5");
     static_assert(COUT % 32 == 0 || COUT == 16, "cout must be whole 32-channel tiles (or one half tile)");
     static_assert(PK == 0 || PK == 4, "pool window 4 or none");
-    static_assert(KC * 4 <= 80 || NTHREADS <= 256, "weights need the whole register file: <= 1 wave per SIMD");
+    static_assert(KCW * 4 <= 80 || NTHREADS <= 256 || KS > 1, "weights need the whole register file: <= 1 wave per SIMD");
+    static_assert(KS == 1 || (KS == 3 && CIN >= 16 && KC % 3 == 0 && !RES), "K split = one kernel row per wave");
     static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
     static_assert(NSLOT % 2 == 0, "pool-ring parity is tied to the unroll");
     static_assert(!PRIV || (LPT - 1) * 64 < RINGCOLS * CP, "every DMA piece must have at least one active lane");
@@ -142,9 +148,9 @@ __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int DT, int CIN, int COUT, int PK, int PS, bool RES, int NPT>
-__global__ __launch_bounds__(64 * NPT * ((COUT + 31) / 32), 1) void stage_rw_kernel(const StageArgs a) {
-    using C = RwCfg<DT, CIN, COUT, PK, PS, RES, NPT>;
+template <int DT, int CIN, int COUT, int PK, int PS, bool RES, int NPT, int KS>
+__global__ __launch_bounds__(64 * NPT * ((COUT + 31) / 32) * KS, 1) void stage_rw_kernel(const StageArgs a) {
+    using C = RwCfg<DT, CIN, COUT, PK, PS, RES, NPT, KS>;
     constexpr int CP = C::CP, KC = C::KC, CT = C::CT, CPO = C::CPO, TSTRIDE = C::TSTRIDE, NOUT_T = C::NOUT_T;
     constexpr int RINGCOLS = C::RINGCOLS, ROWB = C::ROWB, NTHREADS = C::NTHREADS, LPT = C::LPT, SLPT = C::SLPT;
     constexpr int PIXB = CIN * 2, NG = C::NG;
@@ -154,7 +160,9 @@ __global__ __launch_bounds__(64 * NPT * ((COUT + 31) / 32), 1) void stage_rw_ker
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int pt = wave % NPT, ct = wave / NPT;
+    const int pt = wave % NPT, ct = (wave / NPT) % CT;
+    const int ks = __builtin_amdgcn_readfirstlane(wave / (NPT * CT));     // kernel row of this wave (K split)
+    constexpr int KCW = C::KCW;
     const int r = lane & 31, hh = lane >> 5;
 
     int bid = blockIdx.x;
@@ -180,9 +188,9 @@ __global__ __launch_bounds__(64 * NPT * ((COUT + 31) / 32), 1) void stage_rw_ker
     for (int i = tid; i < 4 * COUT; i += NTHREADS) ptab[i] = a.ptab[i];
 
     // ---- this wave's weight fragments -> registers (lane-linear, coalesced)
-    i32x4 wreg[KC];
+    i32x4 wreg[KCW];
 #pragma unroll
-    for (int kc = 0; kc < KC; ++kc) wreg[kc] = a.wfrag[(kc * CT + ct) * 64 + lane];
+    for (int kc = 0; kc < KCW; ++kc) wreg[kc] = a.wfrag[((ks * KCW + kc) * CT + ct) * 64 + lane];
 
     // ---- input-row DMA: piece i of a row covers ring chunks [i*NTHREADS, (i+1)*NTHREADS); this
     // lane fills chunk q = tid + i*NTHREADS = (pixel p, slot c') and therefore fetches source
@@ -419,7 +427,7 @@ __global__ __launch_bounds__(64 * NPT * ((COUT + 31) / 32), 1) void stage_rw_ker
             }
     }
     auto b_read_asm = [&](auto PC, auto KCC) __attribute__((always_inline)) -> i32x4 {
-        constexpr int P = decltype(PC)::value, kc = decltype(KCC)::value;
+        constexpr int P = decltype(PC)::value, kc = decltype(KCC)::value;   // kc: global K-chunk
         constexpr int tap = kc / (CIN / 16), cc = kc % (CIN / 16);
         constexpr int ky = tap / 3, kx = tap % 3;
         constexpr int slot = (P + ky) % RW_NSLOT;
@@ -430,23 +438,24 @@ __global__ __launch_bounds__(64 * NPT * ((COUT + 31) / 32), 1) void stage_rw_ker
             asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(bbase1[kx][cc]), "n"((slot - SLOT_SPLIT) * ROWB));
         return v;
     };
-    // MFMA chain of one conv row
-    auto mma_row = [&](auto PC, f32x16& acc) __attribute__((always_inline)) {
+    // MFMA chain of one conv row over the K-chunks [KB, KB + KCW) (KB = 0 unless K is split)
+    auto mma_chain = [&](auto PC, auto KBC, f32x16& acc) __attribute__((always_inline)) {
+        constexpr int KB = decltype(KBC)::value;
         const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        i32x4 bq[KC];
+        i32x4 bq[KCW];
         if constexpr (CIN >= 16) {
             [&]<int... I>(std::integer_sequence<int, I...>) {
-                ((bq[I] = b_read_asm(PC, IC<I>{})), ...);
+                ((bq[I] = b_read_asm(PC, IC<KB + I>{})), ...);
             }(std::make_integer_sequence<int, BAHEAD>{});
             [&]<int... I>(std::integer_sequence<int, I...>) {
                 (([&] {
-                     if constexpr (I + BAHEAD < KC) bq[I + BAHEAD] = b_read_asm(PC, IC<(I + BAHEAD < KC ? I + BAHEAD : 0)>{});
-                     constexpr int newer = (KC - 1 - I) < BAHEAD ? (KC - 1 - I) : BAHEAD;   // my reads issued after chunk I
+                     if constexpr (I + BAHEAD < KCW) bq[I + BAHEAD] = b_read_asm(PC, IC<KB + (I + BAHEAD < KCW ? I + BAHEAD : 0)>{});
+                     constexpr int newer = (KCW - 1 - I) < BAHEAD ? (KCW - 1 - I) : BAHEAD;   // my reads issued after chunk I
                      asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(bq[I]) : "n"(newer));
                      acc = mfma32<DT>(wreg[I], bq[I], I == 0 ? zero : acc);
                  }()),
                  ...);
-            }(std::make_integer_sequence<int, KC>{});
+            }(std::make_integer_sequence<int, KCW>{});
         } else {
             bq[0] = b_frag(PC, IC<0>{});
             [&]<int... I>(std::integer_sequence<int, I...>) {
@@ -454,6 +463,65 @@ __global__ __launch_bounds__(64 * NPT * ((COUT + 31) / 32), 1) void stage_rw_ker
                   acc = mfma32<DT>(wreg[I], bq[I], I == 0 ? zero : acc)),
                  ...);
             }(std::make_integer_sequence<int, KC>{});
+        }
+    };
+    auto mma_row = [&](auto PC, f32x16& acc) __attribute__((always_inline)) {
+        if constexpr (KS == 1) {
+            mma_chain(PC, IC<0>{}, acc);
+        } else {
+            // wave-uniform dispatch on the kernel row: ring slot and tap offsets stay compile-time
+            if (ks == 0)
+                mma_chain(PC, IC<0>{}, acc);
+            else if (ks == 1)
+                mma_chain(PC, IC<KCW>{}, acc);
+            else
+                mma_chain(PC, IC<2 * KCW>{}, acc);
+        }
+    };
+    // K split: LDS exchange of partial accumulators, double-buffered by step parity
+    const unsigned part_lds = static_cast<unsigned>(reinterpret_cast<uintptr_t>(
+        (__attribute__((address_space(3))) char*)(smem + C::PART_OFF))) + lane * 16;
+    auto part_addr = [&](int parity, int k1) __attribute__((always_inline)) -> unsigned {   // k1 = ks - 1 of the writer
+        return part_lds + static_cast<unsigned>(((parity * NPT * CT + (ct * NPT + pt)) * (KS - 1) + k1) * C::PART_B);
+    };
+    auto part_write = [&](int parity, const f32x16& acc_in) __attribute__((always_inline)) {
+        const unsigned ad = part_addr(parity, ks - 1);
+        // The DS writes below are inline asm and read registers the MFMA chain has just written:
+        // hipcc inserts no XDL-write -> DS-read wait states around asm, so spend them explicitly
+        // (16-pass MFMA: 18 states; two s_nop 15 are 32).  The "+v" operand ties the statement to the
+        // accumulator registers -- a memory clobber alone does not keep the MFMAs in front of it.
+        f32x16 acc = acc_in;
+        asm volatile("s_nop 15\n\ts_nop 15" : "+v"(acc));
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const i32x4 v = {__float_as_int(acc[4 * g]), __float_as_int(acc[4 * g + 1]), __float_as_int(acc[4 * g + 2]),
+                             __float_as_int(acc[4 * g + 3])};
+            switch (g) {
+                case 0: asm volatile("ds_write_b128 %0, %1\n\ts_nop 1" ::"v"(ad), "v"(v) : "memory"); break;
+                case 1: asm volatile("ds_write_b128 %0, %1 offset:1024\n\ts_nop 1" ::"v"(ad), "v"(v) : "memory"); break;
+                case 2: asm volatile("ds_write_b128 %0, %1 offset:2048\n\ts_nop 1" ::"v"(ad), "v"(v) : "memory"); break;
+                default: asm volatile("ds_write_b128 %0, %1 offset:3072\n\ts_nop 1" ::"v"(ad), "v"(v) : "memory"); break;
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    };
+    auto part_add = [&](int parity, f32x16& acc) __attribute__((always_inline)) {
+#pragma unroll
+        for (int k1 = 0; k1 < KS - 1; ++k1) {
+            const unsigned ad = part_addr(parity, k1);
+            i32x4 v0, v1, v2, v3;
+            asm volatile("ds_read_b128 %0, %1" : "=v"(v0) : "v"(ad) : "memory");
+            asm volatile("ds_read_b128 %0, %1 offset:1024" : "=v"(v1) : "v"(ad) : "memory");
+            asm volatile("ds_read_b128 %0, %1 offset:2048" : "=v"(v2) : "v"(ad) : "memory");
+            asm volatile("ds_read_b128 %0, %1 offset:3072" : "=v"(v3) : "v"(ad) : "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3));
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                acc[j] += __int_as_float(v0[j]);
+                acc[4 + j] += __int_as_float(v1[j]);
+                acc[8 + j] += __int_as_float(v2[j]);
+                acc[12 + j] += __int_as_float(v3[j]);
+            }
         }
     };
 
@@ -657,22 +725,31 @@ __global__ __launch_bounds__(64 * NPT * ((COUT + 31) / 32), 1) void stage_rw_ker
                 issue_skip((s - 2) / PS, sbuf_issue);
                 sbuf_issue = sbuf_issue == RW_SKIPBUF - 1 ? 0 : sbuf_issue + 1;
             }
-#ifdef RN_STAMPS
+#if defined(RN_STAMPS) && defined(RN_STAMP_CHAIN)
             const unsigned long long tc0 = stamp();
 #endif
             if constexpr ((P & 1) == 0)
                 mma_row(PC, acc0);
             else
                 mma_row(PC, acc1);
-#ifdef RN_STAMPS
+#if defined(RN_STAMPS) && defined(RN_STAMP_CHAIN)
             st_chain += stamp() - tc0;
 #endif
+            if constexpr (KS > 1) {
+                // waves of kernel rows 1, 2 publish their partial sums for the epilogue of the next step
+                if (ks > 0) part_write(P & 1, (P & 1) == 0 ? acc0 : acc1);
+            }
         }
         if constexpr (EPI) {
-            if constexpr ((P & 1) == 0)
-                epi_row(IC<(P + RW_NSLOT - 1) % RW_NSLOT>{}, acc1, s - 1, sbuf_read);
-            else
-                epi_row(IC<(P + RW_NSLOT - 1) % RW_NSLOT>{}, acc0, s - 1, sbuf_read);
+            if (KS == 1 || ks == 0) {        // K split: only the wave of kernel row 0 owns the epilogue
+                if constexpr ((P & 1) == 0) {
+                    if constexpr (KS > 1) part_add((P + 1) & 1, acc1);
+                    epi_row(IC<(P + RW_NSLOT - 1) % RW_NSLOT>{}, acc1, s - 1, sbuf_read);
+                } else {
+                    if constexpr (KS > 1) part_add((P + 1) & 1, acc0);
+                    epi_row(IC<(P + RW_NSLOT - 1) % RW_NSLOT>{}, acc0, s - 1, sbuf_read);
+                }
+            }
         }
         // the epilogue of this step handled conv row s-1 (phase parity (P+1)&1): rotate after an emit phase
         if constexpr (RES && EPI && (PS == 1 || ((P + 1) & 1) == 1))
@@ -737,10 +814,10 @@ __global__ __launch_bounds__(64 * NPT * ((COUT + 31) / 32), 1) void stage_rw_ker
 #endif
 }
 
-template <int DT, int CIN, int COUT, int PK, int PS, bool RES, int NPT>
+template <int DT, int CIN, int COUT, int PK, int PS, bool RES, int NPT, int KS = 1>
 int launch_rw(hipStream_t s, const StageArgs& a, dim3 grid) {
-    using C = RwCfg<DT, CIN, COUT, PK, PS, RES, NPT>;
-    auto kern = stage_rw_kernel<DT, CIN, COUT, PK, PS, RES, NPT>;
+    using C = RwCfg<DT, CIN, COUT, PK, PS, RES, NPT, KS>;
+    auto kern = stage_rw_kernel<DT, CIN, COUT, PK, PS, RES, NPT, KS>;
     static bool attr_set = false;
     if (!attr_set) {
         RN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -752,10 +829,10 @@ int launch_rw(hipStream_t s, const StageArgs& a, dim3 grid) {
     return RN_OK;
 }
 
-template <int CIN, int COUT, int PK, int PS, bool RES, int NPT>
+template <int CIN, int COUT, int PK, int PS, bool RES, int NPT, int KS = 1>
 int launch_rw_dt(int dtype, hipStream_t s, const StageArgs& a, dim3 grid) {
-    if (dtype == RN_DTYPE_BF16) return launch_rw<RN_DTYPE_BF16, CIN, COUT, PK, PS, RES, NPT>(s, a, grid);
-    return launch_rw<RN_DTYPE_F16, CIN, COUT, PK, PS, RES, NPT>(s, a, grid);
+    if (dtype == RN_DTYPE_BF16) return launch_rw<RN_DTYPE_BF16, CIN, COUT, PK, PS, RES, NPT, KS>(s, a, grid);
+    return launch_rw<RN_DTYPE_F16, CIN, COUT, PK, PS, RES, NPT, KS>(s, a, grid);
 }
 
 }  // namespace
@@ -778,6 +855,7 @@ bool rn_rw_supported(int cin, int cout, int pool_k, int pool_s, bool res, int ou
     if (cin == 32 && cout == 64 && pool_k == 4 && ps == 2 && !res) variant = 3, npt = 4;
     if (cin == 64 && cout == 64 && pool_k == 4 && ps == 2 && res) variant = 4, npt = 2;
     if (cin == 64 && cout == 128 && pool_k == 0 && !res) variant = 5, npt = 1;
+    if (cin == 128 && cout == 16 && pool_k == 4 && ps == 2 && !res) variant = 6, npt = 2;   // K split over 3 waves
     if (variant < 0) return false;
     plan->variant = variant;
     plan->npt = npt;
@@ -816,6 +894,7 @@ int rn_rw_launch(const RwPlan& p, int dtype, hipStream_t s, const StageArgs& a, 
         case 3 * 16 + 4: return launch_rw_dt<32, 64, 4, 2, false, 4>(dtype, s, a, grid);
         case 4 * 16 + 2: return launch_rw_dt<64, 64, 4, 2, true, 2>(dtype, s, a, grid);
         case 5 * 16 + 1: return launch_rw_dt<64, 128, 0, 1, false, 1>(dtype, s, a, grid);
+        case 6 * 16 + 2: return launch_rw_dt<128, 16, 4, 2, false, 2, 3>(dtype, s, a, grid);
         default:
             rn_set_error("rw kernel: no instantiation for variant %d npt %d", p.variant, p.npt);
             return RN_E_INVALID;
