@@ -51,7 +51,7 @@ def measured_traffic(stage, batch, side, dtype):
     """HBM bytes per launch of `stage` from the committed rocprofv3 PMC passes (profiles/), or None
     when no profile matches this configuration.  bench.py cannot profile itself: the counters are
     collected by running this same command under `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE`."""
-    path = os.path.join(ROOT, "profiles", "r1_g_hbm_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r1_h_hbm_traffic.json")
     try:
         with open(path) as f:
             t = json.load(f)
@@ -65,7 +65,7 @@ def measured_traffic(stage, batch, side, dtype):
     return None
 
 
-def cpu_baseline(weights, side, budget_s=20.0):
+def cpu_baseline(weights, side, budget_s=15.0):
     """Time the plain-C oracle on a bounded sample (rank 0, N=1 only)."""
     from oracle import c_oracle
     from roomnet_amd.synth import perf_batch
@@ -80,7 +80,7 @@ def cpu_baseline(weights, side, budget_s=20.0):
         done += len(ims)
         reps += 1
         el = time.perf_counter() - t0
-        if el >= budget_s or reps >= 3 and el >= budget_s / 2 or reps >= 6:
+        if el >= budget_s or reps >= 40:
             break
     el = time.perf_counter() - t0
     return {"value": done / el, "unit": "images/sec", "cores": cores, "kind": "port",
@@ -211,8 +211,9 @@ def main():
                        "parallelism": "dp%d" % world},
             "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK, "traffic": measured_traffic(dom, B, args.side, args.dtype),
-                         "kernel": "stage_mfma_kernel stage %d (%d->%d ch)" % (dom, graph.stages[dom].cin,
-                                                                              graph.stages[dom].cout)
+                         "kernel": ("stage_rw_kernel, stage %d (%d->%d ch%s)" % (
+                                        dom, graph.stages[dom].cin, graph.stages[dom].cout,
+                                        " + residual" if graph.stages[dom].residual else ""))
                                    if dom > 0 and args.dtype != "f32" else "stage %d" % dom,
                          "kernel_ms": float(stage_ms[dom]), "algorithmic_bytes_per_launch": int(dom_bytes)},
             "path": {"algorithmic_bytes_per_image": int(bytes_per_img),

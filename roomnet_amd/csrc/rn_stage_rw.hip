@@ -62,7 +62,10 @@ struct RwCfg {
     // instead of colliding in lockstep (stamps: the barrier alone cost ~20 % of a step).  The 5
     // halo columns neighbouring tiles re-fetch come from L2, not HBM.  (Residual variants keep the
     // workgroup-shared ring: their staged skip rows are shared too.)
-    static constexpr bool PRIV = !RES && KS == 1;
+    // Only for single-cout-tile stages: with several cout tiles the waves of one pixel tile would each
+    // fetch the same input, and once they drift apart the duplicates miss L2 (measured on the 32->64
+    // stage: 1.65x the algorithmic HBM bytes); those stages keep the workgroup-shared ring.
+    static constexpr bool PRIV = !RES && KS == 1 && CT == 1;
     static constexpr int RINGCOLS = PRIV ? 34 : (NPT - 1) * TSTRIDE + 34;
     static constexpr int LOADERS = PRIV ? 64 : NTHREADS;       // lanes cooperating on one ring row
     static constexpr int NRINGS = PRIV ? NPT * CT : 1;
