@@ -83,6 +83,12 @@ __device__ __forceinline__ float lane_next(float v) {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130, 0xf, 0xf, true));
 }
 
+// value of lane+N inside the 16-lane DPP row (row_shl:N; lanes without a source read 0)
+template <int N>
+__device__ __forceinline__ float row_next(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x100 + N, 0xf, 0xf, true));
+}
+
 __device__ __forceinline__ float relu6f(float v) { return __builtin_amdgcn_fmed3f(v, 0.f, 6.f); }
 
 // ------------------------------------------------------------------------ MFMA stage

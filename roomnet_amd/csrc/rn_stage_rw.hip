@@ -36,6 +36,14 @@ using IC = std::integral_constant<int, P>;
 
 typedef __attribute__((address_space(3))) void* lds_void_ptr;
 
+// Tile geometry of the rw kernels.  Pool 4/1: 32 consecutive conv columns per tile, 29 outputs, the
+// horizontal window sums walk the whole wave (DPP wave_shl).  Pool 4/2 ("gapped" tiles): the two
+// 16-lane DPP rows of a half-wave hold conv columns 0..15 and 14..29, so every window that starts
+// at an even column of a row ends inside that row: 7 + 7 outputs per tile from two row-local
+// shifts (row_shl:1, row_shl:2) instead of three wave shifts.
+constexpr int rw_tile_nout(int pk, int ps) { return pk ? (ps == 2 ? 14 : 32 - pk + 1) : 32; }
+constexpr int rw_tile_stride(int pk, int ps) { return pk ? rw_tile_nout(pk, ps) * ps : 32; }
+
 constexpr int RW_SKIPBUF = 3;   // staged skip-row pairs (residual): 1 being read + 2 in flight
 
 template <int DT, int CIN, int COUT, int PK, int PS, bool RES, int NPT, int KS = 1>
@@ -43,15 +51,19 @@ struct RwCfg {
     // Ring depth: at step s the DMA for input row s + AHEAD is issued; NSLOT = AHEAD + 1 slots
     // (3 live rows + AHEAD - 2 in flight).  Rows of the 8-channel stage are only ~3.8 KB, so it
     // keeps 9 of them in flight to cover the HBM latency (Little's law), the others 3.
-    static constexpr int AHEAD = CIN == 8 ? 11 : 5;
+#ifndef RN_AHEAD_PRIV32
+#define RN_AHEAD_PRIV32 5
+#endif
+    static constexpr int AHEAD = CIN == 8 ? 11 : ((CIN == 32 && COUT == 32 && !RES) ? RN_AHEAD_PRIV32 : 5);
     static constexpr int NSLOT = AHEAD + 1;
     static constexpr int CP = CIN / 8;
     static constexpr int KC = (9 * CIN + 15) / 16;
     static constexpr int CT = (COUT + 31) / 32;
     static constexpr int NG = COUT >= 32 ? 4 : COUT / 8;   // 4-channel groups per lane half-row
     static constexpr int CPO = COUT / 8;                       // 16-byte chunks per output/skip pixel
-    static constexpr int TSTRIDE = tile_stride(PK, PS);
-    static constexpr int NOUT_T = tile_nout(PK, PS);
+    static constexpr int TSTRIDE = rw_tile_stride(PK, PS);
+    static constexpr int NOUT_T = rw_tile_nout(PK, PS);
+    static constexpr bool GAP = PK == 4 && PS == 2;           // gapped lane -> column map (see rw_tile_nout)
     // KS = 3: the K dimension is split by kernel row over three waves per pixel tile (each keeps one
     // kernel row's weight fragments in registers); partial accumulators meet in LDS (K = 1152 stage)
     static constexpr int NTHREADS = 64 * NPT * CT * KS;
@@ -81,9 +93,14 @@ struct RwCfg {
     // output staging (one 32-channel cout tile only): each wave transposes its tile-row
     // [pixel][64 B] through LDS so that the global stores are lane-linear (1 KB contiguous per
     // instruction) instead of 16 B per lane at a 64-byte stride
-    // (measured: +23 % on the 8->32 stage whose row has 5 MFMAs and is store-dominated; -20 % on the
-    //  32->32 stages, where the serial write/read/wait/store tail cannot hide behind the MFMA chain)
-    static constexpr bool STAGE_OUT = COUT == 32 && CIN == 8;
+    // (measured: +23 % on the 8->32 stage, +13 % on the 32->32 stage: 64 lanes x 16 B at a 64-byte
+    //  stride are 64 partial-line write requests per instruction, lane-linear stores are 8 full lines;
+    //  no gain on the residual variant, which is bound by its epilogue)
+#ifdef RN_STAGE_OUT_RES
+    static constexpr bool STAGE_OUT = COUT == 32;
+#else
+    static constexpr bool STAGE_OUT = COUT == 32 && !RES;
+#endif
     // folded-BN tables: persistent registers where the register file has room (one wave per SIMD, or the
     // small 8-channel stage); otherwise one batched LDS read at the start of every epilogue
     static constexpr bool PTAB_REGS = NTHREADS <= 256 || CIN == 8;
@@ -131,6 +148,28 @@ __device__ __forceinline__ void raw_barrier() {
 // the host pass drop the kernel's launch stub without a diagnostic.)
 __device__ __forceinline__ void dma16(const void* gsrc, char* lds) {
     __builtin_amdgcn_global_load_lds(gsrc, (lds_void_ptr)lds, 16, 0, 0);
+}
+
+// The same piece with only the lanes of `mask` active (tail piece of a wave-private ring row).
+// Done with an explicit EXEC window instead of `if (lane_ok)`: a divergent branch would split the
+// row step into several basic blocks and the MFMA / epilogue interleave stops at block borders.
+// Only called from wave-uniform code with all lanes active (EXEC is restored to all ones).
+__device__ __forceinline__ void dma16_masked(const void* gsrc, char* lds, unsigned long long mask) {
+    const unsigned lds_addr = static_cast<unsigned>(reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) char*)lds));
+    asm volatile(
+        "s_mov_b32 m0, %1\n\t"
+        "s_mov_b64 exec, %2\n\t"
+#ifdef RN_HZ_EXEC
+        "s_nop 7\n\t"
+#endif
+        "global_load_lds_dwordx4 %0, off\n\t"
+#ifdef RN_HZ_EXEC
+        "s_nop 7\n\t"
+#endif
+        "s_mov_b64 exec, -1"
+        :
+        : "v"(gsrc), "s"(lds_addr), "s"(mask)
+        : "memory", "m0", "exec");
 }
 
 #ifdef RN_STAMPS
@@ -204,7 +243,6 @@ __global__ __launch_bounds__(64 * NPT * ((COUT + 31) / 32) * KS, 1) void stage_r
     const char* const in_img = reinterpret_cast<const char*>(a.in + static_cast<int64_t>(n) * a.H * a.W * CIN);
     const int64_t in_row_bytes = static_cast<int64_t>(a.W) * CIN * 2;
     unsigned ld_goff[LPT];
-    bool ld_ok[LPT];
     const int x_ring0 = C::PRIV ? x0c + pt * TSTRIDE : x0c;            // image column of ring column 0
 #pragma unroll
     for (int i = 0; i < LPT; ++i) {
@@ -212,19 +250,32 @@ __global__ __launch_bounds__(64 * NPT * ((COUT + 31) / 32) * KS, 1) void stage_r
         const int p = q / CP, c8 = q % CP;
         const int pc = min(x_ring0 + min(p, RINGCOLS - 1), a.W - 1);
         ld_goff[i] = static_cast<unsigned>((pc * CIN + (c8 ^ chunk_swz<CP>(p)) * 8) * 2);
-        ld_ok[i] = !C::PRIV || q < RINGCOLS * CP;                        // private ring: mask the tail lanes
     }
     const int piece_base = C::PRIV ? 0 : wave * 64 * 16;   // LDS byte offset of this wave inside a piece
+    // private ring: active lanes of the last (partial) piece of a row
+    constexpr int TAIL_LANES = C::PRIV ? RINGCOLS * CP - (LPT - 1) * 64 : 64;
+    constexpr unsigned long long tail_mask = TAIL_LANES >= 64 ? ~0ull : ((1ull << TAIL_LANES) - 1ull);
     auto issue_row = [&](int j, int slot) __attribute__((always_inline)) {               // input row yc0 + j -> ring slot
         const char* row = in_img + static_cast<int64_t>(yc0 + j) * in_row_bytes;
-#pragma unroll
-        for (int i = 0; i < LPT; ++i) {
+        [&]<int... II>(std::integer_sequence<int, II...>) {
+            (([&] {
+                 constexpr int i = II;
             if constexpr (C::PRIV) {
-                if (ld_ok[i]) dma16(row + ld_goff[i], ring + slot * ROWB + i * 64 * 16);
+                if constexpr ((i + 1) * 64 <= RINGCOLS * CP)
+                    dma16(row + ld_goff[i], ring + slot * ROWB + i * 64 * 16);
+                else {
+#ifdef RN_BIS_DMA
+                    if (lane < TAIL_LANES) dma16(row + ld_goff[i], ring + slot * ROWB + i * 64 * 16);
+#else
+                    dma16_masked(row + ld_goff[i], ring + slot * ROWB + i * 64 * 16, tail_mask);
+#endif
+                }
             } else {
                 dma16(row + ld_goff[i], ring + slot * ROWB + i * NTHREADS * 16 + piece_base);
             }
-        }
+             }()),
+             ...);
+        }(std::make_integer_sequence<int, LPT>{});
     };
 
     // ---- skip-row DMA (residual stages): the pair of rows lo/hi of one output row
@@ -270,7 +321,8 @@ __global__ __launch_bounds__(64 * NPT * ((COUT + 31) / 32) * KS, 1) void stage_r
     for (int j = 0; j < RW_AHEAD; ++j) issue_row(min(j, nin - 1), j);
 
     // ---- lane constants of this wave's pixel tile
-    const int xrel0 = (C::PRIV ? 0 : pt * TSTRIDE) + r;      // ring column of conv column (tap kx = 0)
+    const int pm = C::GAP ? r - 2 * (r >> 4) : r;            // conv column of this lane inside the tile
+    const int xrel0 = (C::PRIV ? 0 : pt * TSTRIDE) + pm;     // ring column of conv column (tap kx = 0)
     int boff[3][CIN >= 16 ? CIN / 16 : 1];
     int b8_ky[CIN >= 16 ? 1 : KC], b8_off[CIN >= 16 ? 1 : KC];   // CIN == 8: per K-chunk tap row / offset
     if constexpr (CIN >= 16) {
@@ -289,11 +341,10 @@ __global__ __launch_bounds__(64 * NPT * ((COUT + 31) / 32) * KS, 1) void stage_r
             b8_off[kc] = (xrel0 + kx) * PIXB;
         }
     }
-    const int xc = x0c + pt * TSTRIDE + r;
+    const int xc = x0c + pt * TSTRIDE + pm;
     const int xo = PK ? xc / PS : xc;
-    const bool lane_out = (PK ? ((r % PS == 0) && r <= 32 - PK) : true) && xo < a.Wo && (xo - xo_blk0) < NPT * NOUT_T;
-    unsigned short* const out_lane =
-        a.out + (static_cast<int64_t>(n) * a.Ho * a.Wo + xo) * COUT + ct * 32 + 8 * hh;   // + yo*Wo*COUT + 8*k
+    const bool lane_win = C::GAP ? ((r & 1) == 0 && (r & 15) <= 12) : (PK ? r <= 32 - PK : true);   // a window starts here
+    const bool lane_out = lane_win && xo < a.Wo && (xo - xo_blk0) < NPT * NOUT_T;
     const float* const ptab_lane = ptab + ct * 32 + 4 * hh;                                // + 8*g (+ table*COUT)
     f32x4 sc1r[NG], sh1r[NG], sc2r[NG], sh2r[NG];
     if constexpr (C::PTAB_REGS) {
@@ -324,10 +375,26 @@ __global__ __launch_bounds__(64 * NPT * ((COUT + 31) / 32) * KS, 1) void stage_r
         const int gp = lane >> 2, gc = lane & 3;
         st_r0 = stage_base + gp * 64 + ((gc ^ ((gp >> 1) & 3)) << 4);
     }
-    // uniform base of the tile's output + lane-linear byte offset (saddr-form stores)
-    char* const out_tile_base = reinterpret_cast<char*>(a.out + (static_cast<int64_t>(n) * a.Ho * a.Wo + xo_t0s) * COUT);
-    const unsigned lane16 = static_cast<unsigned>(lane) * 16u;
-    const int64_t out_row_bytes = static_cast<int64_t>(a.Wo) * COUT * 2;
+    // Output stores go through a raw buffer resource over ONE output row (base = row, num_records =
+    // row bytes, voffset = lane): a lane that must not store passes an out-of-range voffset and the
+    // hardware drops it -- predication without EXEC changes or branches, so a row step stays one
+    // basic block.  soffset stays the literal 0 on purpose: with an SGPR soffset hipcc pads no wait
+    // state between a 128-bit buffer store and a VALU write of its data registers (LLVM assumes the
+    // hazard does not exist in that form); on gfx950 the next v_cndmask then corrupted the first data
+    // dword of the lanes read last (found as NaNs in 4 pixels per tile-row).
+    constexpr int OOB = 0x40000000;
+    const int out_row_bytes = a.Wo * COUT * 2;
+    const char* const out_img = reinterpret_cast<const char*>(a.out + static_cast<int64_t>(n) * a.Ho * a.Wo * COUT);
+    auto out_row_rsrc = [&](int yo) __attribute__((always_inline)) {
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(out_img) + static_cast<int64_t>(yo) * out_row_bytes, 0,
+                                                 out_row_bytes, 0x00020000);
+    };
+    const bool stores_on = !(a.dbg_flags & 1);
+    // direct stores: this lane's 16-byte chunk of pixel xo (second chunk at +32 bytes)
+    const int voff_lane = (lane_out && stores_on) ? (xo * COUT + ct * 32 + 8 * hh) * 2 : OOB;
+    // staged stores: lane-linear 16-byte chunks of the tile-row (second instruction + 1024 bytes)
+    const int voff_st0 = (stores_on && lane < 4 * nvalid) ? xo_t0s * COUT * 2 + lane * 16 : OOB;
+    const int voff_st1 = (stores_on && lane + 64 < 4 * nvalid) ? xo_t0s * COUT * 2 + lane * 16 + 1024 : OOB;
 
     // ---- residual on the matrix cores: R[cout][x_out] = Skip^T[cout][x_in] * Wx[x_in][x_out]
     // (Wx = the legacy-bilinear interpolation matrix of this tile: two non-zeros per column).
@@ -592,19 +659,35 @@ __global__ __launch_bounds__(64 * NPT * ((COUT + 31) / 32) * KS, 1) void stage_r
         for (int g = 0; g < NG; ++g) {
             float v[4], t[4], u[4], hs[4], S[4];
 #pragma unroll
+#ifdef RN_ABL_RELU
+            for (int jj = 0; jj < 4; ++jj) v[jj] = acc[4 * g + jj];
+#else
             for (int jj = 0; jj < 4; ++jj) v[jj] = relu6f(acc[4 * g + jj]);
-            if constexpr (PK == 4) {
+#endif
+            if constexpr (PK == 4 && PS == 1) {
+#ifdef RN_ABL_DPP
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) hs[jj] = v[jj], t[jj] = u[jj] = 0.f;
+#else
 #pragma unroll
                 for (int jj = 0; jj < 4; ++jj) t[jj] = v[jj] + lane_next(v[jj]);
 #pragma unroll
                 for (int jj = 0; jj < 4; ++jj) u[jj] = lane_next(t[jj]);
 #pragma unroll
                 for (int jj = 0; jj < 4; ++jj) hs[jj] = t[jj] + lane_next(u[jj]);
+#endif
             }
+#ifdef RN_ABL_VERT
+            if constexpr (true) {
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) S[jj] = (PK && PS == 1) ? hs[jj] : v[jj];
+            } else if constexpr (PS == 1) {
+#else
             if constexpr (PK == 0) {
 #pragma unroll
                 for (int jj = 0; jj < 4; ++jj) S[jj] = v[jj];
             } else if constexpr (PS == 1) {
+#endif
                 // q_j = h_{j-1} + h_j ; S_j = q_{j-2} + q_j ; q ring by parity of j
 #pragma unroll
                 for (int jj = 0; jj < 4; ++jj) {
@@ -620,22 +703,33 @@ __global__ __launch_bounds__(64 * NPT * ((COUT + 31) / 32) * KS, 1) void stage_r
                     }
                 }
             } else if constexpr ((JP & 1) == 1) {
-                // stride 2: windows start at even conv rows and end at odd rows j = 2e + 3
+                // stride 2, vertical sums first: windows start at even conv rows and end at odd rows
+                // j = 2e + 3, so only odd rows run the horizontal (DPP) half of the pool
 #pragma unroll
                 for (int jj = 0; jj < 4; ++jj) {
                     const int gi = 4 * g + jj;
-                    const float q = hprev[gi] + hs[jj];
-                    S[jj] = q0[gi] + q;
+                    const float q = hprev[gi] + v[jj];
+                    t[jj] = q0[gi] + q;
                     q0[gi] = q;
                 }
+#ifdef RN_ABL_DPP
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) S[jj] = t[jj];
+#else
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) u[jj] = t[jj] + row_next<1>(t[jj]);
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) S[jj] = u[jj] + row_next<2>(u[jj]);
+#endif
             } else {
 #pragma unroll
                 for (int jj = 0; jj < 4; ++jj) {
-                    hprev[4 * g + jj] = hs[jj];
+                    hprev[4 * g + jj] = v[jj];
                     S[jj] = 0.f;
                 }
             }
             if constexpr (emit_phase) {
+#ifndef RN_ABL_TAB
                 if constexpr (C::PTAB_LATE) {
                     // (the OFFSET is made opaque, not the pointer, so the access stays a DS read)
                     int pt_off = 8 * g;
@@ -648,12 +742,21 @@ __global__ __launch_bounds__(64 * NPT * ((COUT + 31) / 32) * KS, 1) void stage_r
                         sh2v[g] = *reinterpret_cast<const f32x4*>(pt_g + 3 * COUT);
                     }
                 }
+#endif
+#ifdef RN_ABL_TAB
+                const f32x4 sc1 = {a.rscale, a.rscale, a.rscale, a.rscale}, sh1 = sc1;
+#else
                 const f32x4 sc1 = sc1v[g], sh1 = sh1v[g];
+#endif
                 float y[4];
 #pragma unroll
                 for (int jj = 0; jj < 4; ++jj) y[jj] = fmaf(S[jj], sc1[jj], sh1[jj]);
                 if constexpr (RES) {
+#ifdef RN_ABL_TAB
+                    const f32x4 sc2 = sc1, sh2 = sc1;
+#else
                     const f32x4 sc2 = sc2v[g], sh2 = sh2v[g];
+#endif
 #pragma unroll
                     for (int jj = 0; jj < 4; ++jj) {
                         const float lo = r_lo[4 * g + jj];
@@ -680,23 +783,33 @@ __global__ __launch_bounds__(64 * NPT * ((COUT + 31) / 32) * KS, 1) void stage_r
                 // transpose through the wave's staging tile, then lane-linear 16-byte stores.
                 // LDS operations of one wave execute in order: no barrier needed.  Inline asm keeps
                 // hipcc from guarding these DS ops with vmcnt(0) against the in-flight LDS-DMA.
-                if (lane_out) {
-                    asm volatile("ds_write_b128 %0, %1\n\ts_nop 1" ::"v"(st_w0), "v"(vv[0]) : "memory");
-                    asm volatile("ds_write_b128 %0, %1\n\ts_nop 1" ::"v"(st_w0 ^ 32u), "v"(vv[1]) : "memory");
+                // (lanes without an output write a pixel slot nobody reads: no predicate needed)
+                // (leading s_nop: the data registers were just written by v_permlane32_swap, and hipcc pads
+                //  no hazards between its own instructions and the inside of an asm string)
+#ifdef RN_BIS_STW
+                if (lane_out)
+#endif
+                {
+#ifdef RN_HZ_SWAP
+                asm volatile("s_nop 7\n\tds_write_b128 %0, %1\n\ts_nop 7" ::"v"(st_w0), "v"(vv[0]) : "memory");
+                asm volatile("s_nop 7\n\tds_write_b128 %0, %1\n\ts_nop 7" ::"v"(st_w0 ^ 32u), "v"(vv[1]) : "memory");
+#else
+                asm volatile("s_nop 1\n\tds_write_b128 %0, %1\n\ts_nop 1" ::"v"(st_w0), "v"(vv[0]) : "memory");
+                asm volatile("s_nop 1\n\tds_write_b128 %0, %1\n\ts_nop 1" ::"v"(st_w0 ^ 32u), "v"(vv[1]) : "memory");
+#endif
                 }
                 i32x4 o0, o1;
                 asm volatile("ds_read_b128 %0, %1" : "=v"(o0) : "v"(st_r0) : "memory");
                 asm volatile("ds_read_b128 %0, %1 offset:1024" : "=v"(o1) : "v"(st_r0) : "memory");
                 asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(o0), "+v"(o1));
-                char* orow = out_tile_base + static_cast<int64_t>(yo) * out_row_bytes;
-                const bool st = emit && !(a.dbg_flags & 1);
-                if (st && lane < 4 * nvalid) *reinterpret_cast<i32x4*>(orow + lane16) = o0;
-                if (st && lane + 64 < 4 * nvalid) *reinterpret_cast<i32x4*>(orow + (lane16 + 1024u)) = o1;
+                const __amdgpu_buffer_rsrc_t rs = out_row_rsrc(yo);
+                __builtin_amdgcn_raw_buffer_store_b128(o0, rs, emit ? voff_st0 : OOB, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(o1, rs, emit ? voff_st1 : OOB, 0, 0);
             } else {
-                unsigned short* orow = out_lane + static_cast<int64_t>(yo) * a.Wo * COUT;
+                const __amdgpu_buffer_rsrc_t rs = out_row_rsrc(yo);
+                const int vo = emit ? voff_lane : OOB;
 #pragma unroll
-                for (int k = 0; k < NG; k += 2)
-                    if (emit && lane_out && !(a.dbg_flags & 1)) *reinterpret_cast<i32x4*>(orow + 8 * k) = vv[k / 2];
+                for (int k = 0; k < NG; k += 2) __builtin_amdgcn_raw_buffer_store_b128(vv[k / 2], rs, vo + 16 * k, 0, 0);
             }
         }
     };
@@ -718,9 +831,13 @@ __global__ __launch_bounds__(64 * NPT * ((COUT + 31) / 32) * KS, 1) void stage_r
         const unsigned long long ts0 = stamp();
 #endif
         constexpr bool MMA = decltype(MMAC)::value != 0, EPI = decltype(EPIC)::value != 0;
-        const bool have_next = MMA && (s + RW_AHEAD < nin);
         if constexpr (MMA) {
-            if (have_next) issue_row(s + RW_AHEAD, (P + RW_AHEAD) % RW_NSLOT);
+            // (past the end of the band the last row is fetched again into a free slot: the number of
+            //  DMA pieces per step stays constant, so the counted waits and the code path do too)
+#ifdef RN_BIS_NEXT
+            if (s + RW_AHEAD < nin)
+#endif
+            issue_row(min(s + RW_AHEAD, nin - 1), (P + RW_AHEAD) % RW_NSLOT);
             if constexpr (RES && (PS == 1 || (P & 1) == 0)) {
                 // pair for the epilogue of conv row s+1 (runs in step s+2): e = (s + 1 - 3) / PS
                 // (stride 2: only odd conv rows emit, so pairs are issued on even steps)
@@ -771,10 +888,14 @@ __global__ __launch_bounds__(64 * NPT * ((COUT + 31) / 32) * KS, 1) void stage_r
 #endif
         if constexpr (MMA) {
             // retire the DMA of input row s+3 (and of the skip pair the next epilogue reads)
-            if (have_next)
+#ifdef RN_BIS_NEXT
+            if (s + RW_AHEAD < nin)
                 wait_vmcnt<C::vmcnt_steady(P)>();
             else
                 wait_vmcnt<0>();
+#else
+            wait_vmcnt<C::vmcnt_steady(P)>();
+#endif
         }
 #ifdef RN_STAMPS
         const unsigned long long ts2 = stamp();
@@ -806,6 +927,7 @@ __global__ __launch_bounds__(64 * NPT * ((COUT + 31) / 32) * KS, 1) void stage_r
     [&]<int... I>(std::integer_sequence<int, I...>) {
         ((s % RW_NSLOT == I ? (step(IC<I>{}, F{}, T{}, s), 0) : 0), ...);
     }(std::make_integer_sequence<int, RW_NSLOT>{});
+    wait_vmcnt<0>();   // the clamped re-fetches of the last steps are still in flight
 #ifdef RN_STAMPS
     if (a.stamp_buf && lane == 0) {
         const int64_t w = (static_cast<int64_t>(blockIdx.y) * gridDim.x + blockIdx.x) * (NTHREADS / 64) + wave;
@@ -848,7 +970,7 @@ bool rn_rw_supported(int cin, int cout, int pool_k, int pool_s, bool res, int ou
     if (pool_k == 4 && pool_s != 1 && pool_s != 2) return false;
     const int ps = pool_k ? pool_s : 1;
     int variant = -1, npt = 0;
-    const int nout_t = tile_nout(pool_k, ps), tstride = tile_stride(pool_k, ps);
+    const int nout_t = rw_tile_nout(pool_k, ps), tstride = rw_tile_stride(pool_k, ps);
     const int tiles = (out_side + nout_t - 1) / nout_t;
     // waves per workgroup = npt x cout tiles: 8 waves (two per SIMD, <= 256 registers) where the
     // weights are small, 4 or 2 waves (one per SIMD, whole register file) for K >= 576 / residual
