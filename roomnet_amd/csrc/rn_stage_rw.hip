@@ -103,7 +103,7 @@ struct RwCfg {
 #endif
     // folded-BN tables: persistent registers where the register file has room (one wave per SIMD, or the
     // small 8-channel stage); otherwise one batched LDS read at the start of every epilogue
-    static constexpr bool PTAB_REGS = NTHREADS <= 256 || CIN == 8;
+    static constexpr bool PTAB_REGS = NTHREADS <= 256 || CIN == 8 || (CIN == 32 && COUT == 64);
     // ... except the 8-wave 32->32 variant, which sits at the 256-register cap: it reads each group's
     // table entries late (right before use) so they never pin registers across the MFMA chain
     static constexpr bool PTAB_LATE = !PTAB_REGS && CIN == 32 && COUT == 32;
@@ -496,16 +496,21 @@ __global__ __launch_bounds__(64 * NPT * ((COUT + 31) / 32) * KS, 1) void stage_r
                 bbase1[kx][cc] = bbase0[kx][cc] + static_cast<unsigned>(SLOT_SPLIT * ROWB);
             }
     }
-    auto b_read_asm = [&](auto PC, auto KCC) __attribute__((always_inline)) -> i32x4 {
+    // `dep` is a scheduling tie only (the instruction does not read it): naming the accumulator of the
+    // MFMA BAHEAD chunks back as an input keeps hipcc from hoisting every read of the row to the top
+    // of the step, which made all KC fragments live at once (72-144 VGPRs, spilled to AGPRs).
+    auto b_read_asm = [&](auto PC, auto KCC, float dep) __attribute__((always_inline)) -> i32x4 {
         constexpr int P = decltype(PC)::value, kc = decltype(KCC)::value;   // kc: global K-chunk
         constexpr int tap = kc / (CIN / 16), cc = kc % (CIN / 16);
         constexpr int ky = tap / 3, kx = tap % 3;
         constexpr int slot = (P + ky) % RW_NSLOT;
         i32x4 v;
         if constexpr (slot < SLOT_SPLIT)
-            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(bbase0[kx][cc]), "n"(slot * ROWB));
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(bbase0[kx][cc]), "n"(slot * ROWB), "v"(dep));
         else
-            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(bbase1[kx][cc]), "n"((slot - SLOT_SPLIT) * ROWB));
+            asm volatile("ds_read_b128 %0, %1 offset:%2"
+                         : "=v"(v)
+                         : "v"(bbase1[kx][cc]), "n"((slot - SLOT_SPLIT) * ROWB), "v"(dep));
         return v;
     };
     // MFMA chain of one conv row over the K-chunks [KB, KB + KCW) (KB = 0 unless K is split)
@@ -515,11 +520,12 @@ __global__ __launch_bounds__(64 * NPT * ((COUT + 31) / 32) * KS, 1) void stage_r
         i32x4 bq[KCW];
         if constexpr (CIN >= 16) {
             [&]<int... I>(std::integer_sequence<int, I...>) {
-                ((bq[I] = b_read_asm(PC, IC<KB + I>{})), ...);
+                ((bq[I] = b_read_asm(PC, IC<KB + I>{}, 0.f)), ...);
             }(std::make_integer_sequence<int, BAHEAD>{});
             [&]<int... I>(std::integer_sequence<int, I...>) {
                 (([&] {
-                     if constexpr (I + BAHEAD < KCW) bq[I + BAHEAD] = b_read_asm(PC, IC<KB + (I + BAHEAD < KCW ? I + BAHEAD : 0)>{});
+                     if constexpr (I + BAHEAD < KCW)
+                         bq[I + BAHEAD] = b_read_asm(PC, IC<KB + (I + BAHEAD < KCW ? I + BAHEAD : 0)>{}, I == 0 ? 0.f : acc[0]);
                      constexpr int newer = (KCW - 1 - I) < BAHEAD ? (KCW - 1 - I) : BAHEAD;   // my reads issued after chunk I
                      asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(bq[I]) : "n"(newer));
                      acc = mfma32<DT>(wreg[I], bq[I], I == 0 ? zero : acc);
