@@ -24,6 +24,7 @@
 #include "rn_stage.h"
 
 #include <algorithm>
+#include <cstdlib>
 #include <type_traits>
 #include <utility>
 
@@ -59,7 +60,17 @@ struct RwCfg {
     static constexpr int CP = CIN / 8;
     static constexpr int KC = (9 * CIN + 15) / 16;
     static constexpr int CT = (COUT + 31) / 32;
-    static constexpr int NG = COUT >= 32 ? 4 : COUT / 8;   // 4-channel groups per lane half-row
+    // KS = 2 ("pair"): two waves share one (pixel tile, 32-channel cout tile).  Each takes half of the
+    // input channels of every tap (so both run the same code on different lane constants), they swap
+    // half of their partial accumulators through LDS and each finishes 16 of the 32 channels: half
+    // the weights, half the epilogue and half the pooling state per wave -- the variant fits two waves
+    // per SIMD, which overlap each other's MFMA, VALU and wait time.  The rows of the weight
+    // fragments are rotated by 16 for the second wave, so "my" channels are accumulator registers
+    // 0..7 and the partner's 8..15 in both.
+    static constexpr bool PAIR = KS == 2;
+    static constexpr int NG = COUT >= 32 ? (PAIR ? 2 : 4) : COUT / 8;   // 4-channel groups per lane half-row this wave finishes
+    static constexpr int CPT = CIN >= 16 ? CIN / 16 : 1;                // K-chunks per tap
+    static constexpr int CPTL = PAIR ? CPT / 2 : CPT;                   // ... that this wave multiplies
     static constexpr int CPO = COUT / 8;                       // 16-byte chunks per output/skip pixel
     static constexpr int TSTRIDE = rw_tile_stride(PK, PS);
     static constexpr int NOUT_T = rw_tile_nout(PK, PS);
@@ -84,7 +95,7 @@ struct RwCfg {
     static constexpr int LPT = (RINGCOLS * CP + LOADERS - 1) / LOADERS;     // DMA pieces per wave per row
     // shared ring: row stride padded to whole pieces; private ring: exact (the last piece is lane-masked)
     static constexpr int ROWB = PRIV ? RINGCOLS * CIN * 2 : LPT * NTHREADS * 16;
-    static constexpr int SKIPCOLS_MAX = RINGCOLS + 8;          // residual scale <= ~1.1 (checked on the host)
+    static constexpr int SKIPCOLS_MAX = RINGCOLS + 8;          // residual scale <= ~1.07 (checked on the host)
     static constexpr int SLPT = RES ? (2 * SKIPCOLS_MAX * CPO + NTHREADS - 1) / NTHREADS : 0;
     static constexpr int SKIPBUFB = SLPT * NTHREADS * 16;      // one staged pair of skip rows (padded)
     static constexpr int PTAB_BYTES = 4 * COUT * 4;
@@ -103,7 +114,7 @@ struct RwCfg {
 #endif
     // folded-BN tables: persistent registers where the register file has room (one wave per SIMD, or the
     // small 8-channel stage); otherwise one batched LDS read at the start of every epilogue
-    static constexpr bool PTAB_REGS = NTHREADS <= 256 || CIN == 8 || (CIN == 32 && COUT == 64);
+    static constexpr bool PTAB_REGS = NTHREADS <= 256 || CIN == 8 || (CIN == 32 && COUT == 64) || PAIR;
     // ... except the 8-wave 32->32 variant, which sits at the 256-register cap: it reads each group's
     // table entries late (right before use) so they never pin registers across the MFMA chain
     static constexpr bool PTAB_LATE = !PTAB_REGS && CIN == 32 && COUT == 32;
@@ -111,7 +122,9 @@ struct RwCfg {
     static constexpr int STAGE_OFF = SKIP_OFF + (RES ? RW_SKIPBUF * SKIPBUFB : 0);
     static constexpr int PART_OFF = STAGE_OFF + (STAGE_OUT ? NPT * CT * STAGE_WAVE_B : 0);
     static constexpr int PART_B = 16 * 64 * 4;                 // one wave's partial accumulator tile
-    static constexpr int LDS_BYTES = PART_OFF + (KS > 1 ? 2 * NPT * CT * (KS - 1) * PART_B : 0);
+    static constexpr int PART_PAIR_B = 8 * 64 * 4;             // pair: the 8 accumulator registers handed to the partner
+    static constexpr int LDS_BYTES =
+        PART_OFF + (PAIR ? 2 * NPT * CT * 2 * PART_PAIR_B : (KS > 1 ? 2 * NPT * CT * (KS - 1) * PART_B : 0));
     // steady-state counted wait at the end of step s: everything up to input row s+3 and the
     // skip pair used by step s+1 has landed; what may stay in flight is what the wave issued
     // after them (the pieces of this step, plus one more row of input when there is no skip)
@@ -126,7 +139,8 @@ struct RwCfg {
     static_assert(COUT % 32 == 0 || COUT == 16, "cout must be whole 32-channel tiles (or one half tile)");
     static_assert(PK == 0 || PK == 4, "pool window 4 or none");
     static_assert(KCW * 4 <= 80 || NTHREADS <= 256 || KS > 1, "weights need the whole register file: <= 1 wave per SIMD");
-    static_assert(KS == 1 || (KS == 3 && CIN >= 16 && KC % 3 == 0 && !RES), "K split = one kernel row per wave");
+    static_assert(KS == 1 || (KS == 3 && CIN >= 16 && KC % 3 == 0 && !RES) || (KS == 2 && CIN >= 32 && COUT % 32 == 0),
+                  "K split = one kernel row per wave, or a channel-half pair");
     static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
     static_assert(NSLOT % 2 == 0, "pool-ring parity is tied to the unroll");
     static_assert(!PRIV || (LPT - 1) * 64 < RINGCOLS * CP, "every DMA piece must have at least one active lane");
@@ -159,13 +173,7 @@ __device__ __forceinline__ void dma16_masked(const void* gsrc, char* lds, unsign
     asm volatile(
         "s_mov_b32 m0, %1\n\t"
         "s_mov_b64 exec, %2\n\t"
-#ifdef RN_HZ_EXEC
-        "s_nop 7\n\t"
-#endif
         "global_load_lds_dwordx4 %0, off\n\t"
-#ifdef RN_HZ_EXEC
-        "s_nop 7\n\t"
-#endif
         "s_mov_b64 exec, -1"
         :
         : "v"(gsrc), "s"(lds_addr), "s"(mask)
@@ -230,9 +238,23 @@ __global__ __launch_bounds__(64 * NPT * ((COUT + 31) / 32) * KS, 1) void stage_r
     for (int i = tid; i < 4 * COUT; i += NTHREADS) ptab[i] = a.ptab[i];
 
     // ---- this wave's weight fragments -> registers (lane-linear, coalesced)
+    // One wave per SIMD (<= 256 threads) owns a 512-entry register file, but only half of it is
+    // VGPRs: values only MFMAs consume (the weight fragments, the residual's interpolation weights)
+    // are pinned to the AGPR half -- an empty asm with "a" constraints gives the value that register
+    // class, the loads then target AGPRs directly and v_mfma reads them as srcA/srcB in place.
+    // (Left to itself hipcc keeps them in VGPRs, runs out, and bounces other values through AGPRs
+    //  with v_accvgpr_read/write: 55-80 extra VALU instructions per row in the residual variants.)
+#ifdef RN_NO_WAGPR
+    constexpr bool W_AGPR = false;
+#else
+    constexpr bool W_AGPR = NTHREADS <= 256;
+#endif
     i32x4 wreg[KCW];
 #pragma unroll
-    for (int kc = 0; kc < KCW; ++kc) wreg[kc] = a.wfrag[((ks * KCW + kc) * CT + ct) * 64 + lane];
+    for (int kc = 0; kc < KCW; ++kc) {
+        wreg[kc] = a.wfrag[((ks * KCW + kc) * CT + ct) * 64 + lane];
+        if constexpr (W_AGPR) asm volatile("" : "+a"(wreg[kc]));
+    }
 
     // ---- input-row DMA: piece i of a row covers ring chunks [i*NTHREADS, (i+1)*NTHREADS); this
     // lane fills chunk q = tid + i*NTHREADS = (pixel p, slot c') and therefore fetches source
@@ -264,11 +286,7 @@ __global__ __launch_bounds__(64 * NPT * ((COUT + 31) / 32) * KS, 1) void stage_r
                 if constexpr ((i + 1) * 64 <= RINGCOLS * CP)
                     dma16(row + ld_goff[i], ring + slot * ROWB + i * 64 * 16);
                 else {
-#ifdef RN_BIS_DMA
-                    if (lane < TAIL_LANES) dma16(row + ld_goff[i], ring + slot * ROWB + i * 64 * 16);
-#else
                     dma16_masked(row + ld_goff[i], ring + slot * ROWB + i * 64 * 16, tail_mask);
-#endif
                 }
             } else {
                 dma16(row + ld_goff[i], ring + slot * ROWB + i * NTHREADS * 16 + piece_base);
@@ -323,14 +341,16 @@ __global__ __launch_bounds__(64 * NPT * ((COUT + 31) / 32) * KS, 1) void stage_r
     // ---- lane constants of this wave's pixel tile
     const int pm = C::GAP ? r - 2 * (r >> 4) : r;            // conv column of this lane inside the tile
     const int xrel0 = (C::PRIV ? 0 : pt * TSTRIDE) + pm;     // ring column of conv column (tap kx = 0)
-    int boff[3][CIN >= 16 ? CIN / 16 : 1];
+    int boff[3][C::CPTL];
     int b8_ky[CIN >= 16 ? 1 : KC], b8_off[CIN >= 16 ? 1 : KC];   // CIN == 8: per K-chunk tap row / offset
     if constexpr (CIN >= 16) {
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx)
 #pragma unroll
-            for (int cc = 0; cc < CIN / 16; ++cc)
-                boff[kx][cc] = (xrel0 + kx) * PIXB + (((cc * 2 + hh) ^ chunk_swz<CP>(xrel0 + kx)) << 4);
+            for (int cc = 0; cc < C::CPTL; ++cc) {
+                const int ccg = C::PAIR ? ks * C::CPTL + cc : cc;      // pair: this wave's half of the tap's channels
+                boff[kx][cc] = (xrel0 + kx) * PIXB + (((ccg * 2 + hh) ^ chunk_swz<CP>(xrel0 + kx)) << 4);
+            }
     } else {
 #pragma unroll
         for (int kc = 0; kc < KC; ++kc) {
@@ -345,12 +365,13 @@ __global__ __launch_bounds__(64 * NPT * ((COUT + 31) / 32) * KS, 1) void stage_r
     const int xo = PK ? xc / PS : xc;
     const bool lane_win = C::GAP ? ((r & 1) == 0 && (r & 15) <= 12) : (PK ? r <= 32 - PK : true);   // a window starts here
     const bool lane_out = lane_win && xo < a.Wo && (xo - xo_blk0) < NPT * NOUT_T;
-    const float* const ptab_lane = ptab + ct * 32 + 4 * hh;                                // + 8*g (+ table*COUT)
+    const int cbase = ct * 32 + (C::PAIR ? 16 * ks : 0);    // first channel this wave finishes
+    const float* const ptab_lane = ptab + cbase + 4 * hh;                                  // + 8*g (+ table*COUT)
     f32x4 sc1r[NG], sh1r[NG], sc2r[NG], sh2r[NG];
     if constexpr (C::PTAB_REGS) {
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
-            const float* gp = a.ptab + ct * 32 + 4 * hh + 8 * g;
+            const float* gp = a.ptab + cbase + 4 * hh + 8 * g;
             sc1r[g] = *reinterpret_cast<const f32x4*>(gp);
             sh1r[g] = *reinterpret_cast<const f32x4*>(gp + COUT);
             if constexpr (RES) {
@@ -391,7 +412,7 @@ __global__ __launch_bounds__(64 * NPT * ((COUT + 31) / 32) * KS, 1) void stage_r
     };
     const bool stores_on = !(a.dbg_flags & 1);
     // direct stores: this lane's 16-byte chunk of pixel xo (second chunk at +32 bytes)
-    const int voff_lane = (lane_out && stores_on) ? (xo * COUT + ct * 32 + 8 * hh) * 2 : OOB;
+    const int voff_lane = (lane_out && stores_on) ? (xo * COUT + cbase + 8 * hh) * 2 : OOB;
     // staged stores: lane-linear 16-byte chunks of the tile-row (second instruction + 1024 bytes)
     const int voff_st0 = (stores_on && lane < 4 * nvalid) ? xo_t0s * COUT * 2 + lane * 16 : OOB;
     const int voff_st1 = (stores_on && lane + 64 < 4 * nvalid) ? xo_t0s * COUT * 2 + lane * 16 + 1024 : OOB;
@@ -427,6 +448,10 @@ __global__ __launch_bounds__(64 * NPT * ((COUT + 31) / 32) * KS, 1) void stage_r
                 bw_h[c][d] = static_cast<int>(static_cast<unsigned>(wh[2 * d]) | (static_cast<unsigned>(wh[2 * d + 1]) << 16));
                 bw_l[c][d] = static_cast<int>(static_cast<unsigned>(wl[2 * d]) | (static_cast<unsigned>(wl[2 * d + 1]) << 16));
             }
+            if constexpr (W_AGPR) {
+                asm volatile("" : "+a"(bw_h[c]));
+                asm volatile("" : "+a"(bw_l[c]));
+            }
         }
         // transposed read: lane 4q+p of a 16-lane group addresses row q, columns 4p..4p+3 of a
         // 4-row x 16-column block and receives column (lane & 15) of the 4 rows
@@ -436,7 +461,8 @@ __global__ __launch_bounds__(64 * NPT * ((COUT + 31) / 32) * KS, 1) void stage_r
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 const int pix = min(max(xs_t + 16 * c + 8 * (grp >> 1) + 4 * t + q, 0), a.skipcols - 1);
-                const int ch = ct * 4 + 2 * (grp & 1) + (pp >> 1);
+                // (pair: the second wave's MFMA rows are rotated by 16 channels = two 16-byte chunks)
+                const int ch = ct * 4 + ((2 * (grp & 1) + (pp >> 1) + (C::PAIR ? 2 * ks : 0)) & 3);
                 a_off[2 * c + t] = (pix * CPO + (ch ^ chunk_swz<CPO>(pix))) * 16 + (pp & 1) * 8;
             }
     }
@@ -469,7 +495,7 @@ __global__ __launch_bounds__(64 * NPT * ((COUT + 31) / 32) * KS, 1) void stage_r
     auto b_frag = [&](auto PC, auto KCC) __attribute__((always_inline)) -> i32x4 {
         constexpr int P = decltype(PC)::value, kc = decltype(KCC)::value;
         if constexpr (CIN >= 16) {
-            constexpr int tap = kc / (CIN / 16), cc = kc % (CIN / 16);
+            constexpr int tap = kc / C::CPTL, cc = kc % C::CPTL;
             constexpr int ky = tap / 3, kx = tap % 3;
             return *reinterpret_cast<const i32x4*>(ring + ((P + ky) % RW_NSLOT) * ROWB + boff[kx][cc]);
         } else {
@@ -485,13 +511,13 @@ __global__ __launch_bounds__(64 * NPT * ((COUT + 31) / 32) * KS, 1) void stage_r
     // the count conservative).  Ring offsets beyond the 16-bit DS immediate use a second base.
     constexpr int BAHEAD = KC >= 6 ? 4 : 1;
     constexpr int SLOT_SPLIT = 65535 / ROWB >= RW_NSLOT ? RW_NSLOT : 65535 / ROWB;   // slots reachable from base 0
-    unsigned bbase0[3][CIN >= 16 ? CIN / 16 : 1], bbase1[3][CIN >= 16 ? CIN / 16 : 1];
+    unsigned bbase0[3][C::CPTL], bbase1[3][C::CPTL];
     if constexpr (CIN >= 16) {
         const unsigned ring_lds = static_cast<unsigned>(reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) char*)ring));
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx)
 #pragma unroll
-            for (int cc = 0; cc < CIN / 16; ++cc) {
+            for (int cc = 0; cc < C::CPTL; ++cc) {
                 bbase0[kx][cc] = ring_lds + static_cast<unsigned>(boff[kx][cc]);
                 bbase1[kx][cc] = bbase0[kx][cc] + static_cast<unsigned>(SLOT_SPLIT * ROWB);
             }
@@ -500,8 +526,8 @@ __global__ __launch_bounds__(64 * NPT * ((COUT + 31) / 32) * KS, 1) void stage_r
     // MFMA BAHEAD chunks back as an input keeps hipcc from hoisting every read of the row to the top
     // of the step, which made all KC fragments live at once (72-144 VGPRs, spilled to AGPRs).
     auto b_read_asm = [&](auto PC, auto KCC, float dep) __attribute__((always_inline)) -> i32x4 {
-        constexpr int P = decltype(PC)::value, kc = decltype(KCC)::value;   // kc: global K-chunk
-        constexpr int tap = kc / (CIN / 16), cc = kc % (CIN / 16);
+        constexpr int P = decltype(PC)::value, kc = decltype(KCC)::value;   // kc: K-chunk (pair: of this wave's half)
+        constexpr int tap = kc / C::CPTL, cc = kc % C::CPTL;
         constexpr int ky = tap / 3, kx = tap % 3;
         constexpr int slot = (P + ky) % RW_NSLOT;
         i32x4 v;
@@ -514,7 +540,10 @@ __global__ __launch_bounds__(64 * NPT * ((COUT + 31) / 32) * KS, 1) void stage_r
         return v;
     };
     // MFMA chain of one conv row over the K-chunks [KB, KB + KCW) (KB = 0 unless K is split)
-    auto mma_chain = [&](auto PC, auto KBC, f32x16& acc) __attribute__((always_inline)) {
+    // `hook` runs once, right behind the wait of the first fragment: LDS returns in order, so every
+    // asm LDS read issued BEFORE the chain (the residual's transposed reads, the pair exchange) has
+    // landed there too -- they get retired for free instead of by an lgkmcnt(0) stall of their own.
+    auto mma_chain = [&](auto PC, auto KBC, f32x16& acc, auto&& hook) __attribute__((always_inline)) {
         constexpr int KB = decltype(KBC)::value;
         const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         i32x4 bq[KCW];
@@ -528,11 +557,13 @@ __global__ __launch_bounds__(64 * NPT * ((COUT + 31) / 32) * KS, 1) void stage_r
                          bq[I + BAHEAD] = b_read_asm(PC, IC<KB + (I + BAHEAD < KCW ? I + BAHEAD : 0)>{}, I == 0 ? 0.f : acc[0]);
                      constexpr int newer = (KCW - 1 - I) < BAHEAD ? (KCW - 1 - I) : BAHEAD;   // my reads issued after chunk I
                      asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(bq[I]) : "n"(newer));
+                     if constexpr (I == 0) hook();
                      acc = mfma32<DT>(wreg[I], bq[I], I == 0 ? zero : acc);
                  }()),
                  ...);
             }(std::make_integer_sequence<int, KCW>{});
         } else {
+            hook();
             bq[0] = b_frag(PC, IC<0>{});
             [&]<int... I>(std::integer_sequence<int, I...>) {
                 ((bq[I + 1 < KC ? I + 1 : 0] = (I + 1 < KC ? b_frag(PC, IC<(I + 1 < KC ? I + 1 : 0)>{}) : bq[0]),
@@ -541,17 +572,17 @@ __global__ __launch_bounds__(64 * NPT * ((COUT + 31) / 32) * KS, 1) void stage_r
             }(std::make_integer_sequence<int, KC>{});
         }
     };
-    auto mma_row = [&](auto PC, f32x16& acc) __attribute__((always_inline)) {
-        if constexpr (KS == 1) {
-            mma_chain(PC, IC<0>{}, acc);
+    auto mma_row = [&](auto PC, f32x16& acc, auto&& hook) __attribute__((always_inline)) {
+        if constexpr (KS == 1 || C::PAIR) {
+            mma_chain(PC, IC<0>{}, acc, hook);
         } else {
             // wave-uniform dispatch on the kernel row: ring slot and tap offsets stay compile-time
             if (ks == 0)
-                mma_chain(PC, IC<0>{}, acc);
+                mma_chain(PC, IC<0>{}, acc, hook);
             else if (ks == 1)
-                mma_chain(PC, IC<KCW>{}, acc);
+                mma_chain(PC, IC<KCW>{}, acc, hook);
             else
-                mma_chain(PC, IC<2 * KCW>{}, acc);
+                mma_chain(PC, IC<2 * KCW>{}, acc, hook);
         }
     };
     // K split: LDS exchange of partial accumulators, double-buffered by step parity
@@ -601,10 +632,56 @@ __global__ __launch_bounds__(64 * NPT * ((COUT + 31) / 32) * KS, 1) void stage_r
         }
     };
 
+    // pair exchange: each wave hands accumulator registers 8..15 (the partner's channels) over and
+    // receives the partner's partial sums of its own 16 channels
+    auto pair_addr = [&](int parity, int writer) __attribute__((always_inline)) -> unsigned {
+        return part_lds + static_cast<unsigned>(((parity * NPT * CT + (ct * NPT + pt)) * 2 + writer) * C::PART_PAIR_B);
+    };
+    auto pair_write = [&](int parity, const f32x16& acc_in) __attribute__((always_inline)) {
+        const unsigned ad = pair_addr(parity, ks);
+        f32x16 acc = acc_in;
+        asm volatile("s_nop 15" : "+v"(acc));    // 8-pass MFMA result -> DS data read: 12 states, not padded around asm
+        const i32x4 v2 = {__float_as_int(acc[8]), __float_as_int(acc[9]), __float_as_int(acc[10]), __float_as_int(acc[11])};
+        const i32x4 v3 = {__float_as_int(acc[12]), __float_as_int(acc[13]), __float_as_int(acc[14]), __float_as_int(acc[15])};
+        asm volatile("ds_write_b128 %0, %1\n\ts_nop 1" ::"v"(ad), "v"(v2) : "memory");
+        asm volatile("ds_write_b128 %0, %1 offset:1024\n\ts_nop 1" ::"v"(ad), "v"(v3) : "memory");
+    };
+    auto pair_read_issue = [&](int parity, i32x4& v0, i32x4& v1) __attribute__((always_inline)) {
+        const unsigned ad = pair_addr(parity, 1 - ks);
+        asm volatile("ds_read_b128 %0, %1" : "=v"(v0) : "v"(ad) : "memory");
+        asm volatile("ds_read_b128 %0, %1 offset:1024" : "=v"(v1) : "v"(ad) : "memory");
+    };
+    // residual, part 1 (issued ahead of the MFMA chain): transposed reads of the staged skip pair
+    using TQ = i32x2[8];
+    auto res_issue = [&](int skip_buf, TQ& t) __attribute__((always_inline)) {
+        const char* sk0 = skipb + skip_buf * C::SKIPBUFB;
+        const char* sk1 = sk0 + skipbytes;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            t[q] = tr_read(sk0 + a_off[q]);
+            t[4 + q] = tr_read(sk1 + a_off[q]);
+        }
+    };
+    // residual, part 2: R_lo / R_hi = Skip_lo/hi^T * Wx on the matrix cores (ordinary MFMA builtins: hipcc
+    // interleaves them with the conv chain)
+    auto res_mfma = [&](const TQ& t, f32x16& r_lo, f32x16& r_hi) __attribute__((always_inline)) {
+        const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        const i32x4 al0 = {t[0][0], t[0][1], t[1][0], t[1][1]}, al1 = {t[2][0], t[2][1], t[3][0], t[3][1]};
+        const i32x4 ah0 = {t[4][0], t[4][1], t[5][0], t[5][1]}, ah1 = {t[6][0], t[6][1], t[7][0], t[7][1]};
+        r_lo = mfma32<DT>(al0, bw_h[0], zero);
+        r_hi = mfma32<DT>(ah0, bw_h[0], zero);
+        r_lo = mfma32<DT>(al0, bw_l[0], r_lo);
+        r_hi = mfma32<DT>(ah0, bw_l[0], r_hi);
+        r_lo = mfma32<DT>(al1, bw_h[1], r_lo);
+        r_hi = mfma32<DT>(ah1, bw_h[1], r_hi);
+        r_lo = mfma32<DT>(al1, bw_l[1], r_lo);
+        r_hi = mfma32<DT>(ah1, bw_l[1], r_hi);
+    };
+
     // epilogue of conv row j (local index); JP = j mod RW_NSLOT (only its parity matters).
     // Works on one group of 4 consecutive channels at a time (4 independent DPP chains in
     // lockstep: short live ranges, and the VALU-write -> DPP-read hazard is covered).
-    auto epi_row = [&](auto JPC, const f32x16& acc, int j, int skip_buf) __attribute__((always_inline)) {
+    auto epi_row = [&](auto JPC, const f32x16& acc, int j, const f32x16& r_lo, const f32x16& r_hi) __attribute__((always_inline)) {
         constexpr int JP = decltype(JPC)::value;
         constexpr bool emit_phase = PK == 0 || PS == 1 || (JP & 1) == 1;
         const bool emit = PK ? j >= 3 : true;
@@ -614,28 +691,6 @@ __global__ __launch_bounds__(64 * NPT * ((COUT + 31) / 32) * KS, 1) void stage_r
         if constexpr (RES) {
             const float src = static_cast<float>(yo) * a.rscale;
             yl = src - static_cast<float>(static_cast<int>(src));
-        }
-        const char* sk0 = skipb + skip_buf * C::SKIPBUFB;
-        const char* sk1 = sk0 + skipbytes;
-        f32x16 r_lo, r_hi;
-        if constexpr (RES && emit_phase) {
-            const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            i32x2 t0 = tr_read(sk0 + a_off[0]), t1 = tr_read(sk0 + a_off[1]);
-            i32x2 t2 = tr_read(sk0 + a_off[2]), t3 = tr_read(sk0 + a_off[3]);
-            i32x2 t4 = tr_read(sk1 + a_off[0]), t5 = tr_read(sk1 + a_off[1]);
-            i32x2 t6 = tr_read(sk1 + a_off[2]), t7 = tr_read(sk1 + a_off[3]);
-            asm volatile("s_waitcnt lgkmcnt(0)"
-                         : "+v"(t0), "+v"(t1), "+v"(t2), "+v"(t3), "+v"(t4), "+v"(t5), "+v"(t6), "+v"(t7));
-            const i32x4 al0 = {t0[0], t0[1], t1[0], t1[1]}, al1 = {t2[0], t2[1], t3[0], t3[1]};
-            const i32x4 ah0 = {t4[0], t4[1], t5[0], t5[1]}, ah1 = {t6[0], t6[1], t7[0], t7[1]};
-            r_lo = mfma32<DT>(al0, bw_h[0], zero);
-            r_hi = mfma32<DT>(ah0, bw_h[0], zero);
-            r_lo = mfma32<DT>(al0, bw_l[0], r_lo);
-            r_hi = mfma32<DT>(ah0, bw_l[0], r_hi);
-            r_lo = mfma32<DT>(al1, bw_h[1], r_lo);
-            r_hi = mfma32<DT>(ah1, bw_h[1], r_hi);
-            r_lo = mfma32<DT>(al1, bw_l[1], r_lo);
-            r_hi = mfma32<DT>(ah1, bw_l[1], r_hi);
         }
         f32x4 sc1v[NG], sh1v[NG], sc2v[NG], sh2v[NG];
         if constexpr (emit_phase) {
@@ -792,17 +847,9 @@ __global__ __launch_bounds__(64 * NPT * ((COUT + 31) / 32) * KS, 1) void stage_r
                 // (lanes without an output write a pixel slot nobody reads: no predicate needed)
                 // (leading s_nop: the data registers were just written by v_permlane32_swap, and hipcc pads
                 //  no hazards between its own instructions and the inside of an asm string)
-#ifdef RN_BIS_STW
-                if (lane_out)
-#endif
                 {
-#ifdef RN_HZ_SWAP
-                asm volatile("s_nop 7\n\tds_write_b128 %0, %1\n\ts_nop 7" ::"v"(st_w0), "v"(vv[0]) : "memory");
-                asm volatile("s_nop 7\n\tds_write_b128 %0, %1\n\ts_nop 7" ::"v"(st_w0 ^ 32u), "v"(vv[1]) : "memory");
-#else
                 asm volatile("s_nop 1\n\tds_write_b128 %0, %1\n\ts_nop 1" ::"v"(st_w0), "v"(vv[0]) : "memory");
                 asm volatile("s_nop 1\n\tds_write_b128 %0, %1\n\ts_nop 1" ::"v"(st_w0 ^ 32u), "v"(vv[1]) : "memory");
-#endif
                 }
                 i32x4 o0, o1;
                 asm volatile("ds_read_b128 %0, %1" : "=v"(o0) : "v"(st_r0) : "memory");
@@ -837,12 +884,26 @@ __global__ __launch_bounds__(64 * NPT * ((COUT + 31) / 32) * KS, 1) void stage_r
         const unsigned long long ts0 = stamp();
 #endif
         constexpr bool MMA = decltype(MMAC)::value != 0, EPI = decltype(EPIC)::value != 0;
+        constexpr int JP = (P + RW_NSLOT - 1) % RW_NSLOT;                     // phase of conv row s-1 (the epilogue's row)
+        constexpr bool emit_phase = PK == 0 || PS == 1 || (JP & 1) == 1;
+        constexpr bool RESW = RES && EPI && emit_phase;                        // this step adds a residual row
+        constexpr bool PAIRR = C::PAIR && EPI;                                 // this step finishes a pair-split row
+        f32x16& acc_new = (P & 1) == 0 ? acc0 : acc1;
+        f32x16& acc_old = (P & 1) == 0 ? acc1 : acc0;
+        // ---- LDS reads the epilogue of row s-1 needs, issued ahead of the chain (retired by its first wait)
+        TQ tq;
+        i32x4 rv0, rv1;
+        f32x16 r_lo, r_hi;
+        if constexpr (PAIRR) pair_read_issue((P + 1) & 1, rv0, rv1);
+        if constexpr (RESW) res_issue(sbuf_read, tq);
+        auto retire = [&]() __attribute__((always_inline)) {
+            if constexpr (PAIRR) asm volatile("" : "+v"(rv0), "+v"(rv1));
+            if constexpr (RESW)
+                asm volatile("" : "+v"(tq[0]), "+v"(tq[1]), "+v"(tq[2]), "+v"(tq[3]), "+v"(tq[4]), "+v"(tq[5]), "+v"(tq[6]), "+v"(tq[7]));
+        };
         if constexpr (MMA) {
             // (past the end of the band the last row is fetched again into a free slot: the number of
             //  DMA pieces per step stays constant, so the counted waits and the code path do too)
-#ifdef RN_BIS_NEXT
-            if (s + RW_AHEAD < nin)
-#endif
             issue_row(min(s + RW_AHEAD, nin - 1), (P + RW_AHEAD) % RW_NSLOT);
             if constexpr (RES && (PS == 1 || (P & 1) == 0)) {
                 // pair for the epilogue of conv row s+1 (runs in step s+2): e = (s + 1 - 3) / PS
@@ -854,37 +915,41 @@ __global__ __launch_bounds__(64 * NPT * ((COUT + 31) / 32) * KS, 1) void stage_r
 #if defined(RN_STAMPS) && defined(RN_STAMP_CHAIN)
             const unsigned long long tc0 = stamp();
 #endif
-            if constexpr ((P & 1) == 0)
-                mma_row(PC, acc0);
-            else
-                mma_row(PC, acc1);
+            mma_row(PC, acc_new, retire);
 #if defined(RN_STAMPS) && defined(RN_STAMP_CHAIN)
             st_chain += stamp() - tc0;
 #endif
-            if constexpr (KS > 1) {
+            if constexpr (C::PAIR) {
+                pair_write(P & 1, acc_new);
+            } else if constexpr (KS > 1) {
                 // waves of kernel rows 1, 2 publish their partial sums for the epilogue of the next step
-                if (ks > 0) part_write(P & 1, (P & 1) == 0 ? acc0 : acc1);
+                if (ks > 0) part_write(P & 1, acc_new);
             }
+        } else if constexpr (PAIRR || RESW) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // drain step: no chain to retire them
+            retire();
         }
         if constexpr (EPI) {
-            if (KS == 1 || ks == 0) {        // K split: only the wave of kernel row 0 owns the epilogue
-                if constexpr ((P & 1) == 0) {
-                    if constexpr (KS > 1) part_add((P + 1) & 1, acc1);
-                    epi_row(IC<(P + RW_NSLOT - 1) % RW_NSLOT>{}, acc1, s - 1, sbuf_read);
-                } else {
-                    if constexpr (KS > 1) part_add((P + 1) & 1, acc0);
-                    epi_row(IC<(P + RW_NSLOT - 1) % RW_NSLOT>{}, acc0, s - 1, sbuf_read);
+            if constexpr (RESW) res_mfma(tq, r_lo, r_hi);
+            if constexpr (PAIRR) {
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    acc_old[jj] += __int_as_float(rv0[jj]);
+                    acc_old[4 + jj] += __int_as_float(rv1[jj]);
                 }
             }
+            if (KS == 1 || C::PAIR || ks == 0) {        // 3-way K split: only the wave of kernel row 0 owns the epilogue
+                if constexpr (KS == 3) part_add((P + 1) & 1, acc_old);
+                epi_row(IC<JP>{}, acc_old, s - 1, r_lo, r_hi);
+            }
         }
-        // the epilogue of this step handled conv row s-1 (phase parity (P+1)&1): rotate after an emit phase
-        if constexpr (RES && EPI && (PS == 1 || ((P + 1) & 1) == 1))
-            sbuf_read = sbuf_read == RW_SKIPBUF - 1 ? 0 : sbuf_read + 1;
+        // the epilogue of this step handled conv row s-1: rotate the skip buffers after an emit phase
+        if constexpr (RESW) sbuf_read = sbuf_read == RW_SKIPBUF - 1 ? 0 : sbuf_read + 1;
         if constexpr (MMA && EPI) {
             // software pipeline: spread the VALU epilogue of row s-1 through the MFMA chain of row s
             constexpr int VPG = RES ? 10 : 8;
 #pragma unroll
-            for (int i = 0; i < KC; ++i) {
+            for (int i = 0; i < KCW + (RESW ? 8 : 0); ++i) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     // one MFMA
                 __builtin_amdgcn_sched_group_barrier(0x002, VPG, 0);   // VALU
             }
@@ -894,15 +959,10 @@ __global__ __launch_bounds__(64 * NPT * ((COUT + 31) / 32) * KS, 1) void stage_r
 #endif
         if constexpr (MMA) {
             // retire the DMA of input row s+3 (and of the skip pair the next epilogue reads)
-#ifdef RN_BIS_NEXT
-            if (s + RW_AHEAD < nin)
-                wait_vmcnt<C::vmcnt_steady(P)>();
-            else
-                wait_vmcnt<0>();
-#else
             wait_vmcnt<C::vmcnt_steady(P)>();
-#endif
         }
+        // pair: the partial sums written above must have reached the LDS before the partner passes the barrier
+        if constexpr (C::PAIR && MMA) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #ifdef RN_STAMPS
         const unsigned long long ts2 = stamp();
 #endif
@@ -988,6 +1048,9 @@ bool rn_rw_supported(int cin, int cout, int pool_k, int pool_s, bool res, int ou
     if (cin == 64 && cout == 128 && pool_k == 0 && !res) variant = 5, npt = 1;
     if (cin == 128 && cout == 16 && pool_k == 4 && ps == 2 && !res) variant = 6, npt = 2;   // K split over 3 waves
     if (variant < 0) return false;
+    // pair split (two waves per tile, two waves per SIMD) for the variants whose single-wave form needs the
+    // whole register file; RN_NO_PAIR=1 selects the single-wave forms (A/B timing)
+    plan->pair = (variant == 2 || variant == 4 || variant == 5) && !getenv("RN_NO_PAIR") ? 1 : 0;
     plan->variant = variant;
     plan->npt = npt;
     plan->n_colblocks = (tiles + npt - 1) / npt;
@@ -1016,7 +1079,10 @@ bool rn_rw_supported(int cin, int cout, int pool_k, int pool_s, bool res, int ou
 }
 
 int rn_rw_launch(const RwPlan& p, int dtype, hipStream_t s, const StageArgs& a, dim3 grid) {
-    switch (p.variant * 16 + p.npt) {
+    switch (p.variant * 16 + p.npt + (p.pair ? 256 : 0)) {
+        case 256 + 2 * 16 + 4: return launch_rw_dt<32, 32, 4, 1, true, 4, 2>(dtype, s, a, grid);
+        case 256 + 4 * 16 + 2: return launch_rw_dt<64, 64, 4, 2, true, 2, 2>(dtype, s, a, grid);
+        case 256 + 5 * 16 + 1: return launch_rw_dt<64, 128, 0, 1, false, 1, 2>(dtype, s, a, grid);
         case 0 * 16 + 4: return launch_rw_dt<8, 32, 4, 1, false, 4>(dtype, s, a, grid);
         case 0 * 16 + 8: return launch_rw_dt<8, 32, 4, 1, false, 8>(dtype, s, a, grid);
         case 1 * 16 + 4: return launch_rw_dt<32, 32, 4, 1, false, 4>(dtype, s, a, grid);
