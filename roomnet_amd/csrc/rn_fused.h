@@ -19,7 +19,6 @@ struct RwPlan {
     int npt = 0;
     int n_colblocks = 0;
     int skipcols = 0;
-    int pair = 0;      // two waves per (pixel tile, cout tile), see RwCfg::PAIR
     size_t lds_bytes = 0;
 };
 bool rn_rw_supported(int cin, int cout, int pool_k, int pool_s, bool res, int out_side, int skip_side,

@@ -655,22 +655,11 @@ int rn_fused_prepare(rn_handle* h, const rn_weights* w) {
         std::vector<unsigned short> frag(static_cast<size_t>(kc) * ct_n * 64 * 8, 0);
         const float* wsrc = w->stages[i].kernel;   // HWIO == [k = tap*cin + c][cout]
         const int K = 9 * s.cin;
-        // pair-split rw variants (rn_stage_rw.hip, KS = 2): fragment index [wave of the pair][its K-chunk]; wave w
-        // multiplies channel half w of every tap, and its MFMA rows are rotated by 16 channels so that the 16
-        // channels it finishes are accumulator registers 0..7
-        const bool pair = f.use_rw && f.rw.pair;
-        const int cpt = s.cin >= 16 ? s.cin / 16 : 1, kcw = kc / 2;
         for (int c = 0; c < kc; ++c)
             for (int t = 0; t < ct_n; ++t)
                 for (int l = 0; l < 64; ++l)
                     for (int j = 0; j < 8; ++j) {
-                        int csrc = c, rot = 0;
-                        if (pair) {
-                            const int w2 = c / kcw, idx = c % kcw, half = cpt / 2;
-                            csrc = (idx / half) * cpt + w2 * half + idx % half;
-                            rot = 16 * w2;
-                        }
-                        const int kk = csrc * 16 + 8 * (l >> 5) + j, co = t * 32 + (((l & 31) + rot) & 31);
+                        const int kk = c * 16 + 8 * (l >> 5) + j, co = t * 32 + (l & 31);
                         float v = 0.f;
                         if (kk < K && co < s.cout) v = wsrc[static_cast<size_t>(kk) * s.cout + co];
                         frag[((static_cast<size_t>(c) * ct_n + t) * 64 + l) * 8 + j] =

@@ -24,7 +24,6 @@
 #include "rn_stage.h"
 
 #include <algorithm>
-#include <cstdlib>
 #include <type_traits>
 #include <utility>
 
@@ -37,12 +36,10 @@ using IC = std::integral_constant<int, P>;
 
 typedef __attribute__((address_space(3))) void* lds_void_ptr;
 
-// Tile geometry of the rw kernels.  Pool 4/1: 32 consecutive conv columns per tile, 29 outputs, the
-// horizontal window sums walk the whole wave (DPP wave_shl).  Pool 4/2 ("gapped" tiles): the two
-// 16-lane DPP rows of a half-wave hold conv columns 0..15 and 14..29, so every window that starts
-// at an even column of a row ends inside that row: 7 + 7 outputs per tile from two row-local
-// shifts (row_shl:1, row_shl:2) instead of three wave shifts.
-constexpr int rw_tile_nout(int pk, int ps) { return pk ? (ps == 2 ? 14 : 32 - pk + 1) : 32; }
+// Tile geometry of the rw kernels: 32 consecutive conv columns per tile; a pooled tile produces the
+// windows that fit inside it (29 at stride 1, 15 at stride 2) on lanes 0 .. NOUT_T-1 -- the banded
+// pooling matrix of the pool MFMA decides which window lands on which lane.
+constexpr int rw_tile_nout(int pk, int ps) { return pk ? (32 - pk) / ps + 1 : 32; }
 constexpr int rw_tile_stride(int pk, int ps) { return pk ? rw_tile_nout(pk, ps) * ps : 32; }
 
 constexpr int RW_SKIPBUF = 3;   // staged skip-row pairs (residual): 1 being read + 2 in flight
@@ -60,21 +57,18 @@ struct RwCfg {
     static constexpr int CP = CIN / 8;
     static constexpr int KC = (9 * CIN + 15) / 16;
     static constexpr int CT = (COUT + 31) / 32;
-    // KS = 2 ("pair"): two waves share one (pixel tile, 32-channel cout tile).  Each takes half of the
-    // input channels of every tap (so both run the same code on different lane constants), they swap
-    // half of their partial accumulators through LDS and each finishes 16 of the 32 channels: half
-    // the weights, half the epilogue and half the pooling state per wave -- the variant fits two waves
-    // per SIMD, which overlap each other's MFMA, VALU and wait time.  The rows of the weight
-    // fragments are rotated by 16 for the second wave, so "my" channels are accumulator registers
-    // 0..7 and the partner's 8..15 in both.
-    static constexpr bool PAIR = KS == 2;
-    static constexpr int NG = COUT >= 32 ? (PAIR ? 2 : 4) : COUT / 8;   // 4-channel groups per lane half-row this wave finishes
-    static constexpr int CPT = CIN >= 16 ? CIN / 16 : 1;                // K-chunks per tap
-    static constexpr int CPTL = PAIR ? CPT / 2 : CPT;                   // ... that this wave multiplies
+    static constexpr int NG = COUT >= 32 ? 4 : COUT / 8;   // 4-channel groups per lane half-row
     static constexpr int CPO = COUT / 8;                       // 16-byte chunks per output/skip pixel
     static constexpr int TSTRIDE = rw_tile_stride(PK, PS);
     static constexpr int NOUT_T = rw_tile_nout(PK, PS);
-    static constexpr bool GAP = PK == 4 && PS == 2;           // gapped lane -> column map (see rw_tile_nout)
+    // POOLM: the 4-wide horizontal window sums run on the matrix cores.  The conv MFMA is issued with its
+    // operands swapped (D'[pixel][cout]: pixel rows in the accumulator registers, one cout per lane), so a
+    // lane's ReLU6'd values, rounded to fp16 pairs, ARE an A-operand fragment V[cout][x] of a second MFMA
+    // H[cout][xo] = V * Pm with the 0/1 band matrix Pm[x][xo] = (PS*xo <= x < PS*xo + 4) as a lane-constant
+    // B operand -- no cross-lane movement at all, and H comes out in the usual cout-in-register /
+    // pixel-on-lane layout for BN, residual and the stores.  Vertical pooling = fp32 pair sums before the
+    // rounding, so a pooled row costs 4 MFMAs (2 pair-sum rows x K = 32) instead of 48 DPP instructions.
+    static constexpr bool POOLM = PK == 4;
     // KS = 3: the K dimension is split by kernel row over three waves per pixel tile (each keeps one
     // kernel row's weight fragments in registers); partial accumulators meet in LDS (K = 1152 stage)
     static constexpr int NTHREADS = 64 * NPT * CT * KS;
@@ -95,7 +89,7 @@ struct RwCfg {
     static constexpr int LPT = (RINGCOLS * CP + LOADERS - 1) / LOADERS;     // DMA pieces per wave per row
     // shared ring: row stride padded to whole pieces; private ring: exact (the last piece is lane-masked)
     static constexpr int ROWB = PRIV ? RINGCOLS * CIN * 2 : LPT * NTHREADS * 16;
-    static constexpr int SKIPCOLS_MAX = RINGCOLS + 8;          // residual scale <= ~1.07 (checked on the host)
+    static constexpr int SKIPCOLS_MAX = RINGCOLS + 8;          // residual scale <= ~1.1 (checked on the host)
     static constexpr int SLPT = RES ? (2 * SKIPCOLS_MAX * CPO + NTHREADS - 1) / NTHREADS : 0;
     static constexpr int SKIPBUFB = SLPT * NTHREADS * 16;      // one staged pair of skip rows (padded)
     static constexpr int PTAB_BYTES = 4 * COUT * 4;
@@ -114,7 +108,7 @@ struct RwCfg {
 #endif
     // folded-BN tables: persistent registers where the register file has room (one wave per SIMD, or the
     // small 8-channel stage); otherwise one batched LDS read at the start of every epilogue
-    static constexpr bool PTAB_REGS = NTHREADS <= 256 || CIN == 8 || (CIN == 32 && COUT == 64) || PAIR;
+    static constexpr bool PTAB_REGS = NTHREADS <= 256 || CIN == 8 || (CIN == 32 && COUT == 64);
     // ... except the 8-wave 32->32 variant, which sits at the 256-register cap: it reads each group's
     // table entries late (right before use) so they never pin registers across the MFMA chain
     static constexpr bool PTAB_LATE = !PTAB_REGS && CIN == 32 && COUT == 32;
@@ -122,9 +116,7 @@ struct RwCfg {
     static constexpr int STAGE_OFF = SKIP_OFF + (RES ? RW_SKIPBUF * SKIPBUFB : 0);
     static constexpr int PART_OFF = STAGE_OFF + (STAGE_OUT ? NPT * CT * STAGE_WAVE_B : 0);
     static constexpr int PART_B = 16 * 64 * 4;                 // one wave's partial accumulator tile
-    static constexpr int PART_PAIR_B = 8 * 64 * 4;             // pair: the 8 accumulator registers handed to the partner
-    static constexpr int LDS_BYTES =
-        PART_OFF + (PAIR ? 2 * NPT * CT * 2 * PART_PAIR_B : (KS > 1 ? 2 * NPT * CT * (KS - 1) * PART_B : 0));
+    static constexpr int LDS_BYTES = PART_OFF + (KS > 1 ? 2 * NPT * CT * (KS - 1) * PART_B : 0);
     // steady-state counted wait at the end of step s: everything up to input row s+3 and the
     // skip pair used by step s+1 has landed; what may stay in flight is what the wave issued
     // after them (the pieces of this step, plus one more row of input when there is no skip)
@@ -139,8 +131,7 @@ struct RwCfg {
     static_assert(COUT % 32 == 0 || COUT == 16, "cout must be whole 32-channel tiles (or one half tile)");
     static_assert(PK == 0 || PK == 4, "pool window 4 or none");
     static_assert(KCW * 4 <= 80 || NTHREADS <= 256 || KS > 1, "weights need the whole register file: <= 1 wave per SIMD");
-    static_assert(KS == 1 || (KS == 3 && CIN >= 16 && KC % 3 == 0 && !RES) || (KS == 2 && CIN >= 32 && COUT % 32 == 0),
-                  "K split = one kernel row per wave, or a channel-half pair");
+    static_assert(KS == 1 || (KS == 3 && CIN >= 16 && KC % 3 == 0 && !RES), "K split = one kernel row per wave");
     static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
     static_assert(NSLOT % 2 == 0, "pool-ring parity is tied to the unroll");
     static_assert(!PRIV || (LPT - 1) * 64 < RINGCOLS * CP, "every DMA piece must have at least one active lane");
@@ -238,23 +229,9 @@ __global__ __launch_bounds__(64 * NPT * ((COUT + 31) / 32) * KS, 1) void stage_r
     for (int i = tid; i < 4 * COUT; i += NTHREADS) ptab[i] = a.ptab[i];
 
     // ---- this wave's weight fragments -> registers (lane-linear, coalesced)
-    // One wave per SIMD (<= 256 threads) owns a 512-entry register file, but only half of it is
-    // VGPRs: values only MFMAs consume (the weight fragments, the residual's interpolation weights)
-    // are pinned to the AGPR half -- an empty asm with "a" constraints gives the value that register
-    // class, the loads then target AGPRs directly and v_mfma reads them as srcA/srcB in place.
-    // (Left to itself hipcc keeps them in VGPRs, runs out, and bounces other values through AGPRs
-    //  with v_accvgpr_read/write: 55-80 extra VALU instructions per row in the residual variants.)
-#ifdef RN_NO_WAGPR
-    constexpr bool W_AGPR = false;
-#else
-    constexpr bool W_AGPR = NTHREADS <= 256;
-#endif
     i32x4 wreg[KCW];
 #pragma unroll
-    for (int kc = 0; kc < KCW; ++kc) {
-        wreg[kc] = a.wfrag[((ks * KCW + kc) * CT + ct) * 64 + lane];
-        if constexpr (W_AGPR) asm volatile("" : "+a"(wreg[kc]));
-    }
+    for (int kc = 0; kc < KCW; ++kc) wreg[kc] = a.wfrag[((ks * KCW + kc) * CT + ct) * 64 + lane];
 
     // ---- input-row DMA: piece i of a row covers ring chunks [i*NTHREADS, (i+1)*NTHREADS); this
     // lane fills chunk q = tid + i*NTHREADS = (pixel p, slot c') and therefore fetches source
@@ -285,9 +262,8 @@ __global__ __launch_bounds__(64 * NPT * ((COUT + 31) / 32) * KS, 1) void stage_r
             if constexpr (C::PRIV) {
                 if constexpr ((i + 1) * 64 <= RINGCOLS * CP)
                     dma16(row + ld_goff[i], ring + slot * ROWB + i * 64 * 16);
-                else {
+                else
                     dma16_masked(row + ld_goff[i], ring + slot * ROWB + i * 64 * 16, tail_mask);
-                }
             } else {
                 dma16(row + ld_goff[i], ring + slot * ROWB + i * NTHREADS * 16 + piece_base);
             }
@@ -339,18 +315,15 @@ __global__ __launch_bounds__(64 * NPT * ((COUT + 31) / 32) * KS, 1) void stage_r
     for (int j = 0; j < RW_AHEAD; ++j) issue_row(min(j, nin - 1), j);
 
     // ---- lane constants of this wave's pixel tile
-    const int pm = C::GAP ? r - 2 * (r >> 4) : r;            // conv column of this lane inside the tile
-    const int xrel0 = (C::PRIV ? 0 : pt * TSTRIDE) + pm;     // ring column of conv column (tap kx = 0)
-    int boff[3][C::CPTL];
+    const int xrel0 = (C::PRIV ? 0 : pt * TSTRIDE) + r;      // ring column of conv column (tap kx = 0)
+    int boff[3][CIN >= 16 ? CIN / 16 : 1];
     int b8_ky[CIN >= 16 ? 1 : KC], b8_off[CIN >= 16 ? 1 : KC];   // CIN == 8: per K-chunk tap row / offset
     if constexpr (CIN >= 16) {
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx)
 #pragma unroll
-            for (int cc = 0; cc < C::CPTL; ++cc) {
-                const int ccg = C::PAIR ? ks * C::CPTL + cc : cc;      // pair: this wave's half of the tap's channels
-                boff[kx][cc] = (xrel0 + kx) * PIXB + (((ccg * 2 + hh) ^ chunk_swz<CP>(xrel0 + kx)) << 4);
-            }
+            for (int cc = 0; cc < CIN / 16; ++cc)
+                boff[kx][cc] = (xrel0 + kx) * PIXB + (((cc * 2 + hh) ^ chunk_swz<CP>(xrel0 + kx)) << 4);
     } else {
 #pragma unroll
         for (int kc = 0; kc < KC; ++kc) {
@@ -361,17 +334,15 @@ __global__ __launch_bounds__(64 * NPT * ((COUT + 31) / 32) * KS, 1) void stage_r
             b8_off[kc] = (xrel0 + kx) * PIXB;
         }
     }
-    const int xc = x0c + pt * TSTRIDE + pm;
-    const int xo = PK ? xc / PS : xc;
-    const bool lane_win = C::GAP ? ((r & 1) == 0 && (r & 15) <= 12) : (PK ? r <= 32 - PK : true);   // a window starts here
-    const bool lane_out = lane_win && xo < a.Wo && (xo - xo_blk0) < NPT * NOUT_T;
-    const int cbase = ct * 32 + (C::PAIR ? 16 * ks : 0);    // first channel this wave finishes
-    const float* const ptab_lane = ptab + cbase + 4 * hh;                                  // + 8*g (+ table*COUT)
+    // output column of this lane: pooled tiles deliver window i of the tile on lane i (see POOLM)
+    const int xo = (PK ? (x0c + pt * TSTRIDE) / PS : x0c + pt * TSTRIDE) + r;
+    const bool lane_out = r < NOUT_T && xo < a.Wo && (xo - xo_blk0) < NPT * NOUT_T;
+    const float* const ptab_lane = ptab + ct * 32 + 4 * hh;                                // + 8*g (+ table*COUT)
     f32x4 sc1r[NG], sh1r[NG], sc2r[NG], sh2r[NG];
     if constexpr (C::PTAB_REGS) {
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
-            const float* gp = a.ptab + cbase + 4 * hh + 8 * g;
+            const float* gp = a.ptab + ct * 32 + 4 * hh + 8 * g;
             sc1r[g] = *reinterpret_cast<const f32x4*>(gp);
             sh1r[g] = *reinterpret_cast<const f32x4*>(gp + COUT);
             if constexpr (RES) {
@@ -381,7 +352,7 @@ __global__ __launch_bounds__(64 * NPT * ((COUT + 31) / 32) * KS, 1) void stage_r
         }
     }
     // staging: this lane's output pixel index inside the tile, number of valid pixels of the tile
-    const int pr = PK ? r / PS : r;
+    const int pr = r;
     const int xo_t0s = PK ? (x0c + pt * TSTRIDE) / PS : (x0c + pt * TSTRIDE);     // first output column of the tile
     const int nvalid = max(0, min(NOUT_T, min(a.Wo, xo_blk0 + NPT * NOUT_T) - xo_t0s)); // wave-uniform
     // LDS byte addresses (as 32-bit LDS offsets, used by inline-asm DS ops):
@@ -412,7 +383,7 @@ __global__ __launch_bounds__(64 * NPT * ((COUT + 31) / 32) * KS, 1) void stage_r
     };
     const bool stores_on = !(a.dbg_flags & 1);
     // direct stores: this lane's 16-byte chunk of pixel xo (second chunk at +32 bytes)
-    const int voff_lane = (lane_out && stores_on) ? (xo * COUT + cbase + 8 * hh) * 2 : OOB;
+    const int voff_lane = (lane_out && stores_on) ? (xo * COUT + ct * 32 + 8 * hh) * 2 : OOB;
     // staged stores: lane-linear 16-byte chunks of the tile-row (second instruction + 1024 bytes)
     const int voff_st0 = (stores_on && lane < 4 * nvalid) ? xo_t0s * COUT * 2 + lane * 16 : OOB;
     const int voff_st1 = (stores_on && lane + 64 < 4 * nvalid) ? xo_t0s * COUT * 2 + lane * 16 + 1024 : OOB;
@@ -448,10 +419,6 @@ __global__ __launch_bounds__(64 * NPT * ((COUT + 31) / 32) * KS, 1) void stage_r
                 bw_h[c][d] = static_cast<int>(static_cast<unsigned>(wh[2 * d]) | (static_cast<unsigned>(wh[2 * d + 1]) << 16));
                 bw_l[c][d] = static_cast<int>(static_cast<unsigned>(wl[2 * d]) | (static_cast<unsigned>(wl[2 * d + 1]) << 16));
             }
-            if constexpr (W_AGPR) {
-                asm volatile("" : "+a"(bw_h[c]));
-                asm volatile("" : "+a"(bw_l[c]));
-            }
         }
         // transposed read: lane 4q+p of a 16-lane group addresses row q, columns 4p..4p+3 of a
         // 4-row x 16-column block and receives column (lane & 15) of the 4 rows
@@ -461,8 +428,7 @@ __global__ __launch_bounds__(64 * NPT * ((COUT + 31) / 32) * KS, 1) void stage_r
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 const int pix = min(max(xs_t + 16 * c + 8 * (grp >> 1) + 4 * t + q, 0), a.skipcols - 1);
-                // (pair: the second wave's MFMA rows are rotated by 16 channels = two 16-byte chunks)
-                const int ch = ct * 4 + ((2 * (grp & 1) + (pp >> 1) + (C::PAIR ? 2 * ks : 0)) & 3);
+                const int ch = ct * 4 + 2 * (grp & 1) + (pp >> 1);
                 a_off[2 * c + t] = (pix * CPO + (ch ^ chunk_swz<CPO>(pix))) * 16 + (pp & 1) * 8;
             }
     }
@@ -480,9 +446,29 @@ __global__ __launch_bounds__(64 * NPT * ((COUT + 31) / 32) * KS, 1) void stage_r
     };
 
     // ---- pooling state
-    float hprev[16], q0[16], q1[16];
+    // vertical pair sums: q_j = v_{j-1} + v_j in fp32 (hprev = previous row), rounded to fp16 pairs;
+    // a 4-row window is q_{j-2} + q_j (stride 1: q ring by row parity; stride 2: pairs of even/odd rows)
+    float hprev[16];
 #pragma unroll
-    for (int g = 0; g < 16; ++g) hprev[g] = q0[g] = q1[g] = 0.f;
+    for (int g = 0; g < 16; ++g) hprev[g] = 0.f;
+    i32x4 qp0[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}}, qp1[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+    // band matrix Pm[x][xo] as the pool MFMA's B operand: lane (xo = r, k-group hh), K slot (chunk c, j) is the
+    // conv column held by accumulator register 8c + j of the transposed conv tile: x = (j & 3) + 8 (j >> 2) + 16 c + 4 hh
+    i32x4 pmw[2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            unsigned w = 0;
+#pragma unroll
+            for (int e2 = 0; e2 < 2; ++e2) {
+                const int j8 = 2 * d + e2;
+                const int x = (j8 & 3) + 8 * (j8 >> 2) + 16 * c + 4 * hh;
+                const bool in = PK && x >= PS * r && x < PS * r + 4;
+                w |= (in ? 0x3C00u : 0u) << (16 * e2);      // fp16 1.0
+            }
+            pmw[c][d] = static_cast<int>(w);
+        }
     f32x16 acc0, acc1;
 #pragma unroll
     for (int g = 0; g < 16; ++g) acc0[g] = acc1[g] = 0.f;
@@ -495,7 +481,7 @@ __global__ __launch_bounds__(64 * NPT * ((COUT + 31) / 32) * KS, 1) void stage_r
     auto b_frag = [&](auto PC, auto KCC) __attribute__((always_inline)) -> i32x4 {
         constexpr int P = decltype(PC)::value, kc = decltype(KCC)::value;
         if constexpr (CIN >= 16) {
-            constexpr int tap = kc / C::CPTL, cc = kc % C::CPTL;
+            constexpr int tap = kc / (CIN / 16), cc = kc % (CIN / 16);
             constexpr int ky = tap / 3, kx = tap % 3;
             return *reinterpret_cast<const i32x4*>(ring + ((P + ky) % RW_NSLOT) * ROWB + boff[kx][cc]);
         } else {
@@ -511,13 +497,13 @@ __global__ __launch_bounds__(64 * NPT * ((COUT + 31) / 32) * KS, 1) void stage_r
     // the count conservative).  Ring offsets beyond the 16-bit DS immediate use a second base.
     constexpr int BAHEAD = KC >= 6 ? 4 : 1;
     constexpr int SLOT_SPLIT = 65535 / ROWB >= RW_NSLOT ? RW_NSLOT : 65535 / ROWB;   // slots reachable from base 0
-    unsigned bbase0[3][C::CPTL], bbase1[3][C::CPTL];
+    unsigned bbase0[3][CIN >= 16 ? CIN / 16 : 1], bbase1[3][CIN >= 16 ? CIN / 16 : 1];
     if constexpr (CIN >= 16) {
         const unsigned ring_lds = static_cast<unsigned>(reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) char*)ring));
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx)
 #pragma unroll
-            for (int cc = 0; cc < C::CPTL; ++cc) {
+            for (int cc = 0; cc < CIN / 16; ++cc) {
                 bbase0[kx][cc] = ring_lds + static_cast<unsigned>(boff[kx][cc]);
                 bbase1[kx][cc] = bbase0[kx][cc] + static_cast<unsigned>(SLOT_SPLIT * ROWB);
             }
@@ -526,8 +512,8 @@ __global__ __launch_bounds__(64 * NPT * ((COUT + 31) / 32) * KS, 1) void stage_r
     // MFMA BAHEAD chunks back as an input keeps hipcc from hoisting every read of the row to the top
     // of the step, which made all KC fragments live at once (72-144 VGPRs, spilled to AGPRs).
     auto b_read_asm = [&](auto PC, auto KCC, float dep) __attribute__((always_inline)) -> i32x4 {
-        constexpr int P = decltype(PC)::value, kc = decltype(KCC)::value;   // kc: K-chunk (pair: of this wave's half)
-        constexpr int tap = kc / C::CPTL, cc = kc % C::CPTL;
+        constexpr int P = decltype(PC)::value, kc = decltype(KCC)::value;   // kc: global K-chunk
+        constexpr int tap = kc / (CIN / 16), cc = kc % (CIN / 16);
         constexpr int ky = tap / 3, kx = tap % 3;
         constexpr int slot = (P + ky) % RW_NSLOT;
         i32x4 v;
@@ -540,10 +526,7 @@ __global__ __launch_bounds__(64 * NPT * ((COUT + 31) / 32) * KS, 1) void stage_r
         return v;
     };
     // MFMA chain of one conv row over the K-chunks [KB, KB + KCW) (KB = 0 unless K is split)
-    // `hook` runs once, right behind the wait of the first fragment: LDS returns in order, so every
-    // asm LDS read issued BEFORE the chain (the residual's transposed reads, the pair exchange) has
-    // landed there too -- they get retired for free instead of by an lgkmcnt(0) stall of their own.
-    auto mma_chain = [&](auto PC, auto KBC, f32x16& acc, auto&& hook) __attribute__((always_inline)) {
+    auto mma_chain = [&](auto PC, auto KBC, f32x16& acc) __attribute__((always_inline)) {
         constexpr int KB = decltype(KBC)::value;
         const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         i32x4 bq[KCW];
@@ -557,32 +540,33 @@ __global__ __launch_bounds__(64 * NPT * ((COUT + 31) / 32) * KS, 1) void stage_r
                          bq[I + BAHEAD] = b_read_asm(PC, IC<KB + (I + BAHEAD < KCW ? I + BAHEAD : 0)>{}, I == 0 ? 0.f : acc[0]);
                      constexpr int newer = (KCW - 1 - I) < BAHEAD ? (KCW - 1 - I) : BAHEAD;   // my reads issued after chunk I
                      asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(bq[I]) : "n"(newer));
-                     if constexpr (I == 0) hook();
-                     acc = mfma32<DT>(wreg[I], bq[I], I == 0 ? zero : acc);
+                     if constexpr (C::POOLM)
+                         acc = mfma32<DT>(bq[I], wreg[I], I == 0 ? zero : acc);   // D'[pixel][cout]
+                     else
+                         acc = mfma32<DT>(wreg[I], bq[I], I == 0 ? zero : acc);   // D[cout][pixel]
                  }()),
                  ...);
             }(std::make_integer_sequence<int, KCW>{});
         } else {
-            hook();
             bq[0] = b_frag(PC, IC<0>{});
             [&]<int... I>(std::integer_sequence<int, I...>) {
                 ((bq[I + 1 < KC ? I + 1 : 0] = (I + 1 < KC ? b_frag(PC, IC<(I + 1 < KC ? I + 1 : 0)>{}) : bq[0]),
-                  acc = mfma32<DT>(wreg[I], bq[I], I == 0 ? zero : acc)),
+                  acc = C::POOLM ? mfma32<DT>(bq[I], wreg[I], I == 0 ? zero : acc) : mfma32<DT>(wreg[I], bq[I], I == 0 ? zero : acc)),
                  ...);
             }(std::make_integer_sequence<int, KC>{});
         }
     };
-    auto mma_row = [&](auto PC, f32x16& acc, auto&& hook) __attribute__((always_inline)) {
-        if constexpr (KS == 1 || C::PAIR) {
-            mma_chain(PC, IC<0>{}, acc, hook);
+    auto mma_row = [&](auto PC, f32x16& acc) __attribute__((always_inline)) {
+        if constexpr (KS == 1) {
+            mma_chain(PC, IC<0>{}, acc);
         } else {
             // wave-uniform dispatch on the kernel row: ring slot and tap offsets stay compile-time
             if (ks == 0)
-                mma_chain(PC, IC<0>{}, acc, hook);
+                mma_chain(PC, IC<0>{}, acc);
             else if (ks == 1)
-                mma_chain(PC, IC<KCW>{}, acc, hook);
+                mma_chain(PC, IC<KCW>{}, acc);
             else
-                mma_chain(PC, IC<2 * KCW>{}, acc, hook);
+                mma_chain(PC, IC<2 * KCW>{}, acc);
         }
     };
     // K split: LDS exchange of partial accumulators, double-buffered by step parity
@@ -632,56 +616,10 @@ __global__ __launch_bounds__(64 * NPT * ((COUT + 31) / 32) * KS, 1) void stage_r
         }
     };
 
-    // pair exchange: each wave hands accumulator registers 8..15 (the partner's channels) over and
-    // receives the partner's partial sums of its own 16 channels
-    auto pair_addr = [&](int parity, int writer) __attribute__((always_inline)) -> unsigned {
-        return part_lds + static_cast<unsigned>(((parity * NPT * CT + (ct * NPT + pt)) * 2 + writer) * C::PART_PAIR_B);
-    };
-    auto pair_write = [&](int parity, const f32x16& acc_in) __attribute__((always_inline)) {
-        const unsigned ad = pair_addr(parity, ks);
-        f32x16 acc = acc_in;
-        asm volatile("s_nop 15" : "+v"(acc));    // 8-pass MFMA result -> DS data read: 12 states, not padded around asm
-        const i32x4 v2 = {__float_as_int(acc[8]), __float_as_int(acc[9]), __float_as_int(acc[10]), __float_as_int(acc[11])};
-        const i32x4 v3 = {__float_as_int(acc[12]), __float_as_int(acc[13]), __float_as_int(acc[14]), __float_as_int(acc[15])};
-        asm volatile("ds_write_b128 %0, %1\n\ts_nop 1" ::"v"(ad), "v"(v2) : "memory");
-        asm volatile("ds_write_b128 %0, %1 offset:1024\n\ts_nop 1" ::"v"(ad), "v"(v3) : "memory");
-    };
-    auto pair_read_issue = [&](int parity, i32x4& v0, i32x4& v1) __attribute__((always_inline)) {
-        const unsigned ad = pair_addr(parity, 1 - ks);
-        asm volatile("ds_read_b128 %0, %1" : "=v"(v0) : "v"(ad) : "memory");
-        asm volatile("ds_read_b128 %0, %1 offset:1024" : "=v"(v1) : "v"(ad) : "memory");
-    };
-    // residual, part 1 (issued ahead of the MFMA chain): transposed reads of the staged skip pair
-    using TQ = i32x2[8];
-    auto res_issue = [&](int skip_buf, TQ& t) __attribute__((always_inline)) {
-        const char* sk0 = skipb + skip_buf * C::SKIPBUFB;
-        const char* sk1 = sk0 + skipbytes;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            t[q] = tr_read(sk0 + a_off[q]);
-            t[4 + q] = tr_read(sk1 + a_off[q]);
-        }
-    };
-    // residual, part 2: R_lo / R_hi = Skip_lo/hi^T * Wx on the matrix cores (ordinary MFMA builtins: hipcc
-    // interleaves them with the conv chain)
-    auto res_mfma = [&](const TQ& t, f32x16& r_lo, f32x16& r_hi) __attribute__((always_inline)) {
-        const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        const i32x4 al0 = {t[0][0], t[0][1], t[1][0], t[1][1]}, al1 = {t[2][0], t[2][1], t[3][0], t[3][1]};
-        const i32x4 ah0 = {t[4][0], t[4][1], t[5][0], t[5][1]}, ah1 = {t[6][0], t[6][1], t[7][0], t[7][1]};
-        r_lo = mfma32<DT>(al0, bw_h[0], zero);
-        r_hi = mfma32<DT>(ah0, bw_h[0], zero);
-        r_lo = mfma32<DT>(al0, bw_l[0], r_lo);
-        r_hi = mfma32<DT>(ah0, bw_l[0], r_hi);
-        r_lo = mfma32<DT>(al1, bw_h[1], r_lo);
-        r_hi = mfma32<DT>(ah1, bw_h[1], r_hi);
-        r_lo = mfma32<DT>(al1, bw_l[1], r_lo);
-        r_hi = mfma32<DT>(ah1, bw_l[1], r_hi);
-    };
-
     // epilogue of conv row j (local index); JP = j mod RW_NSLOT (only its parity matters).
     // Works on one group of 4 consecutive channels at a time (4 independent DPP chains in
     // lockstep: short live ranges, and the VALU-write -> DPP-read hazard is covered).
-    auto epi_row = [&](auto JPC, const f32x16& acc, int j, const f32x16& r_lo, const f32x16& r_hi) __attribute__((always_inline)) {
+    auto epi_row = [&](auto JPC, const f32x16& acc, int j, int skip_buf) __attribute__((always_inline)) {
         constexpr int JP = decltype(JPC)::value;
         constexpr bool emit_phase = PK == 0 || PS == 1 || (JP & 1) == 1;
         const bool emit = PK ? j >= 3 : true;
@@ -691,6 +629,28 @@ __global__ __launch_bounds__(64 * NPT * ((COUT + 31) / 32) * KS, 1) void stage_r
         if constexpr (RES) {
             const float src = static_cast<float>(yo) * a.rscale;
             yl = src - static_cast<float>(static_cast<int>(src));
+        }
+        const char* sk0 = skipb + skip_buf * C::SKIPBUFB;
+        const char* sk1 = sk0 + skipbytes;
+        f32x16 r_lo, r_hi;
+        if constexpr (RES && emit_phase) {
+            const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            i32x2 t0 = tr_read(sk0 + a_off[0]), t1 = tr_read(sk0 + a_off[1]);
+            i32x2 t2 = tr_read(sk0 + a_off[2]), t3 = tr_read(sk0 + a_off[3]);
+            i32x2 t4 = tr_read(sk1 + a_off[0]), t5 = tr_read(sk1 + a_off[1]);
+            i32x2 t6 = tr_read(sk1 + a_off[2]), t7 = tr_read(sk1 + a_off[3]);
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+v"(t0), "+v"(t1), "+v"(t2), "+v"(t3), "+v"(t4), "+v"(t5), "+v"(t6), "+v"(t7));
+            const i32x4 al0 = {t0[0], t0[1], t1[0], t1[1]}, al1 = {t2[0], t2[1], t3[0], t3[1]};
+            const i32x4 ah0 = {t4[0], t4[1], t5[0], t5[1]}, ah1 = {t6[0], t6[1], t7[0], t7[1]};
+            r_lo = mfma32<DT>(al0, bw_h[0], zero);
+            r_hi = mfma32<DT>(ah0, bw_h[0], zero);
+            r_lo = mfma32<DT>(al0, bw_l[0], r_lo);
+            r_hi = mfma32<DT>(ah0, bw_l[0], r_hi);
+            r_lo = mfma32<DT>(al1, bw_h[1], r_lo);
+            r_hi = mfma32<DT>(ah1, bw_h[1], r_hi);
+            r_lo = mfma32<DT>(al1, bw_l[1], r_lo);
+            r_hi = mfma32<DT>(ah1, bw_l[1], r_hi);
         }
         f32x4 sc1v[NG], sh1v[NG], sc2v[NG], sh2v[NG];
         if constexpr (emit_phase) {
@@ -715,80 +675,44 @@ __global__ __launch_bounds__(64 * NPT * ((COUT + 31) / 32) * KS, 1) void stage_r
                 }
             }
         }
+        // ---- ReLU6 + 4x4 window sums
+        f32x16 H;
+        if constexpr (C::POOLM) {
+            const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            float q[16];
+            if constexpr (PS == 1 || (JP & 1) == 1) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const float v = relu6f(acc[i]);
+                    q[i] = hprev[i] + v;
+                    if constexpr (PS == 1) hprev[i] = v;
+                }
+                i32x4 qp[2];
+#pragma unroll
+                for (int c = 0; c < 2; ++c)
+#pragma unroll
+                    for (int d = 0; d < 4; ++d)
+                        qp[c][d] = static_cast<int>(pack2<RN_DTYPE_F16>(q[8 * c + 2 * d], q[8 * c + 2 * d + 1]));
+                // stride 1: window rows j-3..j = q_{j-2} + q_j, ring by parity; stride 2 (odd rows only): rows
+                // 2e..2e+3 = (pair of the previous odd row) + (this pair)
+                i32x4(&qold)[2] = (PS == 2 || (JP & 1) == 0) ? qp0 : qp1;
+                H = mfma32<RN_DTYPE_F16>(qold[0], pmw[0], zero);
+                H = mfma32<RN_DTYPE_F16>(qold[1], pmw[1], H);
+                H = mfma32<RN_DTYPE_F16>(qp[0], pmw[0], H);
+                H = mfma32<RN_DTYPE_F16>(qp[1], pmw[1], H);
+                qold[0] = qp[0];
+                qold[1] = qp[1];
+            } else {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) hprev[i] = relu6f(acc[i]);
+            }
+        }
         uint2 pk[4];
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
-            float v[4], t[4], u[4], hs[4], S[4];
+            float S[4];
 #pragma unroll
-#ifdef RN_ABL_RELU
-            for (int jj = 0; jj < 4; ++jj) v[jj] = acc[4 * g + jj];
-#else
-            for (int jj = 0; jj < 4; ++jj) v[jj] = relu6f(acc[4 * g + jj]);
-#endif
-            if constexpr (PK == 4 && PS == 1) {
-#ifdef RN_ABL_DPP
-#pragma unroll
-                for (int jj = 0; jj < 4; ++jj) hs[jj] = v[jj], t[jj] = u[jj] = 0.f;
-#else
-#pragma unroll
-                for (int jj = 0; jj < 4; ++jj) t[jj] = v[jj] + lane_next(v[jj]);
-#pragma unroll
-                for (int jj = 0; jj < 4; ++jj) u[jj] = lane_next(t[jj]);
-#pragma unroll
-                for (int jj = 0; jj < 4; ++jj) hs[jj] = t[jj] + lane_next(u[jj]);
-#endif
-            }
-#ifdef RN_ABL_VERT
-            if constexpr (true) {
-#pragma unroll
-                for (int jj = 0; jj < 4; ++jj) S[jj] = (PK && PS == 1) ? hs[jj] : v[jj];
-            } else if constexpr (PS == 1) {
-#else
-            if constexpr (PK == 0) {
-#pragma unroll
-                for (int jj = 0; jj < 4; ++jj) S[jj] = v[jj];
-            } else if constexpr (PS == 1) {
-#endif
-                // q_j = h_{j-1} + h_j ; S_j = q_{j-2} + q_j ; q ring by parity of j
-#pragma unroll
-                for (int jj = 0; jj < 4; ++jj) {
-                    const int gi = 4 * g + jj;
-                    const float q = hprev[gi] + hs[jj];
-                    hprev[gi] = hs[jj];
-                    if constexpr ((JP & 1) == 0) {
-                        S[jj] = q0[gi] + q;
-                        q0[gi] = q;
-                    } else {
-                        S[jj] = q1[gi] + q;
-                        q1[gi] = q;
-                    }
-                }
-            } else if constexpr ((JP & 1) == 1) {
-                // stride 2, vertical sums first: windows start at even conv rows and end at odd rows
-                // j = 2e + 3, so only odd rows run the horizontal (DPP) half of the pool
-#pragma unroll
-                for (int jj = 0; jj < 4; ++jj) {
-                    const int gi = 4 * g + jj;
-                    const float q = hprev[gi] + v[jj];
-                    t[jj] = q0[gi] + q;
-                    q0[gi] = q;
-                }
-#ifdef RN_ABL_DPP
-#pragma unroll
-                for (int jj = 0; jj < 4; ++jj) S[jj] = t[jj];
-#else
-#pragma unroll
-                for (int jj = 0; jj < 4; ++jj) u[jj] = t[jj] + row_next<1>(t[jj]);
-#pragma unroll
-                for (int jj = 0; jj < 4; ++jj) S[jj] = u[jj] + row_next<2>(u[jj]);
-#endif
-            } else {
-#pragma unroll
-                for (int jj = 0; jj < 4; ++jj) {
-                    hprev[4 * g + jj] = v[jj];
-                    S[jj] = 0.f;
-                }
-            }
+            for (int jj = 0; jj < 4; ++jj) S[jj] = C::POOLM ? H[4 * g + jj] : relu6f(acc[4 * g + jj]);
             if constexpr (emit_phase) {
 #ifndef RN_ABL_TAB
                 if constexpr (C::PTAB_LATE) {
@@ -847,10 +771,8 @@ __global__ __launch_bounds__(64 * NPT * ((COUT + 31) / 32) * KS, 1) void stage_r
                 // (lanes without an output write a pixel slot nobody reads: no predicate needed)
                 // (leading s_nop: the data registers were just written by v_permlane32_swap, and hipcc pads
                 //  no hazards between its own instructions and the inside of an asm string)
-                {
                 asm volatile("s_nop 1\n\tds_write_b128 %0, %1\n\ts_nop 1" ::"v"(st_w0), "v"(vv[0]) : "memory");
                 asm volatile("s_nop 1\n\tds_write_b128 %0, %1\n\ts_nop 1" ::"v"(st_w0 ^ 32u), "v"(vv[1]) : "memory");
-                }
                 i32x4 o0, o1;
                 asm volatile("ds_read_b128 %0, %1" : "=v"(o0) : "v"(st_r0) : "memory");
                 asm volatile("ds_read_b128 %0, %1 offset:1024" : "=v"(o1) : "v"(st_r0) : "memory");
@@ -884,23 +806,6 @@ __global__ __launch_bounds__(64 * NPT * ((COUT + 31) / 32) * KS, 1) void stage_r
         const unsigned long long ts0 = stamp();
 #endif
         constexpr bool MMA = decltype(MMAC)::value != 0, EPI = decltype(EPIC)::value != 0;
-        constexpr int JP = (P + RW_NSLOT - 1) % RW_NSLOT;                     // phase of conv row s-1 (the epilogue's row)
-        constexpr bool emit_phase = PK == 0 || PS == 1 || (JP & 1) == 1;
-        constexpr bool RESW = RES && EPI && emit_phase;                        // this step adds a residual row
-        constexpr bool PAIRR = C::PAIR && EPI;                                 // this step finishes a pair-split row
-        f32x16& acc_new = (P & 1) == 0 ? acc0 : acc1;
-        f32x16& acc_old = (P & 1) == 0 ? acc1 : acc0;
-        // ---- LDS reads the epilogue of row s-1 needs, issued ahead of the chain (retired by its first wait)
-        TQ tq;
-        i32x4 rv0, rv1;
-        f32x16 r_lo, r_hi;
-        if constexpr (PAIRR) pair_read_issue((P + 1) & 1, rv0, rv1);
-        if constexpr (RESW) res_issue(sbuf_read, tq);
-        auto retire = [&]() __attribute__((always_inline)) {
-            if constexpr (PAIRR) asm volatile("" : "+v"(rv0), "+v"(rv1));
-            if constexpr (RESW)
-                asm volatile("" : "+v"(tq[0]), "+v"(tq[1]), "+v"(tq[2]), "+v"(tq[3]), "+v"(tq[4]), "+v"(tq[5]), "+v"(tq[6]), "+v"(tq[7]));
-        };
         if constexpr (MMA) {
             // (past the end of the band the last row is fetched again into a free slot: the number of
             //  DMA pieces per step stays constant, so the counted waits and the code path do too)
@@ -915,41 +820,37 @@ __global__ __launch_bounds__(64 * NPT * ((COUT + 31) / 32) * KS, 1) void stage_r
 #if defined(RN_STAMPS) && defined(RN_STAMP_CHAIN)
             const unsigned long long tc0 = stamp();
 #endif
-            mma_row(PC, acc_new, retire);
+            if constexpr ((P & 1) == 0)
+                mma_row(PC, acc0);
+            else
+                mma_row(PC, acc1);
 #if defined(RN_STAMPS) && defined(RN_STAMP_CHAIN)
             st_chain += stamp() - tc0;
 #endif
-            if constexpr (C::PAIR) {
-                pair_write(P & 1, acc_new);
-            } else if constexpr (KS > 1) {
+            if constexpr (KS > 1) {
                 // waves of kernel rows 1, 2 publish their partial sums for the epilogue of the next step
-                if (ks > 0) part_write(P & 1, acc_new);
+                if (ks > 0) part_write(P & 1, (P & 1) == 0 ? acc0 : acc1);
             }
-        } else if constexpr (PAIRR || RESW) {
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // drain step: no chain to retire them
-            retire();
         }
         if constexpr (EPI) {
-            if constexpr (RESW) res_mfma(tq, r_lo, r_hi);
-            if constexpr (PAIRR) {
-#pragma unroll
-                for (int jj = 0; jj < 4; ++jj) {
-                    acc_old[jj] += __int_as_float(rv0[jj]);
-                    acc_old[4 + jj] += __int_as_float(rv1[jj]);
+            if (KS == 1 || ks == 0) {        // K split: only the wave of kernel row 0 owns the epilogue
+                if constexpr ((P & 1) == 0) {
+                    if constexpr (KS > 1) part_add((P + 1) & 1, acc1);
+                    epi_row(IC<(P + RW_NSLOT - 1) % RW_NSLOT>{}, acc1, s - 1, sbuf_read);
+                } else {
+                    if constexpr (KS > 1) part_add((P + 1) & 1, acc0);
+                    epi_row(IC<(P + RW_NSLOT - 1) % RW_NSLOT>{}, acc0, s - 1, sbuf_read);
                 }
             }
-            if (KS == 1 || C::PAIR || ks == 0) {        // 3-way K split: only the wave of kernel row 0 owns the epilogue
-                if constexpr (KS == 3) part_add((P + 1) & 1, acc_old);
-                epi_row(IC<JP>{}, acc_old, s - 1, r_lo, r_hi);
-            }
         }
-        // the epilogue of this step handled conv row s-1: rotate the skip buffers after an emit phase
-        if constexpr (RESW) sbuf_read = sbuf_read == RW_SKIPBUF - 1 ? 0 : sbuf_read + 1;
+        // the epilogue of this step handled conv row s-1 (phase parity (P+1)&1): rotate after an emit phase
+        if constexpr (RES && EPI && (PS == 1 || ((P + 1) & 1) == 1))
+            sbuf_read = sbuf_read == RW_SKIPBUF - 1 ? 0 : sbuf_read + 1;
         if constexpr (MMA && EPI) {
             // software pipeline: spread the VALU epilogue of row s-1 through the MFMA chain of row s
             constexpr int VPG = RES ? 10 : 8;
 #pragma unroll
-            for (int i = 0; i < KCW + (RESW ? 8 : 0); ++i) {
+            for (int i = 0; i < KC + (C::POOLM ? 4 : 0) + (RES ? 8 : 0); ++i) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     // one MFMA
                 __builtin_amdgcn_sched_group_barrier(0x002, VPG, 0);   // VALU
             }
@@ -961,8 +862,6 @@ __global__ __launch_bounds__(64 * NPT * ((COUT + 31) / 32) * KS, 1) void stage_r
             // retire the DMA of input row s+3 (and of the skip pair the next epilogue reads)
             wait_vmcnt<C::vmcnt_steady(P)>();
         }
-        // pair: the partial sums written above must have reached the LDS before the partner passes the barrier
-        if constexpr (C::PAIR && MMA) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #ifdef RN_STAMPS
         const unsigned long long ts2 = stamp();
 #endif
@@ -1048,9 +947,6 @@ bool rn_rw_supported(int cin, int cout, int pool_k, int pool_s, bool res, int ou
     if (cin == 64 && cout == 128 && pool_k == 0 && !res) variant = 5, npt = 1;
     if (cin == 128 && cout == 16 && pool_k == 4 && ps == 2 && !res) variant = 6, npt = 2;   // K split over 3 waves
     if (variant < 0) return false;
-    // pair split (two waves per tile, two waves per SIMD) for the variants whose single-wave form needs the
-    // whole register file; RN_NO_PAIR=1 selects the single-wave forms (A/B timing)
-    plan->pair = (variant == 2 || variant == 4 || variant == 5) && !getenv("RN_NO_PAIR") ? 1 : 0;
     plan->variant = variant;
     plan->npt = npt;
     plan->n_colblocks = (tiles + npt - 1) / npt;
@@ -1079,10 +975,7 @@ bool rn_rw_supported(int cin, int cout, int pool_k, int pool_s, bool res, int ou
 }
 
 int rn_rw_launch(const RwPlan& p, int dtype, hipStream_t s, const StageArgs& a, dim3 grid) {
-    switch (p.variant * 16 + p.npt + (p.pair ? 256 : 0)) {
-        case 256 + 2 * 16 + 4: return launch_rw_dt<32, 32, 4, 1, true, 4, 2>(dtype, s, a, grid);
-        case 256 + 4 * 16 + 2: return launch_rw_dt<64, 64, 4, 2, true, 2, 2>(dtype, s, a, grid);
-        case 256 + 5 * 16 + 1: return launch_rw_dt<64, 128, 0, 1, false, 1, 2>(dtype, s, a, grid);
+    switch (p.variant * 16 + p.npt) {
         case 0 * 16 + 4: return launch_rw_dt<8, 32, 4, 1, false, 4>(dtype, s, a, grid);
         case 0 * 16 + 8: return launch_rw_dt<8, 32, 4, 1, false, 8>(dtype, s, a, grid);
         case 1 * 16 + 4: return launch_rw_dt<32, 32, 4, 1, false, 4>(dtype, s, a, grid);
