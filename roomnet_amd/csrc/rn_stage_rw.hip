@@ -36,10 +36,15 @@ using IC = std::integral_constant<int, P>;
 
 typedef __attribute__((address_space(3))) void* lds_void_ptr;
 
-// Tile geometry of the rw kernels: 32 consecutive conv columns per tile; a pooled tile produces the
-// windows that fit inside it (29 at stride 1, 15 at stride 2) on lanes 0 .. NOUT_T-1 -- the banded
-// pooling matrix of the pool MFMA decides which window lands on which lane.
-constexpr int rw_tile_nout(int pk, int ps) { return pk ? (32 - pk) / ps + 1 : 32; }
+// Tile geometry of the rw kernels: 32 conv columns per tile.
+//  pool 4/1: the 29 windows inside the tile, window i on lane i; the horizontal sums run on the matrix
+//            cores (RwCfg::POOLM);
+//  pool 4/2: "gapped" tiles -- the two 16-lane DPP rows of a half-wave hold conv columns 0..15 and 14..29,
+//            so every window that starts at an even column of a row ends inside that row: 7 + 7 outputs per
+//            tile from two row-local DPP shifts (row_shl:1, row_shl:2) on the vertically summed row.
+//            (Measured on the same box: the MFMA pool is 5 % faster than DPP for the stride-1 residual stage,
+//             7 % slower for the stride-2 stages, which pool only every other row.)
+constexpr int rw_tile_nout(int pk, int ps) { return pk ? (ps == 2 ? 14 : 32 - pk + 1) : 32; }
 constexpr int rw_tile_stride(int pk, int ps) { return pk ? rw_tile_nout(pk, ps) * ps : 32; }
 
 constexpr int RW_SKIPBUF = 3;   // staged skip-row pairs (residual): 1 being read + 2 in flight
@@ -68,7 +73,8 @@ struct RwCfg {
     // B operand -- no cross-lane movement at all, and H comes out in the usual cout-in-register /
     // pixel-on-lane layout for BN, residual and the stores.  Vertical pooling = fp32 pair sums before the
     // rounding, so a pooled row costs 4 MFMAs (2 pair-sum rows x K = 32) instead of 48 DPP instructions.
-    static constexpr bool POOLM = PK == 4;
+    static constexpr bool POOLM = PK == 4 && PS == 1;
+    static constexpr bool GAP = PK == 4 && PS == 2;            // gapped lane -> column map, DPP pooling (see rw_tile_nout)
     // KS = 3: the K dimension is split by kernel row over three waves per pixel tile (each keeps one
     // kernel row's weight fragments in registers); partial accumulators meet in LDS (K = 1152 stage)
     static constexpr int NTHREADS = 64 * NPT * CT * KS;
@@ -315,7 +321,8 @@ __global__ __launch_bounds__(64 * NPT * ((COUT + 31) / 32) * KS, 1) void stage_r
     for (int j = 0; j < RW_AHEAD; ++j) issue_row(min(j, nin - 1), j);
 
     // ---- lane constants of this wave's pixel tile
-    const int xrel0 = (C::PRIV ? 0 : pt * TSTRIDE) + r;      // ring column of conv column (tap kx = 0)
+    const int pm = C::GAP ? r - 2 * (r >> 4) : r;            // conv column of this lane inside the tile
+    const int xrel0 = (C::PRIV ? 0 : pt * TSTRIDE) + pm;     // ring column of conv column (tap kx = 0)
     int boff[3][CIN >= 16 ? CIN / 16 : 1];
     int b8_ky[CIN >= 16 ? 1 : KC], b8_off[CIN >= 16 ? 1 : KC];   // CIN == 8: per K-chunk tap row / offset
     if constexpr (CIN >= 16) {
@@ -334,9 +341,11 @@ __global__ __launch_bounds__(64 * NPT * ((COUT + 31) / 32) * KS, 1) void stage_r
             b8_off[kc] = (xrel0 + kx) * PIXB;
         }
     }
-    // output column of this lane: pooled tiles deliver window i of the tile on lane i (see POOLM)
-    const int xo = (PK ? (x0c + pt * TSTRIDE) / PS : x0c + pt * TSTRIDE) + r;
-    const bool lane_out = r < NOUT_T && xo < a.Wo && (xo - xo_blk0) < NPT * NOUT_T;
+    // output column of this lane: MFMA-pooled tiles deliver window i of the tile on lane i (see POOLM), gapped
+    // tiles the window that starts at the lane's own conv column
+    const int xo = C::GAP ? (x0c + pt * TSTRIDE + pm) / PS : (PK ? (x0c + pt * TSTRIDE) / PS : x0c + pt * TSTRIDE) + r;
+    const bool lane_win = C::GAP ? ((r & 1) == 0 && (r & 15) <= 12) : r < NOUT_T;   // a window of the tile ends up here
+    const bool lane_out = lane_win && xo < a.Wo && (xo - xo_blk0) < NPT * NOUT_T;
     const float* const ptab_lane = ptab + ct * 32 + 4 * hh;                                // + 8*g (+ table*COUT)
     f32x4 sc1r[NG], sh1r[NG], sc2r[NG], sh2r[NG];
     if constexpr (C::PTAB_REGS) {
@@ -448,9 +457,9 @@ __global__ __launch_bounds__(64 * NPT * ((COUT + 31) / 32) * KS, 1) void stage_r
     // ---- pooling state
     // vertical pair sums: q_j = v_{j-1} + v_j in fp32 (hprev = previous row), rounded to fp16 pairs;
     // a 4-row window is q_{j-2} + q_j (stride 1: q ring by row parity; stride 2: pairs of even/odd rows)
-    float hprev[16];
+    float hprev[16], q0f[16];    // q0f: fp32 pair-sum ring of the DPP (stride 2) variant
 #pragma unroll
-    for (int g = 0; g < 16; ++g) hprev[g] = 0.f;
+    for (int g = 0; g < 16; ++g) hprev[g] = q0f[g] = 0.f;
     i32x4 qp0[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}}, qp1[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
     // band matrix Pm[x][xo] as the pool MFMA's B operand: lane (xo = r, k-group hh), K slot (chunk c, j) is the
     // conv column held by accumulator register 8c + j of the transposed conv tile: x = (j & 3) + 8 (j >> 2) + 16 c + 4 hh
@@ -526,7 +535,8 @@ __global__ __launch_bounds__(64 * NPT * ((COUT + 31) / 32) * KS, 1) void stage_r
         return v;
     };
     // MFMA chain of one conv row over the K-chunks [KB, KB + KCW) (KB = 0 unless K is split)
-    auto mma_chain = [&](auto PC, auto KBC, f32x16& acc) __attribute__((always_inline)) {
+    // `slot(IC<I>)` runs right behind MFMA I: the epilogue micro-ops of that chain slot (see step())
+    auto mma_chain = [&](auto PC, auto KBC, f32x16& acc, auto&& slot) __attribute__((always_inline)) {
         constexpr int KB = decltype(KBC)::value;
         const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         i32x4 bq[KCW];
@@ -544,6 +554,7 @@ __global__ __launch_bounds__(64 * NPT * ((COUT + 31) / 32) * KS, 1) void stage_r
                          acc = mfma32<DT>(bq[I], wreg[I], I == 0 ? zero : acc);   // D'[pixel][cout]
                      else
                          acc = mfma32<DT>(wreg[I], bq[I], I == 0 ? zero : acc);   // D[cout][pixel]
+                     slot(IC<I>{});
                  }()),
                  ...);
             }(std::make_integer_sequence<int, KCW>{});
@@ -551,22 +562,23 @@ __global__ __launch_bounds__(64 * NPT * ((COUT + 31) / 32) * KS, 1) void stage_r
             bq[0] = b_frag(PC, IC<0>{});
             [&]<int... I>(std::integer_sequence<int, I...>) {
                 ((bq[I + 1 < KC ? I + 1 : 0] = (I + 1 < KC ? b_frag(PC, IC<(I + 1 < KC ? I + 1 : 0)>{}) : bq[0]),
-                  acc = C::POOLM ? mfma32<DT>(bq[I], wreg[I], I == 0 ? zero : acc) : mfma32<DT>(wreg[I], bq[I], I == 0 ? zero : acc)),
+                  acc = C::POOLM ? mfma32<DT>(bq[I], wreg[I], I == 0 ? zero : acc) : mfma32<DT>(wreg[I], bq[I], I == 0 ? zero : acc),
+                  slot(IC<I>{})),
                  ...);
             }(std::make_integer_sequence<int, KC>{});
         }
     };
-    auto mma_row = [&](auto PC, f32x16& acc) __attribute__((always_inline)) {
+    auto mma_row = [&](auto PC, f32x16& acc, auto&& slot) __attribute__((always_inline)) {
         if constexpr (KS == 1) {
-            mma_chain(PC, IC<0>{}, acc);
+            mma_chain(PC, IC<0>{}, acc, slot);
         } else {
             // wave-uniform dispatch on the kernel row: ring slot and tap offsets stay compile-time
             if (ks == 0)
-                mma_chain(PC, IC<0>{}, acc);
+                mma_chain(PC, IC<0>{}, acc, slot);
             else if (ks == 1)
-                mma_chain(PC, IC<KCW>{}, acc);
+                mma_chain(PC, IC<KCW>{}, acc, slot);
             else
-                mma_chain(PC, IC<2 * KCW>{}, acc);
+                mma_chain(PC, IC<2 * KCW>{}, acc, slot);
         }
     };
     // K split: LDS exchange of partial accumulators, double-buffered by step parity
@@ -616,177 +628,29 @@ __global__ __launch_bounds__(64 * NPT * ((COUT + 31) / 32) * KS, 1) void stage_r
         }
     };
 
-    // epilogue of conv row j (local index); JP = j mod RW_NSLOT (only its parity matters).
-    // Works on one group of 4 consecutive channels at a time (4 independent DPP chains in
-    // lockstep: short live ranges, and the VALU-write -> DPP-read hazard is covered).
-    auto epi_row = [&](auto JPC, const f32x16& acc, int j, int skip_buf) __attribute__((always_inline)) {
-        constexpr int JP = decltype(JPC)::value;
-        constexpr bool emit_phase = PK == 0 || PS == 1 || (JP & 1) == 1;
-        const bool emit = PK ? j >= 3 : true;
-        const int e = PK ? (j - 3) / PS : j;         // emitted output row (local)
-        const int yo = yo0 + e;
-        float yl = 0.f;
-        if constexpr (RES) {
-            const float src = static_cast<float>(yo) * a.rscale;
-            yl = src - static_cast<float>(static_cast<int>(src));
-        }
+    // transposed LDS reads of the staged skip pair (residual), then R_lo / R_hi = Skip_lo/hi^T * Wx
+    using TQ = i32x2[8];
+    auto res_issue = [&](int skip_buf, TQ& t) __attribute__((always_inline)) {
         const char* sk0 = skipb + skip_buf * C::SKIPBUFB;
         const char* sk1 = sk0 + skipbytes;
-        f32x16 r_lo, r_hi;
-        if constexpr (RES && emit_phase) {
-            const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            i32x2 t0 = tr_read(sk0 + a_off[0]), t1 = tr_read(sk0 + a_off[1]);
-            i32x2 t2 = tr_read(sk0 + a_off[2]), t3 = tr_read(sk0 + a_off[3]);
-            i32x2 t4 = tr_read(sk1 + a_off[0]), t5 = tr_read(sk1 + a_off[1]);
-            i32x2 t6 = tr_read(sk1 + a_off[2]), t7 = tr_read(sk1 + a_off[3]);
-            asm volatile("s_waitcnt lgkmcnt(0)"
-                         : "+v"(t0), "+v"(t1), "+v"(t2), "+v"(t3), "+v"(t4), "+v"(t5), "+v"(t6), "+v"(t7));
-            const i32x4 al0 = {t0[0], t0[1], t1[0], t1[1]}, al1 = {t2[0], t2[1], t3[0], t3[1]};
-            const i32x4 ah0 = {t4[0], t4[1], t5[0], t5[1]}, ah1 = {t6[0], t6[1], t7[0], t7[1]};
-            r_lo = mfma32<DT>(al0, bw_h[0], zero);
-            r_hi = mfma32<DT>(ah0, bw_h[0], zero);
-            r_lo = mfma32<DT>(al0, bw_l[0], r_lo);
-            r_hi = mfma32<DT>(ah0, bw_l[0], r_hi);
-            r_lo = mfma32<DT>(al1, bw_h[1], r_lo);
-            r_hi = mfma32<DT>(ah1, bw_h[1], r_hi);
-            r_lo = mfma32<DT>(al1, bw_l[1], r_lo);
-            r_hi = mfma32<DT>(ah1, bw_l[1], r_hi);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            t[q] = tr_read(sk0 + a_off[q]);
+            t[4 + q] = tr_read(sk1 + a_off[q]);
         }
-        f32x4 sc1v[NG], sh1v[NG], sc2v[NG], sh2v[NG];
-        if constexpr (emit_phase) {
-#pragma unroll
-            for (int g = 0; g < NG; ++g) {
-                if constexpr (C::PTAB_REGS) {
-                    sc1v[g] = sc1r[g];
-                    sh1v[g] = sh1r[g];
-                    if constexpr (RES) {
-                        sc2v[g] = sc2r[g];
-                        sh2v[g] = sh2r[g];
-                    }
-                } else if constexpr (!C::PTAB_LATE) {
-                    // one batch of LDS reads (a single wait) instead of a read + wait per channel group
-                    const float* pt_g = ptab_lane + 8 * g;
-                    sc1v[g] = *reinterpret_cast<const f32x4*>(pt_g);
-                    sh1v[g] = *reinterpret_cast<const f32x4*>(pt_g + COUT);
-                    if constexpr (RES) {
-                        sc2v[g] = *reinterpret_cast<const f32x4*>(pt_g + 2 * COUT);
-                        sh2v[g] = *reinterpret_cast<const f32x4*>(pt_g + 3 * COUT);
-                    }
-                }
-            }
-        }
-        // ---- ReLU6 + 4x4 window sums
-        f32x16 H;
-        if constexpr (C::POOLM) {
-            const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            float q[16];
-            if constexpr (PS == 1 || (JP & 1) == 1) {
-#pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const float v = relu6f(acc[i]);
-                    q[i] = hprev[i] + v;
-                    if constexpr (PS == 1) hprev[i] = v;
-                }
-                i32x4 qp[2];
-#pragma unroll
-                for (int c = 0; c < 2; ++c)
-#pragma unroll
-                    for (int d = 0; d < 4; ++d)
-                        qp[c][d] = static_cast<int>(pack2<RN_DTYPE_F16>(q[8 * c + 2 * d], q[8 * c + 2 * d + 1]));
-                // stride 1: window rows j-3..j = q_{j-2} + q_j, ring by parity; stride 2 (odd rows only): rows
-                // 2e..2e+3 = (pair of the previous odd row) + (this pair)
-                i32x4(&qold)[2] = (PS == 2 || (JP & 1) == 0) ? qp0 : qp1;
-                H = mfma32<RN_DTYPE_F16>(qold[0], pmw[0], zero);
-                H = mfma32<RN_DTYPE_F16>(qold[1], pmw[1], H);
-                H = mfma32<RN_DTYPE_F16>(qp[0], pmw[0], H);
-                H = mfma32<RN_DTYPE_F16>(qp[1], pmw[1], H);
-                qold[0] = qp[0];
-                qold[1] = qp[1];
-            } else {
-#pragma unroll
-                for (int i = 0; i < 16; ++i) hprev[i] = relu6f(acc[i]);
-            }
-        }
-        uint2 pk[4];
-#pragma unroll
-        for (int g = 0; g < NG; ++g) {
-            float S[4];
-#pragma unroll
-            for (int jj = 0; jj < 4; ++jj) S[jj] = C::POOLM ? H[4 * g + jj] : relu6f(acc[4 * g + jj]);
-            if constexpr (emit_phase) {
-#ifndef RN_ABL_TAB
-                if constexpr (C::PTAB_LATE) {
-                    // (the OFFSET is made opaque, not the pointer, so the access stays a DS read)
-                    int pt_off = 8 * g;
-                    asm volatile("" : "+v"(pt_off) : "v"(S[0]), "v"(S[3]));
-                    const float* pt_g = ptab_lane + pt_off;
-                    sc1v[g] = *reinterpret_cast<const f32x4*>(pt_g);
-                    sh1v[g] = *reinterpret_cast<const f32x4*>(pt_g + COUT);
-                    if constexpr (RES) {
-                        sc2v[g] = *reinterpret_cast<const f32x4*>(pt_g + 2 * COUT);
-                        sh2v[g] = *reinterpret_cast<const f32x4*>(pt_g + 3 * COUT);
-                    }
-                }
-#endif
-#ifdef RN_ABL_TAB
-                const f32x4 sc1 = {a.rscale, a.rscale, a.rscale, a.rscale}, sh1 = sc1;
-#else
-                const f32x4 sc1 = sc1v[g], sh1 = sh1v[g];
-#endif
-                float y[4];
-#pragma unroll
-                for (int jj = 0; jj < 4; ++jj) y[jj] = fmaf(S[jj], sc1[jj], sh1[jj]);
-                if constexpr (RES) {
-#ifdef RN_ABL_TAB
-                    const f32x4 sc2 = sc1, sh2 = sc1;
-#else
-                    const f32x4 sc2 = sc2v[g], sh2 = sh2v[g];
-#endif
-#pragma unroll
-                    for (int jj = 0; jj < 4; ++jj) {
-                        const float lo = r_lo[4 * g + jj];
-                        const float rs = lo + (r_hi[4 * g + jj] - lo) * yl;
-                        y[jj] = fmaf(y[jj] + rs, sc2[jj], sh2[jj]);
-                    }
-                }
-                pk[g] = pack4<DT>(y[0], y[1], y[2], y[3]);
-            }
-        }
-        if constexpr (emit_phase) {
-            // half-wave swap: lower half-wave gets channels 8k..8k+7, upper 8(k+1)..8(k+1)+7
-            i32x4 vv[2];
-#pragma unroll
-            for (int k = 0; k < NG; k += 2) {
-                const auto sx = __builtin_amdgcn_permlane32_swap(pk[k].x, pk[k + 1].x, false, false);
-                const auto sy = __builtin_amdgcn_permlane32_swap(pk[k].y, pk[k + 1].y, false, false);
-                vv[k / 2][0] = static_cast<int>(sx[0]);
-                vv[k / 2][1] = static_cast<int>(sy[0]);
-                vv[k / 2][2] = static_cast<int>(sx[1]);
-                vv[k / 2][3] = static_cast<int>(sy[1]);
-            }
-            if constexpr (C::STAGE_OUT) {
-                // transpose through the wave's staging tile, then lane-linear 16-byte stores.
-                // LDS operations of one wave execute in order: no barrier needed.  Inline asm keeps
-                // hipcc from guarding these DS ops with vmcnt(0) against the in-flight LDS-DMA.
-                // (lanes without an output write a pixel slot nobody reads: no predicate needed)
-                // (leading s_nop: the data registers were just written by v_permlane32_swap, and hipcc pads
-                //  no hazards between its own instructions and the inside of an asm string)
-                asm volatile("s_nop 1\n\tds_write_b128 %0, %1\n\ts_nop 1" ::"v"(st_w0), "v"(vv[0]) : "memory");
-                asm volatile("s_nop 1\n\tds_write_b128 %0, %1\n\ts_nop 1" ::"v"(st_w0 ^ 32u), "v"(vv[1]) : "memory");
-                i32x4 o0, o1;
-                asm volatile("ds_read_b128 %0, %1" : "=v"(o0) : "v"(st_r0) : "memory");
-                asm volatile("ds_read_b128 %0, %1 offset:1024" : "=v"(o1) : "v"(st_r0) : "memory");
-                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(o0), "+v"(o1));
-                const __amdgpu_buffer_rsrc_t rs = out_row_rsrc(yo);
-                __builtin_amdgcn_raw_buffer_store_b128(o0, rs, emit ? voff_st0 : OOB, 0, 0);
-                __builtin_amdgcn_raw_buffer_store_b128(o1, rs, emit ? voff_st1 : OOB, 0, 0);
-            } else {
-                const __amdgpu_buffer_rsrc_t rs = out_row_rsrc(yo);
-                const int vo = emit ? voff_lane : OOB;
-#pragma unroll
-                for (int k = 0; k < NG; k += 2) __builtin_amdgcn_raw_buffer_store_b128(vv[k / 2], rs, vo + 16 * k, 0, 0);
-            }
-        }
+    };
+    auto res_mfma = [&](const TQ& t, f32x16& r_lo, f32x16& r_hi) __attribute__((always_inline)) {
+        const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        const i32x4 al0 = {t[0][0], t[0][1], t[1][0], t[1][1]}, al1 = {t[2][0], t[2][1], t[3][0], t[3][1]};
+        const i32x4 ah0 = {t[4][0], t[4][1], t[5][0], t[5][1]}, ah1 = {t[6][0], t[6][1], t[7][0], t[7][1]};
+        r_lo = mfma32<DT>(al0, bw_h[0], zero);
+        r_hi = mfma32<DT>(ah0, bw_h[0], zero);
+        r_lo = mfma32<DT>(al0, bw_l[0], r_lo);
+        r_hi = mfma32<DT>(ah0, bw_l[0], r_hi);
+        r_lo = mfma32<DT>(al1, bw_h[1], r_lo);
+        r_hi = mfma32<DT>(ah1, bw_h[1], r_hi);
+        r_lo = mfma32<DT>(al1, bw_l[1], r_lo);
+        r_hi = mfma32<DT>(ah1, bw_l[1], r_hi);
     };
 
     // skip-pair bookkeeping: the pair for local output row e lives in buffer (e + 3k) mod 3
@@ -795,17 +659,198 @@ __global__ __launch_bounds__(64 * NPT * ((COUT + 31) / 32) * KS, 1) void stage_r
     int sbuf_issue = PS == 1 ? 1 : 2;
     int sbuf_read = PS == 1 ? 0 : 2;
 
-    // one pipeline step s (ring phase P = s mod RW_NSLOT): DMA for row s+RW_AHEAD, MFMAs of conv
-    // row s, epilogue of conv row s-1, counted wait, barrier
 #ifdef RN_STAMPS
     unsigned long long st_work = 0, st_dma = 0, st_bar = 0, st_chain = 0;
 #endif
+    // One pipeline step s (ring phase P = s mod RW_NSLOT): DMA for row s+RW_AHEAD, MFMA chain of conv row s,
+    // epilogue of conv row s-1, counted wait, barrier.
+    //
+    // The epilogue is cut into micro-ops and micro-op k runs right behind chain MFMA floor(k * KCW / NM) -- in
+    // SOURCE order, pinned by sched_barrier(0).  Explicit placement instead of scheduler hints because the
+    // epilogue has MFMAs of its own (pooling, residual) in the middle of its dependency chain
+    // (ReLU/pair sums -> pool MFMAs -> BN -> stores): left to sched_group_barrier they ended up behind the
+    // whole conv chain, and everything after them ran un-overlapped.  A wave issues one instruction per ~4-5
+    // cycles whatever its kind (tools/ubench/mfma_valu_overlap.hip), so each slot between two dependent
+    // 32-cycle MFMAs holds ~6 of them (12 with two waves per SIMD taking turns on the matrix pipe).
     auto step = [&](auto PC, auto MMAC, auto EPIC, int s) __attribute__((always_inline)) {
         constexpr int P = decltype(PC)::value;
 #ifdef RN_STAMPS
         const unsigned long long ts0 = stamp();
 #endif
         constexpr bool MMA = decltype(MMAC)::value != 0, EPI = decltype(EPIC)::value != 0;
+        constexpr int JP = (P + RW_NSLOT - 1) % RW_NSLOT;                     // phase of conv row s-1 (the epilogue's row)
+        constexpr bool emit_phase = PK == 0 || PS == 1 || (JP & 1) == 1;
+        constexpr bool RESW = RES && EPI && emit_phase;                        // this step adds a residual row
+        f32x16& acc_new = (P & 1) == 0 ? acc0 : acc1;
+        f32x16& acc_old = (P & 1) == 0 ? acc1 : acc0;
+        const int j = s - 1;                         // conv row of the epilogue (local)
+        const bool emit = PK ? j >= 3 : true;
+        const int yo = yo0 + (PK ? (j - 3) / PS : j);   // emitted output row
+        float yl = 0.f;
+        if constexpr (RESW) {
+            const float src = static_cast<float>(yo) * a.rscale;
+            yl = src - static_cast<float>(static_cast<int>(src));
+        }
+        // ---- state of this row's epilogue, shared by its micro-ops
+        TQ tq;
+        f32x16 H, r_lo, r_hi;
+        float q[16];
+        i32x4 qp[2];
+        uint2 pk[4];
+        // micro-op list: residual reads | 8 x front (2 accumulator registers each) | residual MFMAs | pool MFMAs |
+        // 2 idle (MFMA latency) | 2 x NG BN halves (2 channels each) | swaps + stores
+        constexpr int M_RES_RD = 0, M_FRONT = 1, NF = 8, M_RES_MM = M_FRONT + NF, M_POOL = M_RES_MM + 1, M_BN = M_POOL + 3,
+                      M_STORE = M_BN + 2 * NG, NM = M_STORE + 1;
+        float yv[16];
+        const bool epi_wave = KS == 1 || ks == 0;        // K split: only the wave of kernel row 0 owns the epilogue
+        // explicit placement where the epilogue has MFMAs of its own; the plain VALU epilogue of the stride-2
+        // non-residual stage does better under hipcc's own interleave (sched_group_barrier hints): 0.375 vs 0.39 ms
+        constexpr bool SLICED = KS == 1 && !(C::GAP && !RES);
+        auto mop = [&](auto KK) __attribute__((always_inline)) {
+            constexpr int k = decltype(KK)::value;
+            if constexpr (k == M_RES_RD) {
+                if constexpr (KS > 1) part_add((P + 1) & 1, acc_old);
+                if constexpr (RESW) res_issue(sbuf_read, tq);
+            } else if constexpr (k >= M_FRONT && k < M_FRONT + NF) {
+                if constexpr (C::GAP) {
+                    // stride 2, DPP variant: windows start at even conv rows and end at odd rows j = 2e + 3; the odd
+                    // rows sum vertically first, then run the horizontal half on the 4-row sums
+                    constexpr int i2 = 2 * (k - M_FRONT);
+                    if constexpr ((JP & 1) == 1) {
+                        float t[2], u[2];
+#pragma unroll
+                        for (int jj = 0; jj < 2; ++jj) {
+                            const float pq = hprev[i2 + jj] + relu6f(acc_old[i2 + jj]);
+                            t[jj] = q0f[i2 + jj] + pq;
+                            q0f[i2 + jj] = pq;
+                        }
+#pragma unroll
+                        for (int jj = 0; jj < 2; ++jj) u[jj] = t[jj] + row_next<1>(t[jj]);
+#pragma unroll
+                        for (int jj = 0; jj < 2; ++jj) H[i2 + jj] = u[jj] + row_next<2>(u[jj]);
+                    } else {
+#pragma unroll
+                        for (int i = i2; i < i2 + 2; ++i) hprev[i] = relu6f(acc_old[i]);
+                    }
+                }
+                // ReLU6 + vertical pair sums of accumulator registers 4i .. 4i+3, rounded to two fp16 pairs
+                if constexpr (C::POOLM) {
+                    constexpr int i2 = 2 * (k - M_FRONT);
+#pragma unroll
+                    for (int i = i2; i < i2 + 2; ++i) {
+                        const float v = relu6f(acc_old[i]);
+                        q[i] = hprev[i] + v;
+                        hprev[i] = v;
+                    }
+                    qp[i2 / 8][(i2 % 8) / 2] = static_cast<int>(pack2<RN_DTYPE_F16>(q[i2], q[i2 + 1]));
+                }
+            } else if constexpr (k == M_RES_MM) {
+                if constexpr (RESW) {
+                    // the transposed reads were issued a few chain waits ago: LDS returns in order, they have landed
+                    if constexpr (!MMA) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    asm volatile("" : "+v"(tq[0]), "+v"(tq[1]), "+v"(tq[2]), "+v"(tq[3]), "+v"(tq[4]), "+v"(tq[5]), "+v"(tq[6]), "+v"(tq[7]));
+                    res_mfma(tq, r_lo, r_hi);
+                }
+            } else if constexpr (k == M_POOL) {
+                if constexpr (C::POOLM && (PS == 1 || (JP & 1) == 1)) {
+                    // stride 1: window rows j-3..j = q_{j-2} + q_j, ring by parity; stride 2 (odd rows only): rows
+                    // 2e..2e+3 = (pair of the previous odd row) + (this pair)
+                    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                    i32x4(&qold)[2] = (PS == 2 || (JP & 1) == 0) ? qp0 : qp1;
+                    H = mfma32<RN_DTYPE_F16>(qold[0], pmw[0], zero);
+                    H = mfma32<RN_DTYPE_F16>(qold[1], pmw[1], H);
+                    H = mfma32<RN_DTYPE_F16>(qp[0], pmw[0], H);
+                    H = mfma32<RN_DTYPE_F16>(qp[1], pmw[1], H);
+                    qold[0] = qp[0];
+                    qold[1] = qp[1];
+                }
+            } else if constexpr (k >= M_BN && k < M_BN + 2 * NG) {
+                if constexpr (emit_phase) {
+                    constexpr int g = (k - M_BN) / 2, h2 = (k - M_BN) % 2;    // channel group, half (channels 2 h2, 2 h2 + 1)
+                    f32x4 sc1, sh1, sc2, sh2;
+                    if constexpr (C::PTAB_REGS) {
+                        sc1 = sc1r[g];
+                        sh1 = sh1r[g];
+                        if constexpr (RES) {
+                            sc2 = sc2r[g];
+                            sh2 = sh2r[g];
+                        }
+                    } else {
+                        const float* pt_g = ptab_lane + 8 * g;
+                        sc1 = *reinterpret_cast<const f32x4*>(pt_g);
+                        sh1 = *reinterpret_cast<const f32x4*>(pt_g + COUT);
+                        if constexpr (RES) {
+                            sc2 = *reinterpret_cast<const f32x4*>(pt_g + 2 * COUT);
+                            sh2 = *reinterpret_cast<const f32x4*>(pt_g + 3 * COUT);
+                        }
+                    }
+#pragma unroll
+                    for (int jj = 2 * h2; jj < 2 * h2 + 2; ++jj) {
+                        const float S = PK ? H[4 * g + jj] : relu6f(acc_old[4 * g + jj]);
+                        float y = fmaf(S, sc1[jj], sh1[jj]);
+                        if constexpr (RES) {
+                            const float lo = r_lo[4 * g + jj];
+                            const float rs = lo + (r_hi[4 * g + jj] - lo) * yl;
+                            y = fmaf(y + rs, sc2[jj], sh2[jj]);
+                        }
+                        yv[4 * g + jj] = y;
+                    }
+                    if constexpr (h2 == 0)
+                        pk[g].x = pack2<DT>(yv[4 * g], yv[4 * g + 1]);
+                    else
+                        pk[g].y = pack2<DT>(yv[4 * g + 2], yv[4 * g + 3]);
+                }
+            } else if constexpr (k == M_STORE) {
+                if constexpr (emit_phase) {
+                    // half-wave swap: lower half-wave gets channels 8k..8k+7, upper 8(k+1)..8(k+1)+7
+                    i32x4 vv[2];
+#pragma unroll
+                    for (int kk = 0; kk < NG; kk += 2) {
+                        const auto sx = __builtin_amdgcn_permlane32_swap(pk[kk].x, pk[kk + 1].x, false, false);
+                        const auto sy = __builtin_amdgcn_permlane32_swap(pk[kk].y, pk[kk + 1].y, false, false);
+                        vv[kk / 2][0] = static_cast<int>(sx[0]);
+                        vv[kk / 2][1] = static_cast<int>(sy[0]);
+                        vv[kk / 2][2] = static_cast<int>(sx[1]);
+                        vv[kk / 2][3] = static_cast<int>(sy[1]);
+                    }
+                    const __amdgpu_buffer_rsrc_t rs = out_row_rsrc(yo);
+                    if constexpr (C::STAGE_OUT) {
+                        // transpose through the wave's staging tile, then lane-linear 16-byte stores.
+                        // LDS operations of one wave execute in order: no barrier needed.  Inline asm keeps
+                        // hipcc from guarding these DS ops with vmcnt(0) against the in-flight LDS-DMA.
+                        // (lanes without an output write a pixel slot nobody reads: no predicate needed)
+                        // (leading s_nop: the data registers were just written by v_permlane32_swap, and hipcc pads
+                        //  no hazards between its own instructions and the inside of an asm string)
+                        asm volatile("s_nop 1\n\tds_write_b128 %0, %1\n\ts_nop 1" ::"v"(st_w0), "v"(vv[0]) : "memory");
+                        asm volatile("s_nop 1\n\tds_write_b128 %0, %1\n\ts_nop 1" ::"v"(st_w0 ^ 32u), "v"(vv[1]) : "memory");
+                        i32x4 o0, o1;
+                        asm volatile("ds_read_b128 %0, %1" : "=v"(o0) : "v"(st_r0) : "memory");
+                        asm volatile("ds_read_b128 %0, %1 offset:1024" : "=v"(o1) : "v"(st_r0) : "memory");
+                        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(o0), "+v"(o1));
+                        __builtin_amdgcn_raw_buffer_store_b128(o0, rs, emit ? voff_st0 : OOB, 0, 0);
+                        __builtin_amdgcn_raw_buffer_store_b128(o1, rs, emit ? voff_st1 : OOB, 0, 0);
+                    } else {
+                        const int vo = emit ? voff_lane : OOB;
+#pragma unroll
+                        for (int kk = 0; kk < NG; kk += 2)
+                            __builtin_amdgcn_raw_buffer_store_b128(vv[kk / 2], rs, vo + 16 * kk, 0, 0);
+                    }
+                }
+            }
+        };
+        // micro-ops of chain slot I (the ones with floor(k * KCW / NM) == I)
+        auto slot = [&](auto II) __attribute__((always_inline)) {
+            constexpr int I = decltype(II)::value;
+            if constexpr (EPI && SLICED) {
+                [&]<int... K>(std::integer_sequence<int, K...>) {
+                    (([&] {
+                         if constexpr (K * KCW / NM == I) mop(IC<K>{});
+                     }()),
+                     ...);
+                }(std::make_integer_sequence<int, NM>{});
+            }
+            if constexpr (SLICED) __builtin_amdgcn_sched_barrier(0);
+        };
         if constexpr (MMA) {
             // (past the end of the band the last row is fetched again into a free slot: the number of
             //  DMA pieces per step stays constant, so the counted waits and the code path do too)
@@ -820,41 +865,32 @@ __global__ __launch_bounds__(64 * NPT * ((COUT + 31) / 32) * KS, 1) void stage_r
 #if defined(RN_STAMPS) && defined(RN_STAMP_CHAIN)
             const unsigned long long tc0 = stamp();
 #endif
-            if constexpr ((P & 1) == 0)
-                mma_row(PC, acc0);
-            else
-                mma_row(PC, acc1);
+            mma_row(PC, acc_new, slot);
 #if defined(RN_STAMPS) && defined(RN_STAMP_CHAIN)
             st_chain += stamp() - tc0;
 #endif
             if constexpr (KS > 1) {
                 // waves of kernel rows 1, 2 publish their partial sums for the epilogue of the next step
-                if (ks > 0) part_write(P & 1, (P & 1) == 0 ? acc0 : acc1);
+                if (ks > 0) part_write(P & 1, acc_new);
             }
         }
-        if constexpr (EPI) {
-            if (KS == 1 || ks == 0) {        // K split: only the wave of kernel row 0 owns the epilogue
-                if constexpr ((P & 1) == 0) {
-                    if constexpr (KS > 1) part_add((P + 1) & 1, acc1);
-                    epi_row(IC<(P + RW_NSLOT - 1) % RW_NSLOT>{}, acc1, s - 1, sbuf_read);
-                } else {
-                    if constexpr (KS > 1) part_add((P + 1) & 1, acc0);
-                    epi_row(IC<(P + RW_NSLOT - 1) % RW_NSLOT>{}, acc0, s - 1, sbuf_read);
-                }
+        if constexpr (EPI && (!MMA || !SLICED)) {
+            // drain step (no chain to hang the micro-ops on), or the K-split variant (three chain bodies, only
+            // the wave of kernel row 0 finishes rows): the whole epilogue in one piece
+            if (epi_wave) {
+                [&]<int... K>(std::integer_sequence<int, K...>) { (mop(IC<K>{}), ...); }(std::make_integer_sequence<int, NM>{});
             }
         }
-        // the epilogue of this step handled conv row s-1 (phase parity (P+1)&1): rotate after an emit phase
-        if constexpr (RES && EPI && (PS == 1 || ((P + 1) & 1) == 1))
-            sbuf_read = sbuf_read == RW_SKIPBUF - 1 ? 0 : sbuf_read + 1;
-        if constexpr (MMA && EPI) {
-            // software pipeline: spread the VALU epilogue of row s-1 through the MFMA chain of row s
-            constexpr int VPG = RES ? 10 : 8;
+        if constexpr (MMA && EPI && !SLICED && KS == 1) {
+            // software pipeline by hint: spread the VALU epilogue of row s-1 through the MFMA chain of row s
 #pragma unroll
-            for (int i = 0; i < KC + (C::POOLM ? 4 : 0) + (RES ? 8 : 0); ++i) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     // one MFMA
-                __builtin_amdgcn_sched_group_barrier(0x002, VPG, 0);   // VALU
+            for (int i = 0; i < KCW; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // one MFMA
+                __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);   // VALU
             }
         }
+        // the epilogue of this step handled conv row s-1: rotate the skip buffers after an emit phase
+        if constexpr (RESW) sbuf_read = sbuf_read == RW_SKIPBUF - 1 ? 0 : sbuf_read + 1;
 #ifdef RN_STAMPS
         const unsigned long long ts1 = stamp();
 #endif
