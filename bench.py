@@ -48,20 +48,21 @@ def stage_bytes_per_image(graph, elem_bytes):
 
 
 def measured_traffic(stage, batch, side, dtype):
-    """HBM bytes per launch of `stage` from the committed rocprofv3 PMC passes (profiles/), or None
-    when no profile matches this configuration.  bench.py cannot profile itself: the counters are
-    collected by running this same command under `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE`."""
-    path = os.path.join(ROOT, "profiles", "r1_h_hbm_traffic.json")
-    try:
-        with open(path) as f:
-            t = json.load(f)
-    except (OSError, ValueError):
-        return None
-    if (t.get("batch"), t.get("im_side"), t.get("dtype")) != (batch, side, dtype):
-        return None
-    for st in t.get("stages", []):
-        if st.get("stage") == stage:
-            return int(st["traffic_bytes"])
+    """HBM bytes per launch of `stage` from the newest committed rocprofv3 PMC passes (profiles/*_hbm_traffic.json,
+    built by tools/hbm_traffic.py from `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of this same command), or None
+    when no profile matches this configuration.  bench.py cannot profile itself."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_hbm_traffic.json")), reverse=True):
+        try:
+            with open(path) as f:
+                t = json.load(f)
+        except (OSError, ValueError):
+            continue
+        if (t.get("batch"), t.get("im_side"), t.get("dtype")) != (batch, side, dtype):
+            continue
+        for st in t.get("stages", []):
+            if st.get("stage") == stage:
+                return int(st["traffic_bytes"])
     return None
 
 
