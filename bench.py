@@ -100,6 +100,9 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-steps", type=int, default=5)
+    ap.add_argument("--pcie", action="store_true",
+                    help="also time the host-buffer entry point (rn_forward_u8: H2D copy + forward + D2H copy); reported as "
+                         "path.pcie_inclusive_images_per_sec, never as `value`")
     args = ap.parse_args()
 
     import torch
@@ -189,6 +192,15 @@ def main():
     head_ms /= nprof
     total_ms /= nprof
 
+    pcie_rate = None
+    if args.pcie and world == 1:
+        host_ims = perf_batch(B, args.side, seed=rank)
+        eng.forward_u8(host_ims)
+        t1 = time.perf_counter()
+        for _ in range(max(3, args.steps // 4)):
+            eng.forward_u8(host_ims)
+        pcie_rate = B * max(3, args.steps // 4) / (time.perf_counter() - t1)
+
     if rank == 0:
         elem = 4 if args.dtype == "f32" else 2
         sbytes = stage_bytes_per_image(graph, elem)
@@ -225,6 +237,8 @@ def main():
                      "stage_hbm_frac": [float(sbytes[k] * B / (stage_ms[k] * 1e-3) / HBM_PEAK)
                                         for k in range(len(sbytes))]},
         }
+        if pcie_rate is not None:
+            out["path"]["pcie_inclusive_images_per_sec"] = pcie_rate
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(weights, args.side)
         print(json.dumps(out), flush=True)

@@ -102,6 +102,58 @@ def test_timing(engine, parity_images):
     assert len(t["stage_ms"]) == 10 and all(x > 0 for x in t["stage_ms"])
 
 
+# ------------------------------------------------------------------ full size (BASELINE configs 3/4: batch 256)
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+def test_full_batch_256_properties(weights, parity_images, golden_parity, dtype):
+    """Batch 256 (the bench configuration: one band per image, two workgroup rounds per CU) through
+    size-independent properties: (1) every image's result equals, bit for bit, the result the same image
+    gets in a batch of 8 (which the tests above pin to the oracle); (2) a permuted batch gives the permuted
+    results; (3) a second pass over the same buffers is identical (no state leaks between launches)."""
+    rng = np.random.default_rng(256)
+    pick = rng.integers(0, len(parity_images), 256)
+    ims = parity_images[pick]
+    big = _capi.Engine(build_graph(6, 224), weights, device=0, dtype=dtype, max_batch=256)
+    small = _capi.Engine(build_graph(6, 224), weights, device=0, dtype=dtype, max_batch=8)
+    try:
+        ids, probs = big.forward_u8(ims)
+        s7 = big.tap("s7.bn", 256)
+        ids8, probs8 = small.forward_u8(parity_images)          # 40 images in chunks of 8
+        np.testing.assert_array_equal(probs, probs8[pick])
+        np.testing.assert_array_equal(ids, ids8[pick])
+        safe = golden_parity["top2_margin"][pick] > MARGIN
+        np.testing.assert_array_equal(ids[safe], golden_parity["ids"][pick][safe])
+        perm = rng.permutation(256)
+        ids_p, probs_p = big.forward_u8(ims[perm])
+        np.testing.assert_array_equal(probs_p, probs[perm])
+        np.testing.assert_array_equal(big.tap("s7.bn", 256), s7[perm])
+        ids_2, probs_2 = big.forward_u8(ims[perm])
+        np.testing.assert_array_equal(probs_2, probs_p)
+        # ragged tail: 255 and 1 images through the 256-image handle
+        ids_r, probs_r = big.forward_u8(ims[:255])
+        np.testing.assert_array_equal(probs_r, probs[:255])
+        ids_1, probs_1 = big.forward_u8(ims[255:])
+        np.testing.assert_array_equal(probs_1, probs[255:])
+    finally:
+        big.close()
+        small.close()
+
+
+def test_batch_limits(engine):
+    """Empty and over-size batches follow the error convention instead of launching."""
+    buf = np.zeros((engine.max_batch + 1, 224, 224, 3), np.uint8)
+    probs = np.zeros((engine.max_batch + 1, 6), np.float32)
+    ids = np.zeros((engine.max_batch + 1,), np.int64)
+    for n in (0, -1, engine.max_batch + 1):
+        rc = engine.lib.rn_forward_u8(engine.handle, buf.ctypes.data, n, probs.ctypes.data, ids.ctypes.data)
+        assert rc < 0, n
+        assert b"out of range" in engine.lib.rn_last_error()
+    # the Python layer splits an over-size batch into max_batch chunks instead
+    ids2, probs2 = engine.forward_u8(buf[:engine.max_batch + 1])
+    assert probs2.shape == (engine.max_batch + 1, 6) and np.allclose(probs2.sum(1), 1.0, atol=1e-5)
+    ids0, probs0 = engine.forward_u8(buf[:0])
+    assert probs0.shape == (0, 6) and ids0.shape == (0,)
+
+
 # ------------------------------------------------------------------ 600x600 variant (BASELINE config 5)
 @pytest.mark.parametrize("dtype,tol", [("f16", 0.1), ("bf16", 0.1), ("f32", 1e-4)])
 def test_600_variant_vs_golden(weights, dtype, tol):
