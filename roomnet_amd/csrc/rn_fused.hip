@@ -484,11 +484,13 @@ using LaunchFn = int (*)(hipStream_t, const StageArgs&, dim3, dim3, size_t);
 template <int DT, int CIN, int COUT, int PK, int PS, bool RES, int CTW>
 int launch_variant(hipStream_t s, const StageArgs& a, dim3 grid, dim3 block, size_t lds) {
     auto kern = stage_mfma_kernel<DT, CIN, COUT, PK, PS, RES, CTW>;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static unsigned long long attr_devices = 0;     // per device, see launch_rw
+    int dev = 0;
+    RN_HIP(hipGetDevice(&dev));
+    if (!(attr_devices >> (dev & 63) & 1ull)) {
         RN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                    160 * 1024));
-        attr_set = true;
+        attr_devices |= 1ull << (dev & 63);
     }
     hipLaunchKernelGGL(kern, grid, block, lds, s, a);
     RN_CHECK_LAUNCH();

@@ -151,10 +151,28 @@ __global__ __launch_bounds__(64) void head_kernel(const void* __restrict__ flat,
                                                   float* __restrict__ probs, int64_t* __restrict__ ids) {
     __shared__ float buf0[HEAD_MAX_FLAT];
     __shared__ float small[2][64];
+    // dense kernels staged in LDS with coalesced, independent loads (all layers that fit): read from global
+    // inside the k loop, the 64 + 32 + 16 + 8 dependent steps each paid an L2 round trip (40 us per launch)
+    constexpr int HEAD_W_LDS = 3072;
+    __shared__ float wl[HEAD_W_LDS];
     const int img = blockIdx.x;
     const int lane = threadIdx.x;
     const int nin0 = a.nin[0];
     for (int i = lane; i < nin0; i += 64) buf0[i] = load_as_f32(flat, flat_dtype, static_cast<int64_t>(img) * nin0 + i);
+    int w_off[RN_MAX_DENSE];
+    {
+        int off = 0;
+        for (int d = 0; d < a.n_dense; ++d) {
+            const int cnt = a.nin[d] * a.nout[d];
+            if (off + cnt <= HEAD_W_LDS) {
+                w_off[d] = off;
+                for (int i = lane; i < cnt; i += 64) wl[off + i] = a.w[d][i];
+                off += cnt;
+            } else {
+                w_off[d] = -1;
+            }
+        }
+    }
     __syncthreads();
     const float* cur = buf0;
     for (int d = 0; d < a.n_dense; ++d) {
@@ -162,7 +180,7 @@ __global__ __launch_bounds__(64) void head_kernel(const void* __restrict__ flat,
         float* dst = small[d & 1];
         if (lane < nout) {
             float v = 0.f;
-            const float* wd = a.w[d];
+            const float* wd = w_off[d] >= 0 ? wl + w_off[d] : a.w[d];
             for (int k = 0; k < nin; ++k) v = fmaf(cur[k], wd[k * nout + lane], v);
             if (a.bias[d]) v = __fadd_rn(v, a.bias[d][lane]);
             if (a.tap_mm[d]) a.tap_mm[d][static_cast<int64_t>(img) * nout + lane] = v;

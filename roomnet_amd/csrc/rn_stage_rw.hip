@@ -944,11 +944,15 @@ template <int DT, int CIN, int COUT, int PK, int PS, bool RES, int NPT, int KS =
 int launch_rw(hipStream_t s, const StageArgs& a, dim3 grid) {
     using C = RwCfg<DT, CIN, COUT, PK, PS, RES, NPT, KS>;
     auto kern = stage_rw_kernel<DT, CIN, COUT, PK, PS, RES, NPT, KS>;
-    static bool attr_set = false;
-    if (!attr_set) {
+    // the attribute is per device: remember which devices of this process have it (one handle per GPU per process
+    // is the normal deployment, several handles on several GPUs in one process must work too)
+    static unsigned long long attr_devices = 0;
+    int dev = 0;
+    RN_HIP(hipGetDevice(&dev));
+    if (!(attr_devices >> (dev & 63) & 1ull)) {
         RN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                    160 * 1024));
-        attr_set = true;
+        attr_devices |= 1ull << (dev & 63);
     }
     hipLaunchKernelGGL(kern, grid, dim3(C::NTHREADS), C::LDS_BYTES, s, a);
     RN_CHECK_LAUNCH();
