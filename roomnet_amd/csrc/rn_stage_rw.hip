@@ -47,6 +47,9 @@ typedef __attribute__((address_space(3))) void* lds_void_ptr;
 constexpr int rw_tile_nout(int pk, int ps) { return pk ? (ps == 2 ? 14 : 32 - pk + 1) : 32; }
 constexpr int rw_tile_stride(int pk, int ps) { return pk ? rw_tile_nout(pk, ps) * ps : 32; }
 
+#ifndef RN_SPREAD_DMA
+#define RN_SPREAD_DMA 1
+#endif
 constexpr int RW_SKIPBUF = 3;   // staged skip-row pairs (residual): 1 being read + 2 in flight
 
 template <int DT, int CIN, int COUT, int PK, int PS, bool RES, int NPT, int KS = 1>
@@ -260,21 +263,22 @@ __global__ __launch_bounds__(64 * NPT * ((COUT + 31) / 32) * KS, 1) void stage_r
     // private ring: active lanes of the last (partial) piece of a row
     constexpr int TAIL_LANES = C::PRIV ? RINGCOLS * CP - (LPT - 1) * 64 : 64;
     constexpr unsigned long long tail_mask = TAIL_LANES >= 64 ? ~0ull : ((1ull << TAIL_LANES) - 1ull);
-    auto issue_row = [&](int j, int slot) __attribute__((always_inline)) {               // input row yc0 + j -> ring slot
+    // piece i of input row yc0 + j -> ring slot
+    auto issue_row_piece = [&](auto II, int j, int slot) __attribute__((always_inline)) {
+        constexpr int i = decltype(II)::value;
         const char* row = in_img + static_cast<int64_t>(yc0 + j) * in_row_bytes;
+        if constexpr (C::PRIV) {
+            if constexpr ((i + 1) * 64 <= RINGCOLS * CP)
+                dma16(row + ld_goff[i], ring + slot * ROWB + i * 64 * 16);
+            else
+                dma16_masked(row + ld_goff[i], ring + slot * ROWB + i * 64 * 16, tail_mask);
+        } else {
+            dma16(row + ld_goff[i], ring + slot * ROWB + i * NTHREADS * 16 + piece_base);
+        }
+    };
+    auto issue_row = [&](int j, int slot) __attribute__((always_inline)) {
         [&]<int... II>(std::integer_sequence<int, II...>) {
-            (([&] {
-                 constexpr int i = II;
-            if constexpr (C::PRIV) {
-                if constexpr ((i + 1) * 64 <= RINGCOLS * CP)
-                    dma16(row + ld_goff[i], ring + slot * ROWB + i * 64 * 16);
-                else
-                    dma16_masked(row + ld_goff[i], ring + slot * ROWB + i * 64 * 16, tail_mask);
-            } else {
-                dma16(row + ld_goff[i], ring + slot * ROWB + i * NTHREADS * 16 + piece_base);
-            }
-             }()),
-             ...);
+            (issue_row_piece(IC<II>{}, j, slot), ...);
         }(std::make_integer_sequence<int, LPT>{});
     };
 
@@ -299,6 +303,19 @@ __global__ __launch_bounds__(64 * NPT * ((COUT + 31) / 32) * KS, 1) void stage_r
             sk_hi[i] = row != 0;
         }
     }
+    // piece i of the skip-row pair of local output row e -> buffer
+    auto issue_skip_piece = [&](auto II, int e, int buf) __attribute__((always_inline)) {
+        constexpr int i = decltype(II)::value;
+        if constexpr (RES) {
+            const int yo = yo0 + min(max(e, 0), nout_rows - 1);
+            const float src = static_cast<float>(yo) * a.rscale;
+            const int ylo = static_cast<int>(src);
+            const int yhi = min(ylo + 1, a.Ss - 1);
+            const char* r0 = skip_img + static_cast<int64_t>(ylo) * skip_row_bytes;
+            const unsigned hi_delta = static_cast<unsigned>((yhi - ylo) * skip_row_bytes);
+            dma16(r0 + (sk_goff[i] + (sk_hi[i] ? hi_delta : 0u)), skipb + buf * C::SKIPBUFB + i * NTHREADS * 16 + piece_base);
+        }
+    };
     auto issue_skip = [&](int e, int buf) __attribute__((always_inline)) {               // skip rows of local output row e -> buffer
         if constexpr (RES) {
             const int yo = yo0 + min(max(e, 0), nout_rows - 1);
@@ -839,8 +856,29 @@ __global__ __launch_bounds__(64 * NPT * ((COUT + 31) / 32) * KS, 1) void stage_r
             }
         };
         // micro-ops of chain slot I (the ones with floor(k * KCW / NM) == I)
+        // DMA pieces of this step (input row s + AHEAD, then the skip pair), spread over the chain slots: issued in
+        // one burst at the top of the step -- every wave of the CU at once, next to the burst of fragment reads --
+        // each global_load_lds held its wave for 100+ cycles
+        constexpr bool SKIPW = RES && MMA && (PS == 1 || (P & 1) == 0);         // this step issues a skip pair
+        constexpr int NPIECE = LPT + (SKIPW ? SLPT : 0);
+        constexpr int DSTEP = (KCW - 1) / NPIECE >= 1 ? (KCW - 1) / NPIECE : 1;
+        const int sbuf_now = sbuf_issue;
         auto slot = [&](auto II) __attribute__((always_inline)) {
             constexpr int I = decltype(II)::value;
+            if constexpr (MMA && RN_SPREAD_DMA) {
+                [&]<int... PI>(std::integer_sequence<int, PI...>) {
+                    (([&] {
+                         constexpr int at = PI * DSTEP < KCW ? PI * DSTEP : KCW - 1;
+                         if constexpr (at == I) {
+                             if constexpr (PI < LPT)
+                                 issue_row_piece(IC<PI>{}, min(s + RW_AHEAD, nin - 1), (P + RW_AHEAD) % RW_NSLOT);
+                             else
+                                 issue_skip_piece(IC<(PI < LPT ? 0 : PI - LPT)>{}, (s - 2) / PS, sbuf_now);
+                         }
+                     }()),
+                     ...);
+                }(std::make_integer_sequence<int, NPIECE>{});
+            }
             if constexpr (EPI && SLICED) {
                 [&]<int... K>(std::integer_sequence<int, K...>) {
                     (([&] {
@@ -854,12 +892,12 @@ __global__ __launch_bounds__(64 * NPT * ((COUT + 31) / 32) * KS, 1) void stage_r
         if constexpr (MMA) {
             // (past the end of the band the last row is fetched again into a free slot: the number of
             //  DMA pieces per step stays constant, so the counted waits and the code path do too)
-            issue_row(min(s + RW_AHEAD, nin - 1), (P + RW_AHEAD) % RW_NSLOT);
+            if constexpr (!RN_SPREAD_DMA) issue_row(min(s + RW_AHEAD, nin - 1), (P + RW_AHEAD) % RW_NSLOT);
             if constexpr (RES && (PS == 1 || (P & 1) == 0)) {
                 // pair for the epilogue of conv row s+1 (runs in step s+2): e = (s + 1 - 3) / PS
                 // (stride 2: only odd conv rows emit, so pairs are issued on even steps)
                 static_assert(!RES || PK == 4, "residual variant pools");
-                issue_skip((s - 2) / PS, sbuf_issue);
+                if constexpr (!RN_SPREAD_DMA) issue_skip((s - 2) / PS, sbuf_issue);
                 sbuf_issue = sbuf_issue == RW_SKIPBUF - 1 ? 0 : sbuf_issue + 1;
             }
 #if defined(RN_STAMPS) && defined(RN_STAMP_CHAIN)
