@@ -793,6 +793,22 @@ int rn_fused_forward(rn_handle* h, const uint8_t* d_bgr, const float* d_rgb, int
                         rows += stamp_host[k * 4 + 3];
                         ++cnt;
                     }
+                if (cnt && getenv("RN_STAMPS_PER_WAVE")) {
+                    // per wave index inside the workgroup: who is the straggler the others wait for at the barrier?
+                    const size_t wpw = 16;      // stamp slots per workgroup (rn_stage_rw.hip writes NTHREADS / 64 of them)
+                    double ww[16] = {0}, bb[16] = {0}, rr[16] = {0};
+                    const size_t real = static_cast<size_t>(getenv("RN_STAMPS_WAVES") ? atoi(getenv("RN_STAMPS_WAVES")) : 8);
+                    for (size_t k = 0; k < nwaves; ++k)
+                        if (stamp_host[k * 4 + 3]) {
+                            const size_t wi = k % real;
+                            ww[wi] += stamp_host[k * 4];
+                            bb[wi] += static_cast<double>(stamp_host[k * 4 + 2] & 0xffffffffull);
+                            rr[wi] += stamp_host[k * 4 + 3];
+                        }
+                    (void)wpw;
+                    for (size_t wi = 0; wi < real; ++wi)
+                        if (rr[wi] > 0) fprintf(stderr, "[stamps]   stage %zu wave %zu: work %.0f barrier %.0f\n", i, wi, ww[wi] / rr[wi], bb[wi] / rr[wi]);
+                }
                 if (cnt)
                     fprintf(stderr, "[stamps] stage %zu: waves %zu, cycles/step: work %.0f (MFMA chain alone %.0f)  dma-wait %.0f  barrier %.0f  (steps/wave %.0f)\n",
                             i, cnt, w / rows, ch / rows, d / rows, b / rows, rows / cnt);
