@@ -26,6 +26,9 @@
 // Stage 0 (3 input channels, K = 27) is not GEMM-shaped: `stage0_kernel` is a direct
 // VALU kernel that also fuses the uint8 -> [-1,1] pre-processing table.
 #include "rn_fused.h"
+#include <map>
+#include <vector>
+#include <algorithm>
 #include "rn_stage.h"
 
 #include <cmath>
@@ -782,17 +785,49 @@ int rn_fused_forward(rn_handle* h, const uint8_t* d_bgr, const float* d_rgb, int
 #ifdef RN_STAMPS
             (void)hipStreamSynchronize(h->stream);
             {
-                double w = 0, d = 0, b = 0, rows = 0, ch = 0;
+                double w = 0, d = 0, b = 0, rows = 0, ch = 0, life = 0, pro = 0;
                 size_t cnt = 0;
                 for (size_t k = 0; k < nwaves; ++k)
                     if (stamp_host[k * 4 + 3]) {
                         w += stamp_host[k * 4];
-                        d += stamp_host[k * 4 + 1];
+                        d += static_cast<double>(stamp_host[k * 4 + 1] & 0xffffffffull);
+                        life += static_cast<double>(stamp_host[k * 4 + 1] >> 32);
+                        pro += static_cast<double>(stamp_host[k * 4 + 3] >> 32);
                         b += static_cast<double>(stamp_host[k * 4 + 2] & 0xffffffffull);
                         ch += static_cast<double>(stamp_host[k * 4 + 2] >> 32);
-                        rows += stamp_host[k * 4 + 3];
+                        rows += static_cast<double>(stamp_host[k * 4 + 3] & 0xffffffffull);
                         ++cnt;
                     }
+#ifdef RN_STAMP_HWID
+                {
+                    // how many workgroups of this launch were resident on one CU at the same time?
+                    struct Iv { unsigned long long t0, t1; unsigned cu; };
+                    std::vector<Iv> iv;
+                    for (size_t k = 0; k < nwaves; ++k)
+                        if (stamp_host[k * 4 + 3] & 0xffffffffull) {
+                            const unsigned hw = static_cast<unsigned>(stamp_host[k * 4 + 3] >> 32);
+                            const unsigned xcc = static_cast<unsigned>(stamp_host[k * 4 + 1]) & 0xf;
+                            // gfx9 HW_ID: wave[3:0] simd[5:4] pipe[7:6] cu[11:8] sh[12] se[15:13]
+                            const unsigned cu = ((hw >> 8) & 0xf) | (((hw >> 12) & 1) << 4) | (((hw >> 13) & 7) << 5) | (xcc << 8);
+                            iv.push_back({stamp_host[k * 4 + 0], stamp_host[k * 4 + 2], cu});
+                        }
+                    std::map<unsigned, std::vector<Iv>> per;
+                    for (auto& v : iv) per[v.cu].push_back(v);
+                    double avg_conc = 0; size_t ncu = 0; size_t maxc = 0;
+                    for (auto& kv : per) {
+                        // time-weighted mean number of resident waves on this CU
+                        std::vector<std::pair<unsigned long long, int>> ev;
+                        for (auto& v : kv.second) { ev.push_back({v.t0, 1}); ev.push_back({v.t1, -1}); }
+                        std::sort(ev.begin(), ev.end());
+                        double area = 0; int cur = 0; unsigned long long last = ev.front().first; size_t mx = 0;
+                        for (auto& e : ev) { area += static_cast<double>(e.first - last) * cur; last = e.first; cur += e.second; if (static_cast<size_t>(cur) > mx) mx = cur; }
+                        avg_conc += area / static_cast<double>(ev.back().first - ev.front().first);
+                        maxc = std::max(maxc, mx); ++ncu;
+                    }
+                    fprintf(stderr, "[hwid] stage %zu: %zu waves on %zu distinct CUs; resident waves per CU: mean %.2f, max %zu\n", i, iv.size(), ncu,
+                            avg_conc / ncu, maxc);
+                }
+#endif
                 if (cnt && getenv("RN_STAMPS_PER_WAVE")) {
                     // per wave index inside the workgroup: who is the straggler the others wait for at the barrier?
                     const size_t wpw = 16;      // stamp slots per workgroup (rn_stage_rw.hip writes NTHREADS / 64 of them)
@@ -803,7 +838,7 @@ int rn_fused_forward(rn_handle* h, const uint8_t* d_bgr, const float* d_rgb, int
                             const size_t wi = k % real;
                             ww[wi] += stamp_host[k * 4];
                             bb[wi] += static_cast<double>(stamp_host[k * 4 + 2] & 0xffffffffull);
-                            rr[wi] += stamp_host[k * 4 + 3];
+                            rr[wi] += static_cast<double>(stamp_host[k * 4 + 3] & 0xffffffffull);
                         }
                     (void)wpw;
                     for (size_t wi = 0; wi < real; ++wi)
@@ -812,6 +847,9 @@ int rn_fused_forward(rn_handle* h, const uint8_t* d_bgr, const float* d_rgb, int
                 if (cnt)
                     fprintf(stderr, "[stamps] stage %zu: waves %zu, cycles/step: work %.0f (MFMA chain alone %.0f)  dma-wait %.0f  barrier %.0f  (steps/wave %.0f)\n",
                             i, cnt, w / rows, ch / rows, d / rows, b / rows, rows / cnt);
+                if (cnt)
+                    fprintf(stderr, "[stamps]   stage %zu: wave lifetime %.0f cycles, of which prologue %.0f, row loop %.0f\n", i, life / cnt,
+                            pro / cnt, (w + d + b) / cnt);
             }
 #endif
             rn_record_event(h, 2 + static_cast<int>(i));

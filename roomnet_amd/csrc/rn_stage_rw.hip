@@ -24,6 +24,8 @@
 #include "rn_stage.h"
 
 #include <algorithm>
+#include <cstdio>
+#include <cstdlib>
 #include <type_traits>
 #include <utility>
 
@@ -207,6 +209,9 @@ __global__ __launch_bounds__(64 * NPT * ((COUT + 31) / 32) * KS, 1) void stage_r
     constexpr int RW_NSLOT = C::NSLOT, RW_AHEAD = C::AHEAD;
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
+#ifdef RN_STAMPS
+    const unsigned long long st_entry = stamp();
+#endif
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -678,6 +683,7 @@ __global__ __launch_bounds__(64 * NPT * ((COUT + 31) / 32) * KS, 1) void stage_r
 
 #ifdef RN_STAMPS
     unsigned long long st_work = 0, st_dma = 0, st_bar = 0, st_chain = 0;
+    const unsigned long long st_loop0 = stamp();
 #endif
     // One pipeline step s (ring phase P = s mod RW_NSLOT): DMA for row s+RW_AHEAD, MFMA chain of conv row s,
     // epilogue of conv row s-1, counted wait, barrier.
@@ -973,7 +979,20 @@ __global__ __launch_bounds__(64 * NPT * ((COUT + 31) / 32) * KS, 1) void stage_r
         a.stamp_buf[w * 4 + 0] = st_work;
         a.stamp_buf[w * 4 + 1] = st_dma;
         a.stamp_buf[w * 4 + 2] = st_bar | (st_chain << 32);
-        a.stamp_buf[w * 4 + 3] = static_cast<unsigned long long>(nconv);
+        // prologue (entry -> first step) in the upper half of slot 3, whole lifetime in the upper half of slot 1
+        a.stamp_buf[w * 4 + 3] = static_cast<unsigned long long>(nconv) | ((st_loop0 - st_entry) << 32);
+        a.stamp_buf[w * 4 + 1] = (st_dma & 0xffffffffull) | ((stamp() - st_entry) << 32);
+#ifdef RN_STAMP_HWID
+        // residency experiment: where and when did this wave run?  (HW_ID: wave slot, SIMD, CU, SH, SE, ...)
+        unsigned hwid;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        a.stamp_buf[w * 4 + 0] = st_entry;
+        a.stamp_buf[w * 4 + 2] = stamp();
+        a.stamp_buf[w * 4 + 3] = static_cast<unsigned long long>(nconv) | (static_cast<unsigned long long>(hwid) << 32);
+        a.stamp_buf[w * 4 + 1] = xcc;
+#endif
     }
 #endif
 }
@@ -991,6 +1010,14 @@ int launch_rw(hipStream_t s, const StageArgs& a, dim3 grid) {
         RN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                    160 * 1024));
         attr_devices |= 1ull << (dev & 63);
+    }
+    if (getenv("RN_DEBUG_OCC")) {
+        int nb = -1;
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(kern), C::NTHREADS, C::LDS_BYTES);
+        hipFuncAttributes fa{};
+        (void)hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(kern));
+        fprintf(stderr, "[occ] CIN %d COUT %d RES %d NPT %d: threads %d, LDS %d B, regs %d, static LDS %zu, max blocks per CU %d\n", CIN, COUT,
+                int(RES), NPT, C::NTHREADS, C::LDS_BYTES, fa.numRegs, fa.sharedSizeBytes, nb);
     }
     hipLaunchKernelGGL(kern, grid, dim3(C::NTHREADS), C::LDS_BYTES, s, a);
     RN_CHECK_LAUNCH();

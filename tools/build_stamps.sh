@@ -6,6 +6,7 @@ ROOT="$(cd "$(dirname "${BASH_SOURCE[0]}")/.." && pwd)"
 SRC="$ROOT/roomnet_amd/csrc"
 SUF=""; DEFS=(-DRN_STAMPS)
 if [ "${1:-}" = "chain" ]; then SUF="_chain"; DEFS+=(-DRN_STAMP_CHAIN); fi
+if [ "${1:-}" = "hwid" ]; then SUF="_hwid"; DEFS+=(-DRN_STAMP_HWID); fi
 OBJ="$ROOT/build/stamps$SUF"; mkdir -p "$OBJ"
 FLAGS=(--offload-arch=gfx950 -O3 -std=c++20 -fno-slp-vectorize -fPIC -fvisibility=hidden -I"$ROOT/include" -I"$SRC"
        -Wall -Wno-unused-function -DRN_BUILDING "${DEFS[@]}")
