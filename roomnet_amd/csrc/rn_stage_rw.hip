@@ -172,14 +172,19 @@ __device__ __forceinline__ void dma16(const void* gsrc, char* lds) {
 // Only called from wave-uniform code with all lanes active (EXEC is restored to all ones).
 __device__ __forceinline__ void dma16_masked(const void* gsrc, char* lds, unsigned long long mask) {
     const unsigned lds_addr = static_cast<unsigned>(reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) char*)lds));
+    // M0 and EXEC are reserved registers: a clobber entry for them is not honoured, so the statement leaves both
+    // exactly as it found them (M0 saved and restored, EXEC back to all ones -- every caller runs with all lanes on).
+    unsigned m0_save;
     asm volatile(
-        "s_mov_b32 m0, %1\n\t"
-        "s_mov_b64 exec, %2\n\t"
-        "global_load_lds_dwordx4 %0, off\n\t"
-        "s_mov_b64 exec, -1"
-        :
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %2\n\t"
+        "s_mov_b64 exec, %3\n\t"
+        "global_load_lds_dwordx4 %1, off\n\t"
+        "s_mov_b64 exec, -1\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(m0_save)
         : "v"(gsrc), "s"(lds_addr), "s"(mask)
-        : "memory", "m0", "exec");
+        : "memory");
 }
 
 #ifdef RN_STAMPS
