@@ -59,10 +59,8 @@ struct RwCfg {
     // Ring depth: at step s the DMA for input row s + AHEAD is issued; NSLOT = AHEAD + 1 slots
     // (3 live rows + AHEAD - 2 in flight).  Rows of the 8-channel stage are only ~3.8 KB, so it
     // keeps 9 of them in flight to cover the HBM latency (Little's law), the others 3.
-#ifndef RN_AHEAD_PRIV32
-#define RN_AHEAD_PRIV32 5
-#endif
-    static constexpr int AHEAD = CIN == 8 ? 11 : ((CIN == 32 && COUT == 32 && !RES) ? RN_AHEAD_PRIV32 : 5);
+    // (7 instead of 5 for the private-ring 32-channel stage measured the same: it is not latency-bound)
+    static constexpr int AHEAD = CIN == 8 ? 11 : 5;
     static constexpr int NSLOT = AHEAD + 1;
     static constexpr int CP = CIN / 8;
     static constexpr int KC = (9 * CIN + 15) / 16;
@@ -111,12 +109,8 @@ struct RwCfg {
     // instruction) instead of 16 B per lane at a 64-byte stride
     // (measured: +23 % on the 8->32 stage, +13 % on the 32->32 stage: 64 lanes x 16 B at a 64-byte
     //  stride are 64 partial-line write requests per instruction, lane-linear stores are 8 full lines;
-    //  no gain on the residual variant, which is bound by its epilogue)
-#ifdef RN_STAGE_OUT_RES
-    static constexpr bool STAGE_OUT = COUT == 32;
-#else
+    //  -10 % on the residual variant: its extra LDS round trip sits on the critical path of a one-wave-per-SIMD step)
     static constexpr bool STAGE_OUT = COUT == 32 && !RES;
-#endif
     // folded-BN tables: persistent registers where the register file has room (one wave per SIMD, or the
     // small 8-channel stage); otherwise one batched LDS read at the start of every epilogue
     static constexpr bool PTAB_REGS = NTHREADS <= 256 || CIN == 8 || (CIN == 32 && COUT == 64);
