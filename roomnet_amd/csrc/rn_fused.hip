@@ -60,7 +60,7 @@ namespace {
 // measured: stage-2 error 0.5 % -> 3.9 % of abs-max), fp16's 11 bits can.
 constexpr int S0_CO = 8;
 constexpr int S0_TSTRIDE = 29;      // output columns per 32-column tile: 32 - (3 - 1) - 1
-constexpr int S0_AHEAD = 4;         // input rows prefetched (bytes in registers)
+constexpr int S0_AHEAD = 8;         // input rows prefetched (one dword per lane and row in registers)
 
 struct Stage0Args {
     const uint8_t* bgr;             // [N, S, S, 3]
@@ -70,6 +70,7 @@ struct Stage0Args {
     unsigned short* out;            // [N, So, So, 8]
     int S, So;
     int rows_per_band, n_bands, n_colblocks, npt;
+    int lut_arith;                  // the 256 table entries equal fp16(fma(x, 2/255, -1)): compute instead of looking up
 };
 
 template <int DT>
@@ -90,7 +91,11 @@ __global__ __launch_bounds__(512) void stage0_kernel(const Stage0Args a) {
     const int nin = nconv + 2;                         // input rows
     const int xt0 = (cb * a.npt + wave) * S0_TSTRIDE;  // first conv / input column of this wave's tile
     const int px = min(xt0 + r + 2 * hh, a.S - 1);     // this lane's input column (clamped at the edge)
-    const uint8_t* src = a.bgr + (static_cast<int64_t>(n) * a.S * a.S + static_cast<int64_t>(yo0) * a.S + px) * 3;
+    // One (unaligned) dword load per lane and row covers the pixel's 3 bytes -- three byte loads cost the
+    // address coalescer three passes per row.  The last column reads one byte early and shifts, so no lane
+    // ever touches the byte behind the caller's buffer.
+    const int sh0 = px == a.S - 1 ? 8 : 0;
+    const uint8_t* src = a.bgr + (static_cast<int64_t>(n) * a.S * a.S + static_cast<int64_t>(yo0) * a.S + px) * 3 - (sh0 >> 3);
     const int row_bytes = a.S * 3;
 
     i32x4 wreg[3];
@@ -104,14 +109,14 @@ __global__ __launch_bounds__(512) void stage0_kernel(const Stage0Args a) {
     const unsigned nb_mask = hh ? 0u : 0xffffffffu;    // the upper half-wave's second pixel slot is zero
 
     // prefetch queue of raw bytes
-    unsigned pb[S0_AHEAD], pg[S0_AHEAD], pr[S0_AHEAD];
+    unsigned pw[S0_AHEAD];
+    auto load_px = [&](int j) -> unsigned {
+        unsigned w;
+        __builtin_memcpy(&w, src + static_cast<int64_t>(min(j, nin - 1)) * row_bytes, 4);   // unaligned dword
+        return w;
+    };
 #pragma unroll
-    for (int i = 0; i < S0_AHEAD; ++i) {
-        const uint8_t* p = src + static_cast<int64_t>(min(i, nin - 1)) * row_bytes;
-        pb[i] = p[0];
-        pg[i] = p[1];
-        pr[i] = p[2];
-    }
+    for (int i = 0; i < S0_AHEAD; ++i) pw[i] = load_px(i);
     __syncthreads();
 
     i32x4 bfr[3];                                      // B fragments of the 3 live input rows
@@ -123,18 +128,25 @@ __global__ __launch_bounds__(512) void stage0_kernel(const Stage0Args a) {
 
     // consume the oldest prefetched row into a B fragment, refill the queue slot
     auto next_frag = [&](int jrow) -> i32x4 {
-        const unsigned cr = s_lut[pr[0]], cg = s_lut[pg[0]], cbl = s_lut[pb[0]];
-        const int d0 = static_cast<int>(cr | (cg << 16)), d1 = static_cast<int>(cbl);
-#pragma unroll
-        for (int i = 0; i + 1 < S0_AHEAD; ++i) {
-            pb[i] = pb[i + 1];
-            pg[i] = pg[i + 1];
-            pr[i] = pr[i + 1];
+        const unsigned w = pw[0] >> sh0;                       // bytes: B, G, R
+        int d0, d1;
+        if (a.lut_arith) {
+            // ((x / 255.) * 2) - 1 of network.py:129 as one fp32 fma, verified on the host to round to the same
+            // fp16 as the float64 expression for all 256 inputs: no LDS look-ups (random 2-byte reads from a
+            // 512-byte table ran at 63 % bank conflicts)
+            const float fb = fmaf(static_cast<float>(w & 0xff), 2.0f / 255.0f, -1.0f);
+            const float fg = fmaf(static_cast<float>((w >> 8) & 0xff), 2.0f / 255.0f, -1.0f);
+            const float fr = fmaf(static_cast<float>((w >> 16) & 0xff), 2.0f / 255.0f, -1.0f);
+            d0 = static_cast<int>(pack2<RN_DTYPE_F16>(fr, fg));
+            d1 = static_cast<int>(pack2<RN_DTYPE_F16>(fb, 0.f));
+        } else {
+            const unsigned cr = s_lut[(w >> 16) & 0xff], cg = s_lut[(w >> 8) & 0xff], cbl = s_lut[w & 0xff];
+            d0 = static_cast<int>(cr | (cg << 16));
+            d1 = static_cast<int>(cbl);
         }
-        const uint8_t* p = src + static_cast<int64_t>(min(jrow + S0_AHEAD, nin - 1)) * row_bytes;
-        pb[S0_AHEAD - 1] = p[0];
-        pg[S0_AHEAD - 1] = p[1];
-        pr[S0_AHEAD - 1] = p[2];
+#pragma unroll
+        for (int i = 0; i + 1 < S0_AHEAD; ++i) pw[i] = pw[i + 1];
+        pw[S0_AHEAD - 1] = load_px(jrow + S0_AHEAD);
         i32x4 f;
         f[0] = d0;
         f[1] = d1;
@@ -530,6 +542,7 @@ struct FusedState {
     std::vector<FusedStage> st;
     // stage 0
     unsigned short* s0_lut16 = nullptr;
+    int s0_lut_arith = 0;
     i32x4* s0_wfrag = nullptr;
     float* s0_ptab = nullptr;
 };
@@ -590,6 +603,9 @@ int rn_fused_prepare(rn_handle* h, const rn_weights* w) {
         int rc;
         if ((rc = up(lut.data(), lut.size() * 2, &d)) != RN_OK) return rc;
         fs->s0_lut16 = static_cast<unsigned short*>(d);
+        fs->s0_lut_arith = 1;
+        for (int v = 0; v < 256; ++v)
+            if (cvt(fmaf(static_cast<float>(v), 2.0f / 255.0f, -1.0f)) != lut[v]) fs->s0_lut_arith = 0;
         if ((rc = up(frag.data(), frag.size() * 2, &d)) != RN_OK) return rc;
         fs->s0_wfrag = static_cast<i32x4*>(d);
         if ((rc = up(tab.data(), tab.size() * 4, &d)) != RN_OK) return rc;
@@ -701,6 +717,7 @@ int rn_fused_forward(rn_handle* h, const uint8_t* d_bgr, const float* d_rgb, int
         Stage0Args a0{};
         a0.bgr = d_bgr;
         a0.lut16 = fs->s0_lut16;
+        a0.lut_arith = fs->s0_lut_arith && !getenv("RN_S0_LUT");
         a0.wfrag = fs->s0_wfrag;
         a0.ptab = fs->s0_ptab;
         a0.out = static_cast<unsigned short*>(h->nodes[s.node_bn].ptr);
