@@ -1,25 +1,25 @@
-// "rw" (register-weights) fused stage kernel: the hot stages of the 16-bit path
-// (conv3x3 with Cin <= 32 -> ReLU6 -> avg-pool 4x4 / s -> BN [-> + bilinear(skip) -> BN]).
+// "rw" (register-weights) fused stage kernel: stages 1-7 of the 16-bit path
+// (conv3x3 -> ReLU6 -> [avg-pool 4x4 / s] -> BN [-> + legacy-bilinear(skip) -> BN]), one launch per stage.
 //
-// Same row-streaming implicit GEMM as stage_mfma_kernel (rn_fused.hip), restructured
-// around what the counters and the ISA of the first versions showed (profiles/r1_*):
-//   1. the stage is latency-bound, not issue-bound: with ONE input row prefetched per
-//      workgroup only ~15 KB per CU were in flight (Little: ~3.7 B/clk/CU, 35 % of HBM).
-//      -> input rows (and the residual's skip rows) now arrive by LDS-DMA
-//         (global_load_lds_dwordx4, no VGPR staging, no ds_write) into a 6-slot ring with
-//         3 rows in flight, retired by COUNTED s_waitcnt vmcnt(N) and a raw s_barrier that
-//         does not drain the memory pipe (output stores stay in flight too);
-//   2. one wave = one (32-column pixel tile, 32-channel cout tile); its weight fragments
-//      (K/16 x 4 VGPRs) are loaded once into registers: one ds_read_b128 per MFMA;
-//   3. the row loop is unrolled by the ring depth, so every ring access is "lane-constant
-//      VGPR + immediate offset" -- no per-MFMA address arithmetic; the XOR chunk swizzle
-//      that keeps the B-fragment reads bank-conflict free is applied on the DMA's per-lane
-//      SOURCE address (the LDS image of a DMA piece is lane-linear);
-//   4. vertical 4-row pool by pair sums q_i = h_{i-1} + h_i, S_i = q_{i-2} + q_i (two adds
-//      per value, registers renamed by the unroll), horizontal pool by DPP wave shifts
-//      folded into v_add_f32, BN folded to one fma, 16-byte stores via v_permlane32_swap;
-//   5. software pipelining: the MFMA chain of conv row i shares a scheduling region with
-//      the VALU epilogue of row i-1 (two accumulator sets, sched_group_barrier interleave).
+// Row-streaming implicit GEMM: a workgroup owns (image, band of output rows, block of columns) and walks
+// down its band one conv row per step.  What the counters and the ISA of the earlier versions led to
+// (profiles/r1_*):
+//   1. input rows (and the residual's skip rows) arrive by LDS-DMA (global_load_lds_dwordx4: no VGPR
+//      staging, no ds_write) into a ring of row slots, several rows in flight, retired by COUNTED
+//      s_waitcnt vmcnt(N) and a bare s_barrier that does not drain the memory pipe; single-cout-tile
+//      stages give every wave a private ring and need no barrier at all; the DMA pieces of a step are
+//      spread over the step instead of issued in one burst;
+//   2. one wave = one (32-column pixel tile, 32-channel cout tile); its weight fragments (K/16 x 4 VGPRs)
+//      are loaded once into registers: one ds_read_b128 per MFMA, issued a few chunks ahead through
+//      inline asm with counted lgkmcnt waits;
+//   3. the row loop is unrolled by the ring depth, so every ring access is "lane-constant VGPR +
+//      immediate offset"; the XOR chunk swizzle that keeps the fragment reads bank-conflict free is
+//      applied on the DMA's per-lane SOURCE address (the LDS image of a DMA piece is lane-linear);
+//   4. pooling: stride-1 stages run the horizontal window sums on the matrix cores (transposed conv tile,
+//      fp16 pair sums x 0/1 band matrix), stride-2 stages use row-local DPP shifts on gapped tiles;
+//      BN is one fma, the residual's bilinear resize is an MFMA against the interpolation matrix;
+//   5. the epilogue of row s-1 is cut into micro-ops that are placed, in source order, behind the MFMAs of
+//      row s; stores are buffer stores predicated by an out-of-range offset, so a step has no branches.
 #include "rn_fused.h"
 #include "rn_stage.h"
 
