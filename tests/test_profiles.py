@@ -1,0 +1,69 @@
+"""The committed evidence under profiles/ is self-consistent (CPU test: reads files only).
+
+ * the newest bench line carries the contract keys plus the `roofline` and `cpu_baseline` objects;
+ * its roofline arithmetic adds up (achieved = algorithmic bytes / kernel time, frac = achieved / peak);
+ * the HBM-traffic summary is what tools/hbm_traffic.py derives from the two committed PMC passes, and the
+   bench line's `roofline.traffic` is that file's figure for the dominant stage;
+ * the rocprofv3 kernel-trace summary of the same command agrees with the live HIP-event time of that kernel."""
+import csv
+import glob
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PROF = os.path.join(ROOT, "profiles")
+
+
+def _newest(pattern):
+    files = sorted(glob.glob(os.path.join(PROF, pattern)))
+    if not files:
+        pytest.skip("no %s committed yet" % pattern)
+    return files[-1]
+
+
+def test_bench_line_contract_and_roofline_arithmetic():
+    b = json.load(open(_newest("*_bench.json")))
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in b, k
+    assert b["unit"] == "images/sec" and b["higher_is_better"] is True and b["data"] == "synthetic"
+    assert "workload" in b["config"] and "model" not in b["config"]
+    r = b["roofline"]
+    assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s")
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["kernel_ms"] * 1e-3) / 1e9) < 1e-3 * r["achieved"]
+    assert abs(b["value"] - b["config"]["global_batch"] / (b["ms_per_step"] * 1e-3)) < 1e-6 * b["value"]
+    c = b["cpu_baseline"]
+    assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
+
+
+def test_hbm_traffic_summary_is_reproducible_from_the_pmc_passes():
+    tj = _newest("*_hbm_traffic.json")
+    tag = os.path.basename(tj)[:-len("_hbm_traffic.json")]
+    fetch = os.path.join(PROF, tag + "_pmc_fetch_size.csv")
+    write = os.path.join(PROF, tag + "_pmc_write_size.csv")
+    assert os.path.exists(fetch) and os.path.exists(write)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "hbm_traffic.py"), fetch, write], capture_output=True,
+                         text=True, check=True).stdout
+    assert json.loads(out) == json.load(open(tj))
+    t = json.load(open(tj))
+    # every big stage moves its algorithmic bytes once (stage 5's input is partly served on-die)
+    for s in t["stages"][:8]:
+        assert 0.55 <= s["traffic_over_algorithmic"] <= 1.05, s
+    b = json.load(open(os.path.join(PROF, tag + "_bench.json")))
+    dom = [s for s in t["stages"] if s["algorithmic_bytes"] == b["roofline"]["algorithmic_bytes_per_launch"]]
+    assert dom and abs(dom[0]["traffic_bytes"] - b["roofline"]["traffic"]) <= 1e-3 * dom[0]["traffic_bytes"]
+
+
+def test_kernel_trace_agrees_with_live_event_timing():
+    ks = _newest("*_kernel_stats.csv")
+    tag = os.path.basename(ks)[:-len("_kernel_stats.csv")]
+    b = json.load(open(os.path.join(PROF, tag + "_bench.json")))
+    rows = list(csv.DictReader(open(ks)))
+    top = max((r for r in rows if "stage" in r["Name"]), key=lambda r: float(r["AverageNs"]))
+    # the profiler's own overhead and box-to-box spread stay within 12 %
+    assert abs(float(top["AverageNs"]) * 1e-6 - b["roofline"]["kernel_ms"]) <= 0.12 * b["roofline"]["kernel_ms"]
