@@ -29,9 +29,37 @@ def shard_counts(n: int, world_size: int):
     return [shard_bounds(n, world_size, r)[1] - shard_bounds(n, world_size, r)[0] for r in range(world_size)]
 
 
+def result_buffers(n: int, num_classes: int, device):
+    """One byte buffer holding ``probs [n, C]`` float32 followed by ``ids [n]`` int64, plus typed views of its two
+    parts.  A forward pass writes through the views (or their ``data_ptr()``); the exchange moves the buffer."""
+    import torch
+    combo = torch.empty((n * (num_classes * 4 + 8),), dtype=torch.uint8, device=device)
+    probs = combo[:n * num_classes * 4].view(torch.float32).view(n, num_classes)
+    ids = combo[n * num_classes * 4:].view(torch.int64)
+    return combo, probs, ids
+
+
+def all_gather_packed(combo, group=None):
+    """The data path's one collective: all-gather every rank's packed result buffer -> ``[world, bytes]``."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    out = torch.empty((world * combo.numel(),), dtype=torch.uint8, device=combo.device)   # flat: gloo insists on it
+    dist.all_gather_into_tensor(out, combo, group=group)
+    return out.view(world, combo.numel())
+
+
+def unpack_results(packed_row, n: int, num_classes: int):
+    """``(ids [n], probs [n, C])`` views of one rank's row of :func:`all_gather_packed`."""
+    import torch
+    probs = packed_row[:n * num_classes * 4].view(torch.float32).view(n, num_classes)
+    ids = packed_row[n * num_classes * 4:n * (num_classes * 4 + 8)].view(torch.int64)
+    return ids, probs
+
+
 def all_gather_outputs(ids, probs, n_total: int, group=None):
     """All-gather ragged per-rank ``(ids [n_r], probs [n_r, C])`` torch tensors into
-    ``(ids [n_total], probs [n_total, C])`` on every rank (rank order = batch order)."""
+    ``(ids [n_total], probs [n_total, C])`` on every rank (rank order = batch order) with one collective."""
     import torch
     import torch.distributed as dist
     world = dist.get_world_size(group)
@@ -41,18 +69,15 @@ def all_gather_outputs(ids, probs, n_total: int, group=None):
         raise ValueError("rank %d holds %d rows, its shard has %d" % (rank, ids.shape[0], counts[rank]))
     cmax = max(counts) if counts else 0
     c = probs.shape[1]
-    pad_p = torch.zeros((cmax, c), dtype=probs.dtype, device=probs.device)
-    pad_i = torch.zeros((cmax,), dtype=ids.dtype, device=ids.device)
-    pad_p[:counts[rank]] = probs
-    pad_i[:counts[rank]] = ids
-    out_p = torch.empty((world * cmax, c), dtype=probs.dtype, device=probs.device)
-    out_i = torch.empty((world * cmax,), dtype=ids.dtype, device=ids.device)
-    dist.all_gather_into_tensor(out_p, pad_p, group=group)
-    dist.all_gather_into_tensor(out_i, pad_i, group=group)
-    if all(k == cmax for k in counts):
-        return out_i, out_p
-    keep = torch.cat([torch.arange(r * cmax, r * cmax + counts[r], device=probs.device) for r in range(world)])
-    return out_i[keep], out_p[keep]
+    combo, pad_p, pad_i = result_buffers(cmax, c, probs.device)
+    combo.zero_()
+    pad_p[:counts[rank]] = probs.to(torch.float32)
+    pad_i[:counts[rank]] = ids.to(torch.int64)
+    packed = all_gather_packed(combo, group)
+    parts = [unpack_results(packed[r], cmax, c) for r in range(world)]
+    out_i = torch.cat([parts[r][0][:counts[r]] for r in range(world)])
+    out_p = torch.cat([parts[r][1][:counts[r]] for r in range(world)])
+    return out_i, out_p
 
 
 class DataParallelRoomNet:
