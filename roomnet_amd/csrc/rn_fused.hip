@@ -638,9 +638,14 @@ int rn_fused_prepare(rn_handle* h, const rn_weights* w) {
                 tab[c] = s.pool_k ? inv / static_cast<float>(s.pool_k * s.pool_k) : inv;
                 tab[s.cout + c] = ws.beta[c] - ws.mean[c] * inv;
                 if (s.skip_stage >= 0) {
+                    // residual stages: y2 = (S * sc1 + sh1 + R) * sc2 + sh2 = S * (sc1 sc2) + R * sc2 + (sh1 sc2 + sh2):
+                    // tables 0/1 hold the products, so the epilogue is two fmas around the resized skip value
                     const float inv2 = (1.0f / sqrtf(ws.variance2[c] + w->bn_epsilon)) * ws.gamma2[c];
+                    const float sh2 = ws.beta2[c] - ws.mean2[c] * inv2;
                     tab[2 * s.cout + c] = inv2;
-                    tab[3 * s.cout + c] = ws.beta2[c] - ws.mean2[c] * inv2;
+                    tab[3 * s.cout + c] = sh2;
+                    tab[s.cout + c] = tab[s.cout + c] * inv2 + sh2;
+                    tab[c] = tab[c] * inv2;
                 }
             }
             void* dt = nullptr;

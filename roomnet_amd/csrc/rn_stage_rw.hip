@@ -813,7 +813,7 @@ __global__ __launch_bounds__(64 * NPT * ((COUT + 31) / 32) * KS, 1) void stage_r
                         if constexpr (RES) {
                             const float lo = r_lo[4 * g + jj];
                             const float rs = lo + (r_hi[4 * g + jj] - lo) * yl;
-                            y = fmaf(y + rs, sc2[jj], sh2[jj]);
+                            y = fmaf(rs, sc2[jj], y);      // tables 0/1 already carry the second BN (see rn_fused_prepare)
                         }
                         yv[4 * g + jj] = y;
                     }
