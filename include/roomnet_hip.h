@@ -142,6 +142,16 @@ RN_API int rn_forward_f32(rn_handle* h, const float* rgb_nhwc, int n, float* pro
  * Use rn_sync (or your own event on the stream) before reading the outputs. */
 RN_API int rn_forward_u8_device(rn_handle* h, const uint8_t* d_bgr_nhwc, int n, float* d_probs, int64_t* d_ids);
 RN_API int rn_forward_f32_device(rn_handle* h, const float* d_rgb_nhwc, int n, float* d_probs, int64_t* d_ids);
+/* The caller's image pipeline on the device -- RoomNet.center_crop + cv2.resize(INTER_LINEAR) of
+ * RoomNet.infer_optimized (reference network.py:137-146, :152).  `d_src` is one BGR uint8 HWC image of any size
+ * in device memory; its centred square window is resized to im_side x im_side into slot `index` of a device batch
+ * buffer [max_batch, im_side, im_side, 3] that rn_forward_u8_device then takes.  Integer-exact restatement of
+ * OpenCV's fixed-point algorithm (bit-identical to roomnet_amd/imageops.py).  Asynchronous on the handle's stream. */
+RN_API int rn_crop_resize_u8_device(rn_handle* h, const uint8_t* d_src, int src_h, int src_w, uint8_t* d_dst_batch, int index);
+/* infer.py:79-82 for a whole batch: n host images of individual sizes heights[i] x widths[i] (BGR uint8 HWC) are
+ * uploaded, centre-cropped, resized and classified; probs [n, num_classes], ids [n] on the host.  Synchronous. */
+RN_API int rn_classify_images_u8(rn_handle* h, const uint8_t* const* images, const int* heights, const int* widths, int n,
+                                 float* probs, int64_t* ids);
 RN_API int rn_sync(rn_handle* h);
 
 /* Run on a caller-provided hipStream_t (e.g. the framework's current stream)

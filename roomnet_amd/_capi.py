@@ -32,6 +32,7 @@ EXPORTED_SYMBOLS = (
     "rn_forward_u8", "rn_forward_f32", "rn_forward_u8_device", "rn_forward_f32_device", "rn_sync",
     "rn_set_stream", "rn_node_count", "rn_node_info_get", "rn_tap", "rn_set_profiling", "rn_timing",
     "rn_dominant_stage", "rn_device_malloc", "rn_device_free", "rn_memcpy_h2d", "rn_memcpy_d2h",
+    "rn_crop_resize_u8_device", "rn_classify_images_u8",
 )
 
 
@@ -125,6 +126,10 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.rn_memcpy_h2d.restype = i32
     lib.rn_memcpy_d2h.argtypes = [vp, vp, vp, sz]
     lib.rn_memcpy_d2h.restype = i32
+    lib.rn_crop_resize_u8_device.argtypes = [vp, vp, i32, i32, vp, i32]
+    lib.rn_crop_resize_u8_device.restype = i32
+    lib.rn_classify_images_u8.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_int), C.POINTER(C.c_int), i32, vp, vp]
+    lib.rn_classify_images_u8.restype = i32
     if path is None:
         _lib = lib
     return lib
@@ -246,6 +251,45 @@ class Engine:
                                         ids[i:i + m].ctypes.data)
             _check(self.lib, rc, "rn_forward_u8")
         return ids, probs
+
+    def classify_images(self, images) -> Tuple[np.ndarray, np.ndarray]:
+        """``images``: sequence of BGR uint8 HWC arrays of any (individual) size.  Centre crop + INTER_LINEAR resize
+        run on the GPU (``rn_classify_images_u8``); returns ``(ids [n], probs [n, C])``."""
+        ims = [np.ascontiguousarray(im, dtype=np.uint8) for im in images]
+        for im in ims:
+            if im.ndim != 3 or im.shape[2] != 3 or im.shape[0] < 1 or im.shape[1] < 1:
+                raise ValueError("expected HWC uint8 images with 3 channels, got %s" % (im.shape,))
+        n = len(ims)
+        probs = np.empty((n, self.graph.num_classes), np.float32)
+        ids = np.empty((n,), np.int64)
+        for i in range(0, n, self.max_batch):
+            chunk = ims[i:i + self.max_batch]
+            m = len(chunk)
+            ptrs = (C.c_void_p * m)(*[im.ctypes.data for im in chunk])
+            hs = (C.c_int * m)(*[im.shape[0] for im in chunk])
+            ws = (C.c_int * m)(*[im.shape[1] for im in chunk])
+            rc = self.lib.rn_classify_images_u8(self.handle, ptrs, hs, ws, m, probs[i:i + m].ctypes.data,
+                                                ids[i:i + m].ctypes.data)
+            _check(self.lib, rc, "rn_classify_images_u8")
+        return ids, probs
+
+    def crop_resize(self, im_bgr_u8: np.ndarray) -> np.ndarray:
+        """One image through the device crop + resize; returns the ``[S, S, 3]`` uint8 result (parity tests)."""
+        im = np.ascontiguousarray(im_bgr_u8, dtype=np.uint8)
+        s = self.graph.im_side
+        d_src = self.device_malloc(im.nbytes)
+        d_dst = self.device_malloc(self.max_batch * s * s * 3)
+        try:
+            self.h2d(d_src, im)
+            rc = self.lib.rn_crop_resize_u8_device(self.handle, C.c_void_p(d_src), im.shape[0], im.shape[1],
+                                                   C.c_void_p(d_dst), 0)
+            _check(self.lib, rc, "rn_crop_resize_u8_device")
+            out = np.empty((s, s, 3), np.uint8)
+            self.d2h(out, d_dst)
+            return out
+        finally:
+            self.device_free(d_src)
+            self.device_free(d_dst)
 
     def forward_f32(self, x_rgb: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
         s = self.graph.im_side

@@ -481,6 +481,7 @@ extern "C" void rn_destroy(rn_handle* h) {
     for (auto e : h->events)
         if (e) (void)hipEventDestroy(e);
     for (void* p : h->allocs) (void)hipFree(p);
+    if (h->d_raw) (void)hipFree(h->d_raw);
     rn_fused_release(h);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
     delete h;
@@ -557,6 +558,101 @@ extern "C" int rn_forward_u8(rn_handle* h, const uint8_t* bgr, int n, float* pro
     DeviceGuard guard(h->device);
     const size_t in_bytes = static_cast<size_t>(n) * h->im_side * h->im_side * 3;
     RN_HIP(hipMemcpyAsync(h->d_in_u8, bgr, in_bytes, hipMemcpyHostToDevice, h->stream));
+    if ((rc = rn_forward_u8_device(h, h->d_in_u8, n, h->d_probs, h->d_ids)) != RN_OK) return rc;
+    RN_HIP(hipMemcpyAsync(probs, h->d_probs, static_cast<size_t>(n) * h->num_classes * 4, hipMemcpyDeviceToHost,
+                          h->stream));
+    RN_HIP(hipMemcpyAsync(ids, h->d_ids, static_cast<size_t>(n) * 8, hipMemcpyDeviceToHost, h->stream));
+    RN_HIP(hipStreamSynchronize(h->stream));
+    return RN_OK;
+}
+
+// ---- caller-side image pipeline on the device (network.py:137-156)
+namespace {
+// network.py:137-146: the centred square window of an h x w image (abs((w - h) // 2) with Python floor division)
+void center_crop_window(int hh, int ww, int* x0, int* y0, int* side) {
+    if (hh == ww) {
+        *x0 = *y0 = 0;
+        *side = hh;
+    } else if (ww > hh) {
+        *x0 = (ww - hh) / 2;
+        *y0 = 0;
+        *side = hh;
+    } else {
+        // abs((w - h) // 2): floor division of a negative number rounds away from zero before abs()
+        *x0 = 0;
+        *y0 = (hh - ww + 1) / 2;
+        *side = ww;
+    }
+}
+}  // namespace
+
+extern "C" int rn_crop_resize_u8_device(rn_handle* h, const uint8_t* d_src, int src_h, int src_w, uint8_t* d_dst_batch,
+                                        int index) {
+    if (!h || !d_src || !d_dst_batch || src_h < 1 || src_w < 1 || index < 0 || index >= h->max_batch) {
+        rn_set_error("rn_crop_resize_u8_device: bad argument (image %dx%d, slot %d of %d)", src_w, src_h, index,
+                     h ? h->max_batch : 0);
+        return RN_E_INVALID;
+    }
+    DeviceGuard guard(h->device);
+    int x0, y0, side;
+    center_crop_window(src_h, src_w, &x0, &y0, &side);
+    const int S = h->im_side;
+    return rn_launch_resize_u8(h->stream, d_src + (static_cast<int64_t>(y0) * src_w + x0) * 3, side, side,
+                               static_cast<int64_t>(src_w) * 3, d_dst_batch + static_cast<int64_t>(index) * S * S * 3, S, S);
+}
+
+extern "C" int rn_classify_images_u8(rn_handle* h, const uint8_t* const* images, const int* heights, const int* widths, int n,
+                                     float* probs, int64_t* ids) {
+    int rc = check_call(h, n, images, probs, ids);
+    if (rc != RN_OK) return rc;
+    if (!heights || !widths) {
+        rn_set_error("rn_classify_images_u8: heights / widths missing");
+        return RN_E_INVALID;
+    }
+    DeviceGuard guard(h->device);
+    // one staging buffer for the raw images, grown to the batch's total size: uploads and resize launches are queued
+    // on the handle's stream back to back
+    // (only the centred square window of each image crosses PCIe: a 1920x1080 frame uploads 1080x1080)
+    size_t total = 0;
+    for (int i = 0; i < n; ++i) {
+        if (!images[i] || heights[i] < 1 || widths[i] < 1) {
+            rn_set_error("rn_classify_images_u8: image %d is empty", i);
+            return RN_E_INVALID;
+        }
+        const size_t side = static_cast<size_t>(heights[i] < widths[i] ? heights[i] : widths[i]);
+        total += side * side * 3;
+    }
+    if (total > h->raw_cap) {
+        if (h->d_raw) (void)hipFree(h->d_raw);
+        h->d_raw = nullptr;
+        h->raw_cap = 0;
+        void* p = nullptr;
+        const size_t cap = total + total / 4;
+        hipError_t e = hipMalloc(&p, cap);
+        if (e != hipSuccess) {
+            rn_set_error("hipMalloc(%zu bytes of image staging) failed: %s", cap, hipGetErrorString(e));
+            return RN_E_NOMEM;
+        }
+        h->d_raw = static_cast<uint8_t*>(p);
+        h->raw_cap = cap;
+    }
+    size_t off = 0;
+    const int S = h->im_side;
+    for (int i = 0; i < n; ++i) {
+        int x0, y0, side;
+        center_crop_window(heights[i], widths[i], &x0, &y0, &side);
+        const size_t row = static_cast<size_t>(side) * 3, bytes = row * side;
+        const uint8_t* win = images[i] + (static_cast<size_t>(y0) * widths[i] + x0) * 3;
+        if (side == widths[i])
+            RN_HIP(hipMemcpyAsync(h->d_raw + off, win, bytes, hipMemcpyHostToDevice, h->stream));
+        else
+            RN_HIP(hipMemcpy2DAsync(h->d_raw + off, row, win, static_cast<size_t>(widths[i]) * 3, row, side,
+                                    hipMemcpyHostToDevice, h->stream));
+        if ((rc = rn_launch_resize_u8(h->stream, h->d_raw + off, side, side, static_cast<int64_t>(row),
+                                      h->d_in_u8 + static_cast<int64_t>(i) * S * S * 3, S, S)) != RN_OK)
+            return rc;
+        off += bytes;
+    }
     if ((rc = rn_forward_u8_device(h, h->d_in_u8, n, h->d_probs, h->d_ids)) != RN_OK) return rc;
     RN_HIP(hipMemcpyAsync(probs, h->d_probs, static_cast<size_t>(n) * h->num_classes * 4, hipMemcpyDeviceToHost,
                           h->stream));

@@ -90,6 +90,8 @@ struct rn_handle {
     float* lut = nullptr;        // 256-entry uint8 -> float32 table
     // staging for host-buffer calls
     uint8_t* d_in_u8 = nullptr;
+    uint8_t* d_raw = nullptr;      // staging for raw (un-resized) images, rn_classify_images_u8
+    size_t raw_cap = 0;
     float* d_probs = nullptr;
     int64_t* d_ids = nullptr;
     std::vector<void*> allocs;   // everything to hipFree on destroy
@@ -121,6 +123,8 @@ struct HeadArgs {
     float* tap_relu[RN_MAX_DENSE];
     float* tap_bn[RN_MAX_DENSE];
 };
+int rn_launch_resize_u8(hipStream_t s, const uint8_t* d_src, int src_h, int src_w, int64_t src_row_bytes, uint8_t* d_dst,
+                        int dst_h, int dst_w);
 int rn_launch_head(hipStream_t s, const void* flat, int flat_dtype, int n, const HeadArgs& a, float* probs,
                    int64_t* ids);
 int rn_launch_convert_to_f32(hipStream_t s, const void* in, int dtype, float* out, int64_t n);

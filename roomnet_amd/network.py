@@ -208,11 +208,14 @@ class RoomNet:
 
     def infer_optimized(self, im_in):
         """network.py:148-156: one BGR HWC image of any size -> ``(idx[1], conf[1,C])``."""
+        eng = self._engine()
+        if isinstance(im_in, np.ndarray) and im_in.dtype == np.uint8 and im_in.ndim == 3 and im_in.shape[2] == 3:
+            # crop + cv2.resize restatement on the GPU (rn_classify_images_u8): bit-identical to the host path below
+            return eng.classify_images([im_in])
         im = self.center_crop(im_in)
         h, w, _ = im.shape
         if h != self.im_side or w != self.im_side:
             im = resize_linear_u8(im, self.im_side, self.im_side)
-        eng = self._engine()
         im = np.ascontiguousarray(im)
         if im.dtype == np.uint8:
             out_label_idx, out_label_conf = eng.forward_u8(im[None])

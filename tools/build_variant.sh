@@ -11,5 +11,5 @@ OBJ="$ROOT/build/var_$NAME"; mkdir -p "$OBJ"
     -Wall -Wno-unused-function -Wno-unused-variable -Wno-unused-but-set-variable -DRN_BUILDING -mllvm -amdgpu-mfma-vgpr-form "$@" \
     -c "$SRC/rn_stage_rw.hip" -o "$OBJ/rn_stage_rw.o"
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC "$ROOT"/build/obj/rn_api.o "$ROOT"/build/obj/rn_kernels_f32.o \
-    "$ROOT"/build/obj/rn_fused.o "$OBJ/rn_stage_rw.o" -o "$ROOT/roomnet_amd/lib/libroomnet_hip_$NAME.so"
+    "$ROOT"/build/obj/rn_fused.o "$ROOT"/build/obj/rn_imageops.o "$OBJ/rn_stage_rw.o" -o "$ROOT/roomnet_amd/lib/libroomnet_hip_$NAME.so"
 echo "built libroomnet_hip_$NAME.so"
