@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Flag VALU / LDS-return writes to the data VGPRs of a wide store issued fewer than W instructions earlier.
-usage: asm_store_audit.py file.s <kernel-substring> [W=4]"""
+A VALU write right behind the store (+1) is the hazard hipcc does not pad for buffer stores with an SGPR soffset
+(DESIGN.md section 4); an LDS read returning into the registers is harmless (its data arrives 64+ cycles later) and is
+listed as "lds".   usage: asm_store_audit.py file.s <kernel-substring> [W=4]"""
 import re, sys
 s = open(sys.argv[1]).read(); pat = sys.argv[2]; W = int(sys.argv[3]) if len(sys.argv) > 3 else 4
 def regs(tok):
@@ -23,6 +25,7 @@ for m in re.finditer(r'\.type\s+(\S+),@function\n(.*?)\n\.Lfunc_end', s, flags=r
                 if o2.startswith('v_') or o2.startswith('ds_read'):
                     d2 = regs(ins[j][len(o2):].split(',')[0])
                     if d2 & data:
-                        n += 1
-                        print('[%d] %s\n   +%d  %s' % (i, l, j - i, ins[j]))
-    print(m.group(1)[-50:], n, 'flagged')
+                        kind = 'lds' if o2.startswith('ds_read') else 'VALU'
+                        if kind == 'VALU': n += 1
+                        print('[%d] %s\n   +%d  %s  (%s)' % (i, l, j - i, ins[j], kind))
+    print(m.group(1)[-50:], n, 'VALU overwrites flagged')
