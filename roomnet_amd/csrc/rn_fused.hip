@@ -898,8 +898,11 @@ int rn_fused_forward(rn_handle* h, const uint8_t* d_bgr, const float* d_rgb, int
         // bands: aim for >= ~2 workgroups per CU across the launch, at least 4 output rows per band
         const int per_band_wgs = n * f.n_colblocks * n_ctg;
         int bands = (768 + per_band_wgs - 1) / per_band_wgs;
-        const int max_bands = (s.out_side + 3) / 4;
+        // tiny stages are pure latency chains (one wave per workgroup, a global-load round trip per row): give
+        // every output row its own workgroup instead of 4 rows each
+        const int max_bands = s.out_side <= 8 ? s.out_side : (s.out_side + 3) / 4;
         if (bands > max_bands) bands = max_bands;
+        if (s.out_side <= 8) bands = max_bands;
         if (bands < 1) bands = 1;
         a.rows_per_band = (s.out_side + bands - 1) / bands;
         a.n_bands = (s.out_side + a.rows_per_band - 1) / a.rows_per_band;
