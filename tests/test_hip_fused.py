@@ -138,6 +138,43 @@ def test_full_batch_256_properties(weights, parity_images, golden_parity, dtype)
         small.close()
 
 
+def test_randomized_batch_256_against_the_f32_hip_path(weights):
+    """256 random images (uniform noise, blurred noise, extremes) through the fused bf16 path at bench size vs the
+    per-node float32 HIP path: every image's logits within the 16-bit tolerance and the late stage outputs finite and
+    close everywhere -- a localized corruption (one tile-row of one workgroup) cannot hide in a maximum over 40 images."""
+    rng = np.random.default_rng(20261002)
+    ims = rng.integers(0, 256, (256, 224, 224, 3), dtype=np.uint8)
+    ims[0] = 0
+    ims[1] = 255
+    for i in range(2, 66):                                   # low-frequency content reaches the other classes
+        k = int(rng.integers(4, 57))
+        small = rng.integers(0, 256, (224 // k + 2, 224 // k + 2, 3), dtype=np.uint8)
+        ims[i] = np.kron(small, np.ones((k, k, 1), np.uint8))[:224, :224]
+    big = _capi.Engine(build_graph(6, 224), weights, device=0, dtype="bf16", max_batch=256)
+    f32 = _capi.Engine(build_graph(6, 224), weights, device=0, dtype="f32", max_batch=32)
+    try:
+        ids, probs = big.forward_u8(ims)
+        logits = big.tap("d3.relu", 256)
+        s7 = big.tap("s7.bn", 256)
+        s3 = big.tap("s3.bn2", 256)
+        assert np.isfinite(logits).all() and np.isfinite(s7).all() and np.isfinite(s3).all()
+        worst = 0.0
+        for i in range(0, 256, 32):
+            f32.forward_u8(ims[i:i + 32])
+            ref_logits = f32.tap("d3.relu", 32)
+            ref_s7 = f32.tap("s7.bn", 32)
+            ref_s3 = f32.tap("s3.bn2", 32)
+            worst = max(worst, float(np.abs(logits[i:i + 32] - ref_logits).max()))
+            for got, want in ((s7[i:i + 32], ref_s7), (s3[i:i + 32], ref_s3)):
+                per_image = np.abs(got - want).reshape(32, -1).max(1) / max(float(np.abs(want).max()), 1e-6)
+                assert per_image.max() <= STAGE_TOL["bf16"], (i, per_image.argmax(), per_image.max())
+        assert worst <= TOL_LOGITS, worst
+        np.testing.assert_allclose(probs.sum(1), 1.0, atol=1e-5)
+    finally:
+        big.close()
+        f32.close()
+
+
 def test_batch_limits(engine):
     """Empty and over-size batches follow the error convention instead of launching."""
     buf = np.zeros((engine.max_batch + 1, 224, 224, 3), np.uint8)
