@@ -2,7 +2,7 @@
 """Headline benchmark: images/sec of the RoomNet forward pass (BASELINE.json metric) on
 synthetic 224x224 uint8 batches, batch 256 per GPU, 16-bit storage / fp32 accumulate.
 
-  python bench.py --gpus 1 --steps 20 --warmup 5
+  python bench.py --gpus 1 --steps 200 --warmup 20      (the defaults: 0.4 s of GPU time + ~15 s of cpu_baseline)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
          --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -93,8 +93,8 @@ def cpu_baseline(weights, side, budget_s=15.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=256, help="images per GPU per step")
     ap.add_argument("--side", type=int, default=224)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f32"])
