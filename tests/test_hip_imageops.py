@@ -46,6 +46,16 @@ def test_crop_resize_is_bit_identical_to_the_host_restatement(engine, shape):
     np.testing.assert_array_equal(got, want)
 
 
+@pytest.mark.parametrize("shape", [(37, 53), (61, 40), (300, 301)])
+def test_crop_resize_vs_the_scalar_oracle(engine, shape):
+    """Against the independent loop-per-pixel restatement under oracle/ (not the NumPy product code)."""
+    from oracle.cv_resize_ref import center_crop, resize_linear_u8_scalar
+    rng = np.random.default_rng(shape[0] + 1000 * shape[1])
+    im = rng.integers(0, 256, (shape[0], shape[1], 3), dtype=np.uint8)
+    want = resize_linear_u8_scalar(center_crop(im), 224, 224)
+    np.testing.assert_array_equal(engine.crop_resize(im), want)
+
+
 def test_structured_images_and_extremes(engine):
     yy, xx = np.mgrid[0:517, 0:389]
     grad = np.stack([(xx * 255 // 388), (yy * 255 // 516), ((xx + yy) % 256)], -1).astype(np.uint8)

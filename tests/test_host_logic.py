@@ -10,36 +10,7 @@ from xls_reader import read_xls
 
 
 # ------------------------------------------------------------------ resize (cv2.resize INTER_LINEAR, uint8)
-def _brute_force_linear(src, dw, dh):
-    """Scalar restatement of OpenCV's 8-bit bilinear resize (11-bit fixed-point coefficients)."""
-    sh, sw, cn = src.shape
-    sx_scale, sy_scale = 1.0 / (dw / sw), 1.0 / (dh / sh)
-    out = np.zeros((dh, dw, cn), np.uint8)
-
-    def coef(d, scale, ssize, clamp):
-        f = np.float32((d + 0.5) * scale - 0.5)
-        s = int(np.floor(f))
-        f = np.float32(f - np.float32(s))
-        if clamp:
-            if s < 0:
-                f, s = np.float32(0), 0
-            if s >= ssize - 1:
-                f, s = np.float32(0), ssize - 1
-        c0 = int(np.rint(np.float32(np.float32(1) - f) * np.float32(2048)))
-        c1 = int(np.rint(f * np.float32(2048)))
-        return s, c0, c1
-
-    for dy in range(dh):
-        sy, b0, b1 = coef(dy, sy_scale, sh, False)
-        y0, y1 = min(max(sy, 0), sh - 1), min(max(sy + 1, 0), sh - 1)
-        for dx in range(dw):
-            sx, a0, a1 = coef(dx, sx_scale, sw, True)
-            sx1 = min(sx + 1, sw - 1)
-            for c in range(cn):
-                r0 = int(src[y0, sx, c]) * a0 + int(src[y0, sx1, c]) * a1
-                r1 = int(src[y1, sx, c]) * a0 + int(src[y1, sx1, c]) * a1
-                out[dy, dx, c] = (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2
-    return out
+from oracle.cv_resize_ref import resize_linear_u8_scalar as _brute_force_linear  # noqa: E402
 
 
 @pytest.mark.parametrize("shape,dst", [((37, 53, 3), (24, 24)), ((20, 20, 3), (33, 33)), ((50, 31, 1), (17, 40))])
