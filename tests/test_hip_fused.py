@@ -74,6 +74,26 @@ def test_band_and_batch_invariance(engine, parity_images):
         assert ids_1[0] == ids_b[i]
 
 
+@pytest.mark.parametrize("nb", [2, 3, 9, 33, 100, 129])
+def test_results_do_not_depend_on_the_batch_geometry(weights, parity_images, nb):
+    """The band count per launch follows the batch size (whole rounds of the chip): 1, 2, 4 ... 26 bands.  Whatever
+    the decomposition, an image's stage outputs and probabilities are bit-identical to its batch-of-one result."""
+    eng = _capi.Engine(build_graph(6, 224), weights, device=0, dtype="bf16", max_batch=nb)
+    try:
+        pick = np.arange(nb) % len(parity_images)
+        ids, probs = eng.forward_u8(parity_images[pick])
+        s5 = eng.tap("s5.bn2", nb)
+        s7 = eng.tap("s7.bn", nb)
+        for i in sorted({0, nb // 2, nb - 1}):
+            ids1, probs1 = eng.forward_u8(parity_images[pick[i]:pick[i] + 1])
+            np.testing.assert_array_equal(eng.tap("s5.bn2", 1)[0], s5[i])
+            np.testing.assert_array_equal(eng.tap("s7.bn", 1)[0], s7[i])
+            np.testing.assert_array_equal(probs1[0], probs[i])
+            assert ids1[0] == ids[i]
+    finally:
+        eng.close()
+
+
 def test_against_f32_hip_path(engine, weights, parity_images):
     f32 = _capi.Engine(build_graph(6, 224), weights, device=0, dtype="f32", max_batch=8)
     try:
