@@ -268,9 +268,8 @@ __global__ __launch_bounds__(64 * NPT * ((COUT + 31) / 32) * KS, 1) void stage_r
     constexpr int TAIL_LANES = C::PRIV ? RINGCOLS * CP - (LPT - 1) * 64 : 64;
     constexpr unsigned long long tail_mask = TAIL_LANES >= 64 ? ~0ull : ((1ull << TAIL_LANES) - 1ull);
     // piece i of input row yc0 + j -> ring slot
-    auto issue_row_piece = [&](auto II, int j, int slot) __attribute__((always_inline)) {
+    auto issue_row_piece_at = [&](auto II, const char* row, int slot) __attribute__((always_inline)) {
         constexpr int i = decltype(II)::value;
-        const char* row = in_img + static_cast<int64_t>(yc0 + j) * in_row_bytes;
         if constexpr (C::PRIV) {
             if constexpr ((i + 1) * 64 <= RINGCOLS * CP)
                 dma16(row + ld_goff[i], ring + slot * ROWB + i * 64 * 16);
@@ -281,8 +280,9 @@ __global__ __launch_bounds__(64 * NPT * ((COUT + 31) / 32) * KS, 1) void stage_r
         }
     };
     auto issue_row = [&](int j, int slot) __attribute__((always_inline)) {
+        const char* row = in_img + static_cast<int64_t>(yc0 + j) * in_row_bytes;
         [&]<int... II>(std::integer_sequence<int, II...>) {
-            (issue_row_piece(IC<II>{}, j, slot), ...);
+            (issue_row_piece_at(IC<II>{}, row, slot), ...);
         }(std::make_integer_sequence<int, LPT>{});
     };
 
@@ -308,17 +308,28 @@ __global__ __launch_bounds__(64 * NPT * ((COUT + 31) / 32) * KS, 1) void stage_r
         }
     }
     // piece i of the skip-row pair of local output row e -> buffer
-    auto issue_skip_piece = [&](auto II, int e, int buf) __attribute__((always_inline)) {
-        constexpr int i = decltype(II)::value;
+    // (row base and lo->hi distance are computed once per step by skip_rows(), not per piece)
+    struct SkipRows {
+        const char* r0;
+        unsigned hi_delta;
+    };
+    auto skip_rows = [&](int e) __attribute__((always_inline)) -> SkipRows {
+        SkipRows sr{nullptr, 0u};
         if constexpr (RES) {
             const int yo = yo0 + min(max(e, 0), nout_rows - 1);
+            // TF-1.13 compute_interpolation_weights: src = yo * scale (fp32), lo = int(src), hi = min(lo+1, in-1)
             const float src = static_cast<float>(yo) * a.rscale;
             const int ylo = static_cast<int>(src);
             const int yhi = min(ylo + 1, a.Ss - 1);
-            const char* r0 = skip_img + static_cast<int64_t>(ylo) * skip_row_bytes;
-            const unsigned hi_delta = static_cast<unsigned>((yhi - ylo) * skip_row_bytes);
-            dma16(r0 + (sk_goff[i] + (sk_hi[i] ? hi_delta : 0u)), skipb + buf * C::SKIPBUFB + i * NTHREADS * 16 + piece_base);
+            sr.r0 = skip_img + static_cast<int64_t>(ylo) * skip_row_bytes;
+            sr.hi_delta = static_cast<unsigned>((yhi - ylo) * skip_row_bytes);
         }
+        return sr;
+    };
+    auto issue_skip_piece = [&](auto II, const SkipRows& sr, int buf) __attribute__((always_inline)) {
+        constexpr int i = decltype(II)::value;
+        if constexpr (RES)
+            dma16(sr.r0 + (sk_goff[i] + (sk_hi[i] ? sr.hi_delta : 0u)), skipb + buf * C::SKIPBUFB + i * NTHREADS * 16 + piece_base);
     };
     auto issue_skip = [&](int e, int buf) __attribute__((always_inline)) {               // skip rows of local output row e -> buffer
         if constexpr (RES) {
@@ -868,6 +879,8 @@ __global__ __launch_bounds__(64 * NPT * ((COUT + 31) / 32) * KS, 1) void stage_r
         constexpr int NPIECE = LPT + (SKIPW ? SLPT : 0);
         constexpr int DSTEP = (KCW - 1) / NPIECE >= 1 ? (KCW - 1) / NPIECE : 1;
         const int sbuf_now = sbuf_issue;
+        const SkipRows skr = skip_rows((s - 2) / PS);
+        const char* const in_row_next = in_img + static_cast<int64_t>(yc0 + min(s + RW_AHEAD, nin - 1)) * in_row_bytes;
         auto slot = [&](auto II) __attribute__((always_inline)) {
             constexpr int I = decltype(II)::value;
             if constexpr (MMA && RN_SPREAD_DMA) {
@@ -876,9 +889,9 @@ __global__ __launch_bounds__(64 * NPT * ((COUT + 31) / 32) * KS, 1) void stage_r
                          constexpr int at = PI * DSTEP < KCW ? PI * DSTEP : KCW - 1;
                          if constexpr (at == I) {
                              if constexpr (PI < LPT)
-                                 issue_row_piece(IC<PI>{}, min(s + RW_AHEAD, nin - 1), (P + RW_AHEAD) % RW_NSLOT);
+                                 issue_row_piece_at(IC<PI>{}, in_row_next, (P + RW_AHEAD) % RW_NSLOT);
                              else
-                                 issue_skip_piece(IC<(PI < LPT ? 0 : PI - LPT)>{}, (s - 2) / PS, sbuf_now);
+                                 issue_skip_piece(IC<(PI < LPT ? 0 : PI - LPT)>{}, skr, sbuf_now);
                          }
                      }()),
                      ...);
