@@ -100,6 +100,8 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-steps", type=int, default=5)
+    ap.add_argument("--stage-launches", action="store_true",
+                    help="one launch per conv stage (RN_FLAG_STAGE_LAUNCHES): the unfused comparison arm")
     ap.add_argument("--pcie", action="store_true",
                     help="also time the host-buffer entry point (rn_forward_u8: H2D copy + forward + D2H copy); reported as "
                          "path.pcie_inclusive_images_per_sec, never as `value`")
@@ -135,7 +137,8 @@ def main():
         weights["dense/kernel"] = np.random.default_rng(600).uniform(
             -0.04, 0.04, (graph.flat_len, 32)).astype(np.float32)
     B = args.batch
-    eng = _capi.Engine(graph, weights, device=local_rank, dtype=args.dtype, max_batch=B)
+    eng = _capi.Engine(graph, weights, device=local_rank, dtype=args.dtype, max_batch=B,
+                       stage_launches=args.stage_launches)
 
     ims = torch.from_numpy(perf_batch(B, args.side, seed=rank)).to(dev)
     # probs [B,6] fp32 and ids [B] int64 live in ONE byte buffer per rank, so the result exchange is a single

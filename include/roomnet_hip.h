@@ -52,6 +52,13 @@ extern "C" {
 /* rn_create flags */
 #define RN_FLAG_TAPS 1u     /* unfused per-node path; every graph node can be read
                                back with rn_tap (float32 only)                     */
+#define RN_FLAG_STAGE_LAUNCHES 2u /* 16-bit handles: one launch per conv stage, every
+                               stage output "sK.bn"/"sK.bn2" materialised in HBM (per-stage
+                               parity taps).  Default: stages are fused across their
+                               boundaries where a kernel exists (the output of a stage
+                               that only feeds its fused successor is then never written) */
+#define RN_FLAG_GENERIC_KERNELS 4u /* 16-bit handles: every stage on the generic
+                               stage_mfma_kernel (diagnostic cross-check of the tuned kernels) */
 
 #define RN_MAX_STAGES 16
 #define RN_MAX_DENSE 8

@@ -16,6 +16,8 @@ from .graph import BN_EPSILON, Graph
 RN_OK = 0
 RN_DTYPE_F32, RN_DTYPE_BF16, RN_DTYPE_F16 = 0, 1, 2
 RN_FLAG_TAPS = 1
+RN_FLAG_STAGE_LAUNCHES = 2      # 16-bit handles: one launch per conv stage (no cross-stage fusion)
+RN_FLAG_GENERIC_KERNELS = 4     # 16-bit handles: generic stage kernel everywhere (diagnostic cross-check)
 RN_MAX_STAGES = 16
 RN_MAX_DENSE = 8
 RN_NAME_LEN = 32
@@ -204,7 +206,8 @@ class Engine:
     """One rn_handle: a model instance bound to one GPU and one stream."""
 
     def __init__(self, graph: Graph, weights: Dict[str, np.ndarray], device: int = 0, dtype="f32",
-                 max_batch: int = 64, taps: bool = False, lib_path: Optional[str] = None):
+                 max_batch: int = 64, taps: bool = False, lib_path: Optional[str] = None,
+                 stage_launches: bool = False, generic_kernels: bool = False):
         self.lib = load_library(lib_path)
         self.graph = graph
         self.dtype = DTYPES[dtype] if isinstance(dtype, str) else int(dtype)
@@ -213,7 +216,8 @@ class Engine:
         packed = _Packed(graph, weights)
         h = C.c_void_p()
         rc = self.lib.rn_create(C.byref(packed.w), self.device, self.dtype, self.max_batch,
-                                RN_FLAG_TAPS if taps else 0, C.byref(h))
+                                (RN_FLAG_TAPS if taps else 0) | (RN_FLAG_STAGE_LAUNCHES if stage_launches else 0)
+                                | (RN_FLAG_GENERIC_KERNELS if generic_kernels else 0), C.byref(h))
         _check(self.lib, rc, "rn_create")
         self._h = h
         self._nodes: Optional[Dict[str, Tuple[int, Tuple[int, int, int]]]] = None

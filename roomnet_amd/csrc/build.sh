@@ -19,7 +19,8 @@ done
 # accumulators cost one v_accvgpr_read each (64 per row in the residual variant).
 # (max-ilp scheduling was measured slower)
 "$HIPCC" "${CFLAGS[@]}" ${RN_RW_FLAGS:--mllvm -amdgpu-mfma-vgpr-form} -c "$HERE/rn_stage_rw.hip" -o "$OBJ/rn_stage_rw.o" &
+"$HIPCC" "${CFLAGS[@]}" ${RN_RW_FLAGS:--mllvm -amdgpu-mfma-vgpr-form} -c "$HERE/rn_stage23.hip" -o "$OBJ/rn_stage23.o" &
 wait
-"$HIPCC" --offload-arch=gfx950 -shared -fPIC "$OBJ"/rn_api.o "$OBJ"/rn_kernels_f32.o "$OBJ"/rn_fused.o "$OBJ"/rn_imageops.o "$OBJ"/rn_stage_rw.o \
+"$HIPCC" --offload-arch=gfx950 -shared -fPIC "$OBJ"/rn_api.o "$OBJ"/rn_kernels_f32.o "$OBJ"/rn_fused.o "$OBJ"/rn_imageops.o "$OBJ"/rn_stage_rw.o "$OBJ"/rn_stage23.o \
     ${RN_EXTRA_FLAGS:-} -o "$OUT/libroomnet_hip.so"
 echo "built $OUT/libroomnet_hip.so"

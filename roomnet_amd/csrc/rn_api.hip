@@ -128,6 +128,10 @@ int validate(const rn_weights* w, int dtype, int max_batch, unsigned flags) {
         rn_set_error("rn_create: unknown dtype %d", dtype);
         return RN_E_INVALID;
     }
+    if (flags & ~(RN_FLAG_TAPS | RN_FLAG_STAGE_LAUNCHES | RN_FLAG_GENERIC_KERNELS)) {
+        rn_set_error("rn_create: unknown flag bits 0x%x", flags);
+        return RN_E_INVALID;
+    }
     if ((flags & RN_FLAG_TAPS) && dtype != RN_DTYPE_F32) {
         rn_set_error("rn_create: RN_FLAG_TAPS needs RN_DTYPE_F32 (the unfused per-node path)");
         return RN_E_INVALID;
@@ -435,6 +439,22 @@ extern "C" int rn_create(const rn_weights* w, int device, int dtype, int max_bat
         rn_set_error("rn_create: out of host memory");
         return RN_E_NOMEM;
     }
+    {
+        // the kernels are gfx950 code sized for its 160 KiB of LDS per CU: refuse anything else up front
+        hipDeviceProp_t prop{};
+        if (hipGetDeviceProperties(&prop, device) != hipSuccess) {
+            rn_set_error("rn_create: hipGetDeviceProperties(%d) failed", device);
+            delete h;
+            return RN_E_HIP;
+        }
+        if (strncmp(prop.gcnArchName, "gfx950", 6) != 0 || prop.maxSharedMemoryPerMultiProcessor < 160 * 1024) {
+            rn_set_error("rn_create: device %d is %s with %zu bytes of LDS per CU; this library is built for gfx950 (MI355X, 160 KiB)",
+                         device, prop.gcnArchName, static_cast<size_t>(prop.maxSharedMemoryPerMultiProcessor));
+            delete h;
+            return RN_E_INVALID;
+        }
+        h->n_cu = prop.multiProcessorCount;
+    }
     h->device = device;
     h->dtype = dtype;
     h->flags = flags;
@@ -704,6 +724,14 @@ extern "C" int rn_tap(rn_handle* h, int node_id, float* out, size_t cap_elems, s
     if (!nb.ptr) {
         rn_set_error("rn_tap: node %s is not materialised on this handle (create with RN_FLAG_TAPS)", nb.info.name);
         return RN_E_STATE;
+    }
+    if (fused_mode(h)) {
+        const int pf = rn_fused_pair_first(h);
+        if (pf >= 0 && node_id == h->stages[pf].node_bn) {
+            rn_set_error("rn_tap: node %s is fused into its successor's kernel on this handle and never written "
+                         "(create with RN_FLAG_STAGE_LAUNCHES)", nb.info.name);
+            return RN_E_STATE;
+        }
     }
     const bool shared_scratch = !(h->flags & RN_FLAG_TAPS) && !fused_mode(h);
     if (shared_scratch) {

@@ -9,6 +9,8 @@ int rn_fused_prepare(rn_handle* h, const rn_weights* w);
 int rn_fused_forward(rn_handle* h, const uint8_t* d_bgr, const float* d_rgb, int n, float* d_probs,
                      int64_t* d_ids);
 void rn_fused_release(rn_handle* h);
+// index of the first stage of the cross-stage fused pair, or -1
+int rn_fused_pair_first(const rn_handle* h);
 // head launcher shared with the unfused path (defined in rn_api.hip)
 int rn_run_head(rn_handle* h, int n, float* d_probs, int64_t* d_ids);
 void rn_record_event(rn_handle* h, int idx);
@@ -24,3 +26,7 @@ struct RwPlan {
 bool rn_rw_supported(int cin, int cout, int pool_k, int pool_s, bool res, int out_side, int skip_side,
                      RwPlan* plan);
 int rn_rw_launch(const RwPlan& p, int dtype, hipStream_t s, const rnk::StageArgs& a, dim3 grid);
+
+// ---- cross-stage fused pair: conv-pool-BN -> conv-pool-BN + residual of a depth-3 block (rn_stage23.hip)
+bool rn_stage23_supported(int in_side);
+int rn_stage23_launch(int dtype, hipStream_t s, const rnk::Stage23Args& a, int n);

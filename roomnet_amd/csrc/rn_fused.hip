@@ -29,6 +29,7 @@
 #include <map>
 #include <vector>
 #include <algorithm>
+#include <atomic>
 #include "rn_stage.h"
 
 #include <cmath>
@@ -499,13 +500,13 @@ using LaunchFn = int (*)(hipStream_t, const StageArgs&, dim3, dim3, size_t);
 template <int DT, int CIN, int COUT, int PK, int PS, bool RES, int CTW>
 int launch_variant(hipStream_t s, const StageArgs& a, dim3 grid, dim3 block, size_t lds) {
     auto kern = stage_mfma_kernel<DT, CIN, COUT, PK, PS, RES, CTW>;
-    static unsigned long long attr_devices = 0;     // per device, see launch_rw
+    static std::atomic<unsigned long long> attr_devices{0};     // per device, see launch_rw
     int dev = 0;
     RN_HIP(hipGetDevice(&dev));
-    if (!(attr_devices >> (dev & 63) & 1ull)) {
+    if (!(attr_devices.load(std::memory_order_acquire) >> (dev & 63) & 1ull)) {
         RN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                    160 * 1024));
-        attr_devices |= 1ull << (dev & 63);
+        attr_devices.fetch_or(1ull << (dev & 63), std::memory_order_release);
     }
     hipLaunchKernelGGL(kern, grid, block, lds, s, a);
     RN_CHECK_LAUNCH();
@@ -540,6 +541,9 @@ constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 
 struct FusedState {
     std::vector<FusedStage> st;
+    // cross-stage fused pair (rn_stage23.hip): stages pair_first, pair_first + 1 run as one launch
+    int pair_first = -1;
+    float* pair_ptab = nullptr;  // [5][32]: the first stage's scale, shift | the second stage's scale', shift', scale2
     // stage 0
     unsigned short* s0_lut16 = nullptr;
     int s0_lut_arith = 0;
@@ -628,7 +632,7 @@ int rn_fused_prepare(rn_handle* h, const rn_weights* w) {
             return RN_E_INVALID;
         }
         f.use_rw = rn_rw_supported(s.cin, s.cout, s.pool_k, s.pool_s, s.skip_stage >= 0, s.out_side, s.skip_side,
-                                   &f.rw) && !getenv("RN_DISABLE_RW");
+                                   &f.rw) && !(h->flags & RN_FLAG_GENERIC_KERNELS);
         if (f.use_rw) {
             // y = S * (inv / k^2) + (beta - mean * inv);  y2 = (y + r) * inv2 + (beta2 - mean2 * inv2)
             const rn_conv_stage& ws = w->stages[i];
@@ -701,7 +705,41 @@ int rn_fused_prepare(rn_handle* h, const rn_weights* w) {
         RN_HIP(hipMemcpy(d, frag.data(), frag.size() * 2, hipMemcpyHostToDevice));
         f.wfrag = static_cast<i32x4*>(d);
     }
+    // ---- cross-stage fusion: the last two steps of a depth-3 block (network.py:183-203 with block_depth = 3):
+    // stage i (32->32, pool 4/1) feeds only stage i+1 (32->32, pool 4/1 + residual), whose skip tensor is stage i's
+    // INPUT.  One kernel runs both; stage i's output never reaches HBM.
+    if (!(h->flags & (RN_FLAG_STAGE_LAUNCHES | RN_FLAG_GENERIC_KERNELS)))
+        for (size_t i = 2; i + 1 < h->stages.size(); ++i) {
+            const StagePlan& s1 = h->stages[i];
+            const StagePlan& s2 = h->stages[i + 1];
+            auto is3232 = [](const StagePlan& s) { return s.cin == 32 && s.cout == 32 && s.pool_k == 4 && s.pool_s == 1; };
+            if (!is3232(s1) || !is3232(s2) || s1.skip_stage >= 0 || s2.skip_stage != static_cast<int>(i) - 1) continue;
+            if (!fs->st[i].use_rw || !fs->st[i + 1].use_rw || !rn_stage23_supported(s1.in_side)) continue;
+            bool feeds_others = false;      // stage i's output must have no other consumer
+            for (size_t k = i + 2; k < h->stages.size(); ++k) feeds_others |= h->stages[k].skip_stage == static_cast<int>(i);
+            if (feeds_others) continue;
+            std::vector<float> t1(4 * 32), t2(4 * 32), tab(5 * 32);
+            RN_HIP(hipMemcpy(t1.data(), fs->st[i].ptab, t1.size() * 4, hipMemcpyDeviceToHost));
+            RN_HIP(hipMemcpy(t2.data(), fs->st[i + 1].ptab, t2.size() * 4, hipMemcpyDeviceToHost));
+            std::copy(t1.begin(), t1.begin() + 64, tab.begin());
+            std::copy(t2.begin(), t2.begin() + 96, tab.begin() + 64);
+            void* dt = nullptr;
+            if (hipMalloc(&dt, tab.size() * 4) != hipSuccess) {
+                rn_set_error("hipMalloc(fused pair tables) failed");
+                return RN_E_NOMEM;
+            }
+            h->allocs.push_back(dt);
+            RN_HIP(hipMemcpy(dt, tab.data(), tab.size() * 4, hipMemcpyHostToDevice));
+            fs->pair_ptab = static_cast<float*>(dt);
+            fs->pair_first = static_cast<int>(i);
+            break;
+        }
     return RN_OK;
+}
+
+int rn_fused_pair_first(const rn_handle* h) {
+    const FusedState* fs = static_cast<const FusedState*>(h->fused);
+    return fs ? fs->pair_first : -1;
 }
 
 int rn_fused_forward(rn_handle* h, const uint8_t* d_bgr, const float* d_rgb, int n, float* d_probs,
@@ -722,7 +760,7 @@ int rn_fused_forward(rn_handle* h, const uint8_t* d_bgr, const float* d_rgb, int
         Stage0Args a0{};
         a0.bgr = d_bgr;
         a0.lut16 = fs->s0_lut16;
-        a0.lut_arith = fs->s0_lut_arith && !getenv("RN_S0_LUT");
+        a0.lut_arith = fs->s0_lut_arith;
         a0.wfrag = fs->s0_wfrag;
         a0.ptab = fs->s0_ptab;
         a0.out = static_cast<unsigned short*>(h->nodes[s.node_bn].ptr);
@@ -751,6 +789,49 @@ int rn_fused_forward(rn_handle* h, const uint8_t* d_bgr, const float* d_rgb, int
         const StagePlan& s = h->stages[i];
         const FusedStage& f = fs->st[i];
         const StagePlan& prev = h->stages[i - 1];
+        if (static_cast<int>(i) == fs->pair_first) {
+            // both stages of the pair in one launch; the event of the first stage is recorded in front of it, so
+            // rn_timing reports the whole launch under the second stage
+            rn_record_event(h, 2 + static_cast<int>(i));
+            const StagePlan& s2 = h->stages[i + 1];
+            Stage23Args fa{};
+            fa.in = static_cast<const unsigned short*>(h->nodes[prev.node_bn2 >= 0 ? prev.node_bn2 : prev.node_bn].ptr);
+            fa.out = static_cast<unsigned short*>(h->nodes[s2.node_bn2].ptr);
+            fa.wfrag2 = f.wfrag;
+            fa.wfrag3 = fs->st[i + 1].wfrag;
+            fa.ptab = fs->pair_ptab;
+            fa.rlo = s2.rt.lo;
+            fa.rhi = s2.rt.hi;
+            fa.rlerp = s2.rt.lerp;
+            fa.rscale = static_cast<float>(s2.skip_side) / static_cast<float>(s2.out_side);
+            fa.W = s.in_side;
+            fa.Wo = s2.out_side;
+            // whole rows per workgroup, one workgroup per CU: bands only to fill the chip / even out the rounds
+            // (a band costs its rows plus 11 steps of pipeline fill)
+            const int n_cu = h->n_cu;
+            int bands = 1;
+            long best_cost = -1;
+            const int max_bands = (s2.out_side + 7) / 8;
+            for (int b = 1; b <= 8 && b <= max_bands; ++b) {
+                const long rounds = (static_cast<long>(n) * b + n_cu - 1) / n_cu;
+                const long cost = rounds * ((s2.out_side + b - 1) / b + 11);
+                if (best_cost < 0 || cost < best_cost) {
+                    best_cost = cost;
+                    bands = b;
+                }
+            }
+            if (n * bands < n_cu) {
+                bands = (n_cu + n - 1) / n;
+                if (bands > max_bands) bands = max_bands;
+            }
+            fa.rows_per_band = (s2.out_side + bands - 1) / bands;
+            fa.n_bands = (s2.out_side + fa.rows_per_band - 1) / fa.rows_per_band;
+            int rc = rn_stage23_launch(h->dtype, h->stream, fa, n);
+            if (rc != RN_OK) return rc;
+            rn_record_event(h, 2 + static_cast<int>(i) + 1);
+            ++i;
+            continue;
+        }
         StageArgs a{};
         a.in = static_cast<const unsigned short*>(h->nodes[prev.node_bn2 >= 0 ? prev.node_bn2 : prev.node_bn].ptr);
         a.out = static_cast<unsigned short*>(h->nodes[s.node_bn2 >= 0 ? s.node_bn2 : s.node_bn].ptr);
@@ -778,7 +859,9 @@ int rn_fused_forward(rn_handle* h, const uint8_t* d_bgr, const float* d_rgb, int
         a.H = a.W = s.in_side;
         a.Ho = a.Wo = s.out_side;
         if (f.use_rw) {
-            if (const char* dbg = getenv("RN_DEBUG_FLAGS")) a.dbg_flags = atoi(dbg);
+#ifdef RN_DIAG
+            if (const char* dbg = getenv("RN_DEBUG_FLAGS")) a.dbg_flags = atoi(dbg);   // diagnostic builds only
+#endif
             a.ptab = f.ptab;
             a.skipcols = f.rw.skipcols;
             a.n_colblocks = f.rw.n_colblocks;
@@ -790,7 +873,7 @@ int rn_fused_forward(rn_handle* h, const uint8_t* d_bgr, const float* d_rgb, int
             // the chip give the least time: 1 band at batch 256 x 224^2, 2 when e.g. 64 x 600^2 images x 6 column
             // blocks = 384 workgroups would otherwise run 1.5 rounds.
             const int per_band = n * f.rw.n_colblocks;
-            const int n_cu = 256;
+            const int n_cu = h->n_cu;
             const int max_bands = (s.out_side + 7) / 8;
             int bands = 1;
             long best_cost = -1;

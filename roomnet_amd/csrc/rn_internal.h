@@ -81,6 +81,7 @@ struct rn_handle {
     int max_batch = 0;
     int im_side = 0, num_classes = 0;
     float bn_eps = 1e-3f;
+    int n_cu = 0;                // compute units of the device (launch geometry is sized in rounds of the chip)
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     std::vector<StagePlan> stages;

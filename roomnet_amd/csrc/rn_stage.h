@@ -2,6 +2,8 @@
 #pragma once
 #include "rn_internal.h"
 
+#include <type_traits>
+
 namespace rnk {
 
 using i32x4 = __attribute__((ext_vector_type(4))) int;
@@ -89,7 +91,81 @@ __device__ __forceinline__ float row_next(float v) {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x100 + N, 0xf, 0xf, true));
 }
 
+// packed fp16 add of two dwords holding two halves each (one v_pk_add_f16)
+__device__ __forceinline__ int pk_add_f16(int a, int b) {
+    using h2 = __attribute__((ext_vector_type(2))) _Float16;
+    return __builtin_bit_cast(int, __builtin_bit_cast(h2, a) + __builtin_bit_cast(h2, b));
+}
+
+// Residual interpolation weight as ONE 16-bit MFMA operand: the lerp fraction t is rounded to a multiple of 2^-8
+// (bf16) / 2^-11 (fp16), for which t and 1 - t are both exactly representable -- the two weights still sum to
+// exactly 1, the interpolation position moves by at most 2^-9 (2^-12) of a pixel.
+template <int DT>
+__host__ __device__ __forceinline__ float res_quant_lerp(float t) {
+    constexpr float s = DT == RN_DTYPE_BF16 ? 256.0f : 2048.0f;
+    return __builtin_rintf(t * s) / s;
+}
+
+// a * b rounded to float32 BEFORE anything else uses it.  TF-1.13's compute_interpolation_weights rounds
+// in = out_index * scale and then takes lerp = in - floor(in); left to -ffp-contract=fast, hipcc fuses the product
+// into the subtraction (v_fma_f32 lerp, scale, index, -floor), which moves the lerp weight by an ulp of `in`.
+__device__ __forceinline__ float mul_rounded(float a, float b) {
+    float p = a * b;
+    asm volatile("" : "+v"(p));
+    return p;
+}
+
 __device__ __forceinline__ float relu6f(float v) { return __builtin_amdgcn_fmed3f(v, 0.f, 6.f); }
+
+// ------------------------------------------------------------------------ LDS-DMA / barrier helpers
+template <int P>
+using IC = std::integral_constant<int, P>;
+
+typedef __attribute__((address_space(3))) void* lds_void_ptr;
+
+// Bare workgroup barrier.  No fence: a fence would make the compiler drain the LDS-DMA queue
+// (vmcnt(0)) at every barrier.  Correctness is by construction: DMA data is retired by the
+// counted s_waitcnt vmcnt(N) in front of it, every ds_read of a step has been consumed by
+// an MFMA / VALU instruction of that step, and there are no ds_writes in the loop.
+__device__ __forceinline__ void raw_barrier() {
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
+// 16-byte-per-lane LDS-DMA piece: LDS destination = wave-uniform `lds` + lane * 16.
+// (Kept in an explicit __device__ function: used directly inside a lambda the builtin makes
+// the host pass drop the kernel's launch stub without a diagnostic.)
+__device__ __forceinline__ void dma16(const void* gsrc, char* lds) {
+    __builtin_amdgcn_global_load_lds(gsrc, (lds_void_ptr)lds, 16, 0, 0);
+}
+
+// The same piece with only the lanes of `mask` active (tail piece of a wave-private ring row).
+// Done with an explicit EXEC window instead of `if (lane_ok)`: a divergent branch would split the
+// row step into several basic blocks and the MFMA / epilogue interleave stops at block borders.
+// Only called from wave-uniform code with all lanes active (EXEC is restored to all ones).
+__device__ __forceinline__ void dma16_masked(const void* gsrc, char* lds, unsigned long long mask) {
+    const unsigned lds_addr = static_cast<unsigned>(reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) char*)lds));
+    // M0 and EXEC are reserved registers: a clobber entry for them is not honoured, so the statement leaves both
+    // exactly as it found them (M0 saved and restored, EXEC back to all ones -- every caller runs with all lanes on).
+    unsigned m0_save;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %2\n\t"
+        "s_mov_b64 exec, %3\n\t"
+        "global_load_lds_dwordx4 %1, off\n\t"
+        "s_mov_b64 exec, -1\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(m0_save)
+        : "v"(gsrc), "s"(lds_addr), "s"(mask)
+        : "memory");
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    static_assert(N >= 0 && N <= 63, "vmcnt range");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
 
 // ------------------------------------------------------------------------ MFMA stage
 struct StageArgs {
@@ -115,6 +191,21 @@ struct StageArgs {
     int dbg_flags;                // timing experiments only: bit 0 = skip output stores, bit 1 = skip MFMAs
     unsigned long long* stamp_buf; // diagnostic build (-DRN_STAMPS) only: per-wave phase cycle sums
     float rscale;                 // residual resize scale = float(Ss) / float(Ho), fp32 as TF computes it
+};
+
+// launch arguments of the cross-stage fused kernel (rn_stage23.hip): the last two steps of a depth-3 conv_block
+struct Stage23Args {
+    const unsigned short* in;     // [N, W, W, 32]: the block's first BN output (input of the pair AND skip tensor)
+    unsigned short* out;          // [N, Wo, Wo, 32]
+    const i32x4* wfrag2;          // [18][64] fragments of the first conv of the pair
+    const i32x4* wfrag3;          // [18][64] fragments of the second conv
+    const float* ptab;            // [5][32] folded BN: scale, shift of the first stage | scale', shift', scale2 of the second
+    const int32_t* rlo;           // legacy bilinear tables W -> Wo, [Wo]
+    const int32_t* rhi;
+    const float* rlerp;
+    float rscale;                 // float(W) / float(Wo), fp32 as TF computes it
+    int W, Wo;                    // side of the input / of the output (= W - 10)
+    int rows_per_band, n_bands;
 };
 
 template <int CIN>

@@ -24,6 +24,7 @@
 #include "rn_stage.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <type_traits>
@@ -32,11 +33,6 @@
 using namespace rnk;
 
 namespace {
-
-template <int P>
-using IC = std::integral_constant<int, P>;
-
-typedef __attribute__((address_space(3))) void* lds_void_ptr;
 
 // Tile geometry of the rw kernels: 32 conv columns per tile.
 //  pool 4/1: the 29 windows inside the tile, window i on lane i; the horizontal sums run on the matrix
@@ -77,6 +73,7 @@ struct RwCfg {
     // pixel-on-lane layout for BN, residual and the stores.  Vertical pooling = fp32 pair sums before the
     // rounding, so a pooled row costs 4 MFMAs (2 pair-sum rows x K = 32) instead of 48 DPP instructions.
     static constexpr bool POOLM = PK == 4 && PS == 1;
+    static constexpr bool RES_SPLIT = !POOLM;                  // residual interpolation weights as hi + lo 16-bit operands
     static constexpr bool GAP = PK == 4 && PS == 2;            // gapped lane -> column map, DPP pooling (see rw_tile_nout)
     // KS = 3: the K dimension is split by kernel row over three waves per pixel tile (each keeps one
     // kernel row's weight fragments in registers); partial accumulators meet in LDS (K = 1152 stage)
@@ -143,44 +140,6 @@ struct RwCfg {
     static_assert(VMCNT_STEADY <= 63, "vmcnt field");
 };
 
-// Bare workgroup barrier.  No fence: a fence would make the compiler drain the LDS-DMA queue
-// (vmcnt(0)) at every barrier.  Correctness is by construction: DMA data is retired by the
-// counted s_waitcnt vmcnt(N) in front of it, every ds_read of a step has been consumed by
-// an MFMA / VALU instruction of that step, and there are no ds_writes in the loop.
-__device__ __forceinline__ void raw_barrier() {
-    asm volatile("" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-}
-
-// 16-byte-per-lane LDS-DMA piece: LDS destination = wave-uniform `lds` + lane * 16.
-// (Kept in an explicit __device__ function: used directly inside a lambda the builtin makes
-// the host pass drop the kernel's launch stub without a diagnostic.)
-__device__ __forceinline__ void dma16(const void* gsrc, char* lds) {
-    __builtin_amdgcn_global_load_lds(gsrc, (lds_void_ptr)lds, 16, 0, 0);
-}
-
-// The same piece with only the lanes of `mask` active (tail piece of a wave-private ring row).
-// Done with an explicit EXEC window instead of `if (lane_ok)`: a divergent branch would split the
-// row step into several basic blocks and the MFMA / epilogue interleave stops at block borders.
-// Only called from wave-uniform code with all lanes active (EXEC is restored to all ones).
-__device__ __forceinline__ void dma16_masked(const void* gsrc, char* lds, unsigned long long mask) {
-    const unsigned lds_addr = static_cast<unsigned>(reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) char*)lds));
-    // M0 and EXEC are reserved registers: a clobber entry for them is not honoured, so the statement leaves both
-    // exactly as it found them (M0 saved and restored, EXEC back to all ones -- every caller runs with all lanes on).
-    unsigned m0_save;
-    asm volatile(
-        "s_mov_b32 %0, m0\n\t"
-        "s_mov_b32 m0, %2\n\t"
-        "s_mov_b64 exec, %3\n\t"
-        "global_load_lds_dwordx4 %1, off\n\t"
-        "s_mov_b64 exec, -1\n\t"
-        "s_mov_b32 m0, %0"
-        : "=&s"(m0_save)
-        : "v"(gsrc), "s"(lds_addr), "s"(mask)
-        : "memory");
-}
-
 #ifdef RN_STAMPS
 // In-kernel stamps (diagnostic build only; never in the shipped library): s_memtime + its own wait
 // in ONE asm statement, fenced by sched_barrier so the segments hold what they are named for.
@@ -192,12 +151,6 @@ __device__ __forceinline__ unsigned long long stamp() {
     return t;
 }
 #endif
-
-template <int N>
-__device__ __forceinline__ void wait_vmcnt() {
-    static_assert(N >= 0 && N <= 63, "vmcnt range");
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-}
 
 template <int DT, int CIN, int COUT, int PK, int PS, bool RES, int NPT, int KS>
 __global__ __launch_bounds__(64 * NPT * ((COUT + 31) / 32) * KS, 1) void stage_rw_kernel(const StageArgs a) {
@@ -318,7 +271,7 @@ __global__ __launch_bounds__(64 * NPT * ((COUT + 31) / 32) * KS, 1) void stage_r
         if constexpr (RES) {
             const int yo = yo0 + min(max(e, 0), nout_rows - 1);
             // TF-1.13 compute_interpolation_weights: src = yo * scale (fp32), lo = int(src), hi = min(lo+1, in-1)
-            const float src = static_cast<float>(yo) * a.rscale;
+            const float src = mul_rounded(static_cast<float>(yo), a.rscale);
             const int ylo = static_cast<int>(src);
             const int yhi = min(ylo + 1, a.Ss - 1);
             sr.r0 = skip_img + static_cast<int64_t>(ylo) * skip_row_bytes;
@@ -335,7 +288,7 @@ __global__ __launch_bounds__(64 * NPT * ((COUT + 31) / 32) * KS, 1) void stage_r
         if constexpr (RES) {
             const int yo = yo0 + min(max(e, 0), nout_rows - 1);
             // TF-1.13 compute_interpolation_weights: src = yo * scale (fp32), lo = int(src), hi = min(lo+1, in-1)
-            const float src = static_cast<float>(yo) * a.rscale;
+            const float src = mul_rounded(static_cast<float>(yo), a.rscale);
             const int ylo = static_cast<int>(src);
             const int yhi = min(ylo + 1, a.Ss - 1);
             // uniform base = lo row; lanes of the hi row add the (uniform) row distance
@@ -422,7 +375,11 @@ __global__ __launch_bounds__(64 * NPT * ((COUT + 31) / 32) * KS, 1) void stage_r
         return __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(out_img) + static_cast<int64_t>(yo) * out_row_bytes, 0,
                                                  out_row_bytes, 0x00020000);
     };
-    const bool stores_on = !(a.dbg_flags & 1);
+#ifdef RN_DIAG
+    const bool stores_on = !(a.dbg_flags & 1);     // diagnostic builds only: timing without the output stores
+#else
+    constexpr bool stores_on = true;
+#endif
     // direct stores: this lane's 16-byte chunk of pixel xo (second chunk at +32 bytes)
     const int voff_lane = (lane_out && stores_on) ? (xo * COUT + ct * 32 + 8 * hh) * 2 : OOB;
     // staged stores: lane-linear 16-byte chunks of the tile-row (second instruction + 1024 bytes)
@@ -442,7 +399,9 @@ __global__ __launch_bounds__(64 * NPT * ((COUT + 31) / 32) * KS, 1) void stage_r
         const int xs_t = a.rlo[xo_t0] - xs0;                 // K origin inside the staged block
         const int xq = min(xo, a.Wo - 1);
         const int plo = a.rlo[xq] - xs0, phi = a.rhi[xq] - xs0;
-        const float xl = a.rlerp[xq];
+        // stride-1 residual (scale ~1.05, shared with the cross-stage fused kernel rn_stage23.hip): ONE 16-bit operand
+        // whose two weights are exact (res_quant_lerp); the stride-2 residual keeps the hi + lo split
+        const float xl = C::RES_SPLIT ? a.rlerp[xq] : res_quant_lerp<DT>(a.rlerp[xq]);
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
             unsigned short wh[8], wl[8];
@@ -493,6 +452,7 @@ __global__ __launch_bounds__(64 * NPT * ((COUT + 31) / 32) * KS, 1) void stage_r
 #pragma unroll
     for (int g = 0; g < 16; ++g) hprev[g] = q0f[g] = 0.f;
     i32x4 qp0[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}}, qp1[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+    i32x4 hprevp[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};    // POOLM: previous row's ReLU6 output as fp16 pairs
     // band matrix Pm[x][xo] as the pool MFMA's B operand: lane (xo = r, k-group hh), K slot (chunk c, j) is the
     // conv column held by accumulator register 8c + j of the transposed conv tile: x = (j & 3) + 8 (j >> 2) + 16 c + 4 hh
     i32x4 pmw[2];
@@ -677,12 +637,16 @@ __global__ __launch_bounds__(64 * NPT * ((COUT + 31) / 32) * KS, 1) void stage_r
         const i32x4 ah0 = {t[4][0], t[4][1], t[5][0], t[5][1]}, ah1 = {t[6][0], t[6][1], t[7][0], t[7][1]};
         r_lo = mfma32<DT>(al0, bw_h[0], zero);
         r_hi = mfma32<DT>(ah0, bw_h[0], zero);
-        r_lo = mfma32<DT>(al0, bw_l[0], r_lo);
-        r_hi = mfma32<DT>(ah0, bw_l[0], r_hi);
+        if constexpr (C::RES_SPLIT) {
+            r_lo = mfma32<DT>(al0, bw_l[0], r_lo);
+            r_hi = mfma32<DT>(ah0, bw_l[0], r_hi);
+        }
         r_lo = mfma32<DT>(al1, bw_h[1], r_lo);
         r_hi = mfma32<DT>(ah1, bw_h[1], r_hi);
-        r_lo = mfma32<DT>(al1, bw_l[1], r_lo);
-        r_hi = mfma32<DT>(ah1, bw_l[1], r_hi);
+        if constexpr (C::RES_SPLIT) {
+            r_lo = mfma32<DT>(al1, bw_l[1], r_lo);
+            r_hi = mfma32<DT>(ah1, bw_l[1], r_hi);
+        }
     };
 
     // skip-pair bookkeeping: the pair for local output row e lives in buffer (e + 3k) mod 3
@@ -721,13 +685,12 @@ __global__ __launch_bounds__(64 * NPT * ((COUT + 31) / 32) * KS, 1) void stage_r
         const int yo = yo0 + (PK ? (j - 3) / PS : j);   // emitted output row
         float yl = 0.f;
         if constexpr (RESW) {
-            const float src = static_cast<float>(yo) * a.rscale;
+            const float src = mul_rounded(static_cast<float>(yo), a.rscale);
             yl = src - static_cast<float>(static_cast<int>(src));
         }
         // ---- state of this row's epilogue, shared by its micro-ops
         TQ tq;
         f32x16 H, r_lo, r_hi;
-        float q[16];
         i32x4 qp[2];
         uint2 pk[4];
         // micro-op list: residual reads | 8 x front (2 accumulator registers each) | residual MFMAs | pool MFMAs |
@@ -768,14 +731,12 @@ __global__ __launch_bounds__(64 * NPT * ((COUT + 31) / 32) * KS, 1) void stage_r
                 }
                 // ReLU6 + vertical pair sums of accumulator registers 4i .. 4i+3, rounded to two fp16 pairs
                 if constexpr (C::POOLM) {
+                    // ReLU6 -> fp16 pair -> vertical pair sum q_j = v_{j-1} + v_j as one packed fp16 add (the previous
+                    // row is kept as fp16 pairs: 8 registers instead of 16)
                     constexpr int i2 = 2 * (k - M_FRONT);
-#pragma unroll
-                    for (int i = i2; i < i2 + 2; ++i) {
-                        const float v = relu6f(acc_old[i]);
-                        q[i] = hprev[i] + v;
-                        hprev[i] = v;
-                    }
-                    qp[i2 / 8][(i2 % 8) / 2] = static_cast<int>(pack2<RN_DTYPE_F16>(q[i2], q[i2 + 1]));
+                    const int vp = static_cast<int>(pack2<RN_DTYPE_F16>(relu6f(acc_old[i2]), relu6f(acc_old[i2 + 1])));
+                    qp[i2 / 8][(i2 % 8) / 2] = pk_add_f16(hprevp[i2 / 8][(i2 % 8) / 2], vp);
+                    hprevp[i2 / 8][(i2 % 8) / 2] = vp;
                 }
             } else if constexpr (k == M_RES_MM) {
                 if constexpr (RESW) {
@@ -1014,15 +975,16 @@ int launch_rw(hipStream_t s, const StageArgs& a, dim3 grid) {
     using C = RwCfg<DT, CIN, COUT, PK, PS, RES, NPT, KS>;
     auto kern = stage_rw_kernel<DT, CIN, COUT, PK, PS, RES, NPT, KS>;
     // the attribute is per device: remember which devices of this process have it (one handle per GPU per process
-    // is the normal deployment, several handles on several GPUs in one process must work too)
-    static unsigned long long attr_devices = 0;
+    // is the normal deployment, several handles on several GPUs / threads in one process must work too)
+    static std::atomic<unsigned long long> attr_devices{0};
     int dev = 0;
     RN_HIP(hipGetDevice(&dev));
-    if (!(attr_devices >> (dev & 63) & 1ull)) {
+    if (!(attr_devices.load(std::memory_order_acquire) >> (dev & 63) & 1ull)) {
         RN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                    160 * 1024));
-        attr_devices |= 1ull << (dev & 63);
+        attr_devices.fetch_or(1ull << (dev & 63), std::memory_order_release);
     }
+#ifdef RN_DIAG
     if (getenv("RN_DEBUG_OCC")) {
         int nb = -1;
         (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(kern), C::NTHREADS, C::LDS_BYTES);
@@ -1031,6 +993,7 @@ int launch_rw(hipStream_t s, const StageArgs& a, dim3 grid) {
         fprintf(stderr, "[occ] CIN %d COUT %d RES %d NPT %d: threads %d, LDS %d B, regs %d, static LDS %zu, max blocks per CU %d\n", CIN, COUT,
                 int(RES), NPT, C::NTHREADS, C::LDS_BYTES, fa.numRegs, fa.sharedSizeBytes, nb);
     }
+#endif
     hipLaunchKernelGGL(kern, grid, dim3(C::NTHREADS), C::LDS_BYTES, s, a);
     RN_CHECK_LAUNCH();
     return RN_OK;
