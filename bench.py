@@ -100,6 +100,7 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-steps", type=int, default=5)
+    ap.add_argument("--no-parity-check", action="store_true", help="skip the golden check (timing experiments with garbage results)")
     ap.add_argument("--stage-launches", action="store_true",
                     help="one launch per conv stage (RN_FLAG_STAGE_LAUNCHES): the unfused comparison arm")
     ap.add_argument("--pcie", action="store_true",
@@ -177,7 +178,8 @@ def main():
     # sanity: outputs are a distribution and an argmax of it
     p = probs.cpu().numpy()
     i = ids.cpu().numpy()
-    assert np.allclose(p.sum(1), 1.0, atol=1e-4) and (p.argmax(1) == i).all()
+    if not args.no_parity_check:
+        assert np.allclose(p.sum(1), 1.0, atol=1e-4) and (p.argmax(1) == i).all()
 
     # ---- per-stage device time (HIP events on the launch stream), separate from the timed region
     eng.set_profiling(True)

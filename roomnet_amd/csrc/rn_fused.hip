@@ -826,8 +826,30 @@ int rn_fused_forward(rn_handle* h, const uint8_t* d_bgr, const float* d_rgb, int
             }
             fa.rows_per_band = (s2.out_side + bands - 1) / bands;
             fa.n_bands = (s2.out_side + fa.rows_per_band - 1) / fa.rows_per_band;
+#ifdef RN_STAMPS
+            static unsigned long long* stamp_host23 = nullptr;
+            const size_t nwaves23 = static_cast<size_t>(fa.n_bands) * n * 8;
+            if (!stamp_host23) (void)hipHostMalloc(reinterpret_cast<void**>(&stamp_host23), 16u << 20, 0);
+            std::memset(stamp_host23, 0, nwaves23 * 32);
+            fa.stamp_buf = stamp_host23;
+#endif
             int rc = rn_stage23_launch(h->dtype, h->stream, fa, n);
             if (rc != RN_OK) return rc;
+#ifdef RN_STAMPS
+            (void)hipStreamSynchronize(h->stream);
+            {
+                double wtot[8] = {0}, wbar[8] = {0}, wsteps[8] = {0};
+                for (size_t k = 0; k < nwaves23; ++k) {
+                    wtot[k & 7] += stamp_host23[k * 4];
+                    wbar[k & 7] += stamp_host23[k * 4 + 2];
+                    wsteps[k & 7] += stamp_host23[k * 4 + 3];
+                }
+                for (int w8 = 0; w8 < 8; ++w8)
+                    if (wsteps[w8] > 0)
+                        fprintf(stderr, "[stamps] fused stages %zu+%zu wave %d (%s): cycles/step %.0f, of which barrier wait %.0f\n", i, i + 1, w8,
+                                w8 < 4 ? "producer" : "consumer", wtot[w8] / wsteps[w8], wbar[w8] / wsteps[w8]);
+            }
+#endif
             rn_record_event(h, 2 + static_cast<int>(i) + 1);
             ++i;
             continue;

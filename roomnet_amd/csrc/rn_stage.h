@@ -206,6 +206,7 @@ struct Stage23Args {
     float rscale;                 // float(W) / float(Wo), fp32 as TF computes it
     int W, Wo;                    // side of the input / of the output (= W - 10)
     int rows_per_band, n_bands;
+    unsigned long long* stamp_buf; // diagnostic build (-DRN_STAMPS) only: per-wave cycle sums
 };
 
 template <int CIN>

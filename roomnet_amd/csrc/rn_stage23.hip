@@ -8,18 +8,16 @@
 // re-reads recent rows, served by L2 / Infinity Cache), B's write and re-read disappear.  Stage-boundary model:
 // 14.25 MB per image for the two stages (bf16, 224 input); this kernel moves 5.65 MB.
 //
-// Geometry: a workgroup = 4 waves (one per SIMD, whole register file) owns one image x one band of output rows and
-// ALL columns (W <= 215: whole rows of A and B fit the LDS rings).  Per step t one row of A arrives by LDS-DMA and
-// every wave runs four "jobs": the first conv's row t-2 for its two 32-column tiles (reads the A ring), then the
-// second conv's row t-8 for its two tiles (reads the B ring rows the workgroup finished in earlier steps).  The
-// epilogue of each job (ReLU6, pooling on the matrix cores, BN; residual MFMAs for the second stage) is cut into
-// micro-ops that are placed between the MFMAs of the NEXT job's chain; the first stage's epilogue writes its B-row
-// segment into the B ring (ds_write_b64), the second stage's epilogue stores to HBM.  One s_barrier per step.
-// The residual's skip rows are fetched again (L2) into a small wave-private ring: each wave stages only the 64 skip
-// columns its own two tiles interpolate from, so nothing but the B ring is shared between waves.
+// Geometry: a workgroup owns one image x one band of output rows and ALL columns (W <= 215: whole rows of A and B
+// fit the LDS rings: 4 x A row + 4 x B row + the skip rows = 155 KB).  Per step t one row of A arrives by LDS-DMA,
+// the first stage finishes B row t-5 for all eight 32-column tiles (written to the B ring with ds_write_b64), the
+// second stage finishes output row t-11 from the B rows of earlier steps.  One s_barrier per step.  The residual's
+// skip rows are fetched again (L2) into small wave-private rings: each second-stage wave stages only the 64 skip
+// columns its own two tiles interpolate from, so nothing but the A and B rings is shared between waves.
 //
 // The arithmetic of both stages is instruction-for-instruction that of stage_rw_kernel's POOLM variants
-// (rn_stage_rw.hip): results are bit-identical to the two-launch path (tests/test_hip_fused.py).
+// (rn_stage_rw.hip): results are bit-identical to the two-launch path
+// (tests/test_hip_fused.py::test_cross_stage_fusion_is_bit_identical_to_stage_launches).
 #include "rn_fused.h"
 #include "rn_stage.h"
 
@@ -54,13 +52,35 @@ __device__ __forceinline__ int swz4(int pix) { return (pix >> 2) & 3; }   // chu
 
 using i32x2 = __attribute__((ext_vector_type(2))) int;
 
+#ifdef RN_STAMPS
+// diagnostic build only (tools/build_stamps.sh): s_memtime + its wait in one statement, fenced
+__device__ __forceinline__ unsigned long long stamp23() {
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
+#endif
+
+// Producer / consumer workgroup: 8 waves, two per SIMD.  Waves 0-3 ("producers") run the first stage of the pair for
+// two column tiles each, fetch the A rows and write their B-row segments into the B ring; waves 4-7 ("consumers") run
+// the second stage for two tiles each on the B rows of earlier steps.  Wave w and wave w + 4 share a SIMD, so every
+// SIMD hosts one producer and one consumer: while one of them is in a VALU-heavy epilogue the other one's MFMA chain
+// keeps the matrix pipe busy.  (Measured against a 4-wave form -- one wave per SIMD doing all four jobs with the
+// epilogue micro-ops placed between its own MFMAs, in the history: a single wave pays ~5 cycles per non-MFMA
+// instruction and hides none of them behind its own dependent MFMAs; 5800 cycles per step against 5200 here, where
+// the consumer's serial instruction stream is the critical path and the producer waits ~1500 cycles at the barrier:
+// profiles/r2_stage23_stamps.txt.)  The consumer defers the epilogue of its second tile to the start of the next step,
+// which puts its chains opposite the producer's epilogues, and runs at s_setprio 1 (it is the wave the step waits for).
 template <int DT>
-__global__ __launch_bounds__(256, 1) void stage23_kernel(const Stage23Args a) {
+__global__ __launch_bounds__(512, 2) void stage23pc_kernel(const Stage23Args a) {
     constexpr int KC = 18, BAHEAD = 4;
     extern __shared__ __attribute__((aligned(64))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wq = wave & 3;                             // tile pair of this wave
     const int r = lane & 31, hh = lane >> 5;
     const int band = blockIdx.x, n = blockIdx.y;
     const int W = a.W, Wb = W - 5, Wo = a.Wo;
@@ -69,48 +89,200 @@ __global__ __launch_bounds__(256, 1) void stage23_kernel(const Stage23Args a) {
     const int nsteps = nrows + F_LAG;
 
     float* const tab = reinterpret_cast<float*>(smem);
-    for (int i = tid; i < F_NTAB; i += 256) tab[i] = a.ptab[i];
-
-    // ---- both weight sets -> registers (lane-linear fragment order, see rn_fused_prepare)
-    i32x4 w2[KC], w3[KC];
-#pragma unroll
-    for (int kc = 0; kc < KC; ++kc) {
-        w2[kc] = a.wfrag2[kc * 64 + lane];
-        w3[kc] = a.wfrag3[kc * 64 + lane];
-        // pin the weights to the accumulator half of the register file (MFMA operands may be AGPRs; the VALU side
-        // of the epilogues needs the architectural VGPRs)
-        asm volatile("" : "+a"(w2[kc]), "+a"(w3[kc]));
-    }
-
-    // ---- A-row DMA: the workgroup's 256 lanes cover the 4 W chunks of a row in 3 full pieces + one tail piece that
-    // gives every wave W - 192 chunks (so every piece of every wave has active lanes).  Chunk q = (pixel q / 4, slot
-    // q % 4) holds source chunk (q % 4) ^ swz(pixel): the XOR swizzle is applied on the source address.
-    const char* const in_img = reinterpret_cast<const char*>(a.in + static_cast<int64_t>(n) * W * W * 32);
-    const int64_t in_row_bytes = static_cast<int64_t>(W) * 64;
-    const int tailn = W - 192;
-    const unsigned long long tail_mask = (1ull << tailn) - 1ull;
-    unsigned ld_goff[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int q = i < 3 ? tid + 256 * i : 768 + tailn * wave + min(lane, tailn - 1);
-        const int p = q >> 2, c = q & 3;
-        ld_goff[i] = static_cast<unsigned>(min(p, W - 1) * 64 + ((c ^ swz4(p)) << 4));
-    }
+    for (int i = tid; i < F_NTAB; i += 512) tab[i] = a.ptab[i];
     char* const ringA = smem + F_RINGA_OFF;
     char* const ringB = smem + F_RINGB_OFF;
-    auto issue_A_piece = [&](auto II, const char* row, int slot) __attribute__((always_inline)) {
-        constexpr int i = decltype(II)::value;
-        if constexpr (i < 3)
-            dma16(row + ld_goff[i], ringA + slot * F_ROWA + (i * 256 + wave * 64) * 16);
-        else
-            dma16_masked(row + ld_goff[3], ringA + slot * F_ROWA + (768 + tailn * wave) * 16, tail_mask);
+    const unsigned ringA_lds = lds_addr(ringA), ringB_lds = lds_addr(ringB);
+    const char* const in_img = reinterpret_cast<const char*>(a.in + static_cast<int64_t>(n) * W * W * 32);
+    constexpr int OOB = 0x40000000;
+
+    // band matrix of the pool MFMA (see rn_stage_rw.hip, POOLM)
+    i32x4 pmw[2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            unsigned w = 0;
+#pragma unroll
+            for (int e2 = 0; e2 < 2; ++e2) {
+                const int j8 = 2 * d + e2;
+                const int x = (j8 & 3) + 8 * (j8 >> 2) + 16 * c + 4 * hh;
+                w |= ((x >= r && x < r + 4) ? 0x3C00u : 0u) << (16 * e2);
+            }
+            pmw[c][d] = static_cast<int>(w);
+        }
+    asm volatile("" : "+a"(pmw[0]), "+a"(pmw[1]));
+
+    // fragment read of K-chunk kc, conv row whose first input row sits in ring slot S0 (inline asm, counted lgkmcnt)
+    auto chain = [&](auto S0C, auto ROWBC, const unsigned (&base)[3][2], const i32x4 (&wr)[KC], f32x16& accn) __attribute__((always_inline)) {
+        constexpr int S0 = decltype(S0C)::value, ROWB_ = decltype(ROWBC)::value;
+        const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        i32x4 bq[KC];
+        auto rd = [&](auto KCC, float dep) __attribute__((always_inline)) -> i32x4 {
+            constexpr int kc = decltype(KCC)::value;
+            constexpr int tap = kc / 2, cc = kc % 2, ky = tap / 3, kx = tap % 3;
+            constexpr int off = ((S0 + ky) % 4) * ROWB_;
+            i32x4 v;
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(base[kx][cc]), "n"(off), "v"(dep));
+            return v;
+        };
+        [&]<int... I>(std::integer_sequence<int, I...>) { ((bq[I] = rd(IC<I>{}, 0.f)), ...); }(std::make_integer_sequence<int, BAHEAD>{});
+        [&]<int... I>(std::integer_sequence<int, I...>) {
+            (([&] {
+                 if constexpr (I + BAHEAD < KC) bq[I + BAHEAD] = rd(IC<(I + BAHEAD < KC ? I + BAHEAD : 0)>{}, I == 0 ? 0.f : accn[0]);
+                 constexpr int newer = (KC - 1 - I) < BAHEAD ? (KC - 1 - I) : BAHEAD;
+                 asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(bq[I]) : "n"(newer));
+                 accn = mfma32<DT>(bq[I], wr[I], I == 0 ? zero : accn);      // D'[pixel][cout]
+             }()),
+             ...);
+        }(std::make_integer_sequence<int, KC>{});
     };
-    auto a_row_ptr = [&](int j) __attribute__((always_inline)) {       // local A row j (clamped to the band's last row)
-        return in_img + static_cast<int64_t>(yo0 + min(j, nrows + 9)) * in_row_bytes;
+    // ReLU6 -> fp16 pairs -> vertical pair sums -> pooled sums H on the matrix cores (state: hp, q0, q1 of the tile)
+    auto pool = [&](auto PRC, const f32x16& acce, i32x4 (&hp)[2], i32x4 (&q0)[2], i32x4 (&q1)[2]) __attribute__((always_inline)) -> f32x16 {
+        constexpr int PR = decltype(PRC)::value;
+        i32x4 qp[2];
+#pragma unroll
+        for (int i2 = 0; i2 < 16; i2 += 2) {
+            const int vp = static_cast<int>(pack2<RN_DTYPE_F16>(relu6f(acce[i2]), relu6f(acce[i2 + 1])));
+            qp[i2 / 8][(i2 % 8) / 2] = pk_add_f16(hp[i2 / 8][(i2 % 8) / 2], vp);
+            hp[i2 / 8][(i2 % 8) / 2] = vp;
+        }
+        const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        i32x4(&qold)[2] = PR == 0 ? q0 : q1;
+        f32x16 H = mfma32<RN_DTYPE_F16>(qold[0], pmw[0], zero);
+        H = mfma32<RN_DTYPE_F16>(qold[1], pmw[1], H);
+        H = mfma32<RN_DTYPE_F16>(qp[0], pmw[0], H);
+        H = mfma32<RN_DTYPE_F16>(qp[1], pmw[1], H);
+        qold[0] = qp[0];
+        qold[1] = qp[1];
+        return H;
     };
 
-    // ---- private skip ring: the 64 columns of A this wave's two second-stage tiles interpolate from
-    const int xs0 = a.rlo[min(58 * wave, Wo - 1)];
+    if (wave < 4) {
+        // =============================================================== producer: first stage, A ring -> B ring
+        i32x4 w2[KC];
+#pragma unroll
+        for (int kc = 0; kc < KC; ++kc) {
+            w2[kc] = a.wfrag2[kc * 64 + lane];
+            asm volatile("" : "+a"(w2[kc]));
+        }
+        const int ptid = wq * 64 + lane;                 // the four producer waves fetch the A rows
+        const int tailn = W - 192;
+        const unsigned long long tail_mask = (1ull << tailn) - 1ull;
+        unsigned ld_goff[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int q = i < 3 ? ptid + 256 * i : 768 + tailn * wq + min(lane, tailn - 1);
+            const int p = q >> 2, c = q & 3;
+            ld_goff[i] = static_cast<unsigned>(min(p, W - 1) * 64 + ((c ^ swz4(p)) << 4));
+        }
+        auto issue_A_row = [&](const char* row, int slot) __attribute__((always_inline)) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                unsigned off = ld_goff[i];
+                asm volatile("" : "+v"(off));
+                if (i < 3)
+                    dma16(row + off, ringA + slot * F_ROWA + (i * 256 + wq * 64) * 16);
+                else
+                    dma16_masked(row + off, ringA + slot * F_ROWA + (768 + tailn * wq) * 16, tail_mask);
+            }
+        };
+        unsigned baseA[2][3][2], wbB[2];
+#pragma unroll
+        for (int T = 0; T < 2; ++T) {
+            const int x_t = 29 * (2 * wq + T);
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                for (int cc = 0; cc < 2; ++cc) {
+                    const int ca = min(x_t + r + kx, W - 1);
+                    baseA[T][kx][cc] = ringA_lds + static_cast<unsigned>(ca * 64 + (((cc * 2 + hh) ^ swz4(ca)) << 4));
+                }
+            const int xo = x_t + r;
+            const int colw = (r < 29 && xo < Wb) ? xo : F_BDUMMY;
+            wbB[T] = ringB_lds + static_cast<unsigned>(colw * 64 + (swz4(colw) << 4) + hh * 8);
+        }
+        i32x4 hp[2][2], q0[2][2], q1[2][2];
+#pragma unroll
+        for (int T = 0; T < 2; ++T) hp[T][0] = hp[T][1] = q0[T][0] = q0[T][1] = q1[T][0] = q1[T][1] = i32x4{0, 0, 0, 0};
+        const char* a_next = in_img + static_cast<int64_t>(yo0) * (W * 64);
+        issue_A_row(a_next, 0);
+        wait_vmcnt<0>();
+        lds_barrier();
+
+        const float* const tabl = tab + 4 * hh;
+        auto epi = [&](auto TC, auto PC, const f32x16& acce) __attribute__((always_inline)) {
+            constexpr int T = decltype(TC)::value, P = decltype(PC)::value;
+            const f32x16 H = pool(IC<(P & 1)>{}, acce, hp[T], q0[T], q1[T]);
+            constexpr int off = ((P + 3) % F_NB) * F_ROWB;       // B row t-5
+            auto& wb = wbB;                                      // (named here: implicit capture of an asm operand)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 sc = *reinterpret_cast<const f32x4*>(tabl + 8 * g);
+                const f32x4 sh = *reinterpret_cast<const f32x4*>(tabl + 32 + 8 * g);
+                const i32x2 d = {static_cast<int>(pack2<DT>(fmaf(H[4 * g], sc[0], sh[0]), fmaf(H[4 * g + 1], sc[1], sh[1]))),
+                                 static_cast<int>(pack2<DT>(fmaf(H[4 * g + 2], sc[2], sh[2]), fmaf(H[4 * g + 3], sc[3], sh[3])))};
+                asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(wb[T] ^ static_cast<unsigned>(g << 4)), "v"(d), "n"(off) : "memory");
+            }
+        };
+#ifdef RN_STAMPS
+        unsigned long long st_bar = 0;
+#endif
+        auto step = [&](auto PC, int t) __attribute__((always_inline)) {
+            constexpr int P = decltype(PC)::value;
+            if (t < nrows + 9) a_next += W * 64;
+            issue_A_row(a_next, (P + 1) % F_NA);            // A row t+1
+            f32x16 acc;
+            chain(IC<(P + 2) % 4>{}, IC<F_ROWA>{}, baseA[0], w2, acc);     // conv row t-2: A rows t-2 .. t
+            epi(IC<0>{}, PC, acc);
+            chain(IC<(P + 2) % 4>{}, IC<F_ROWA>{}, baseA[1], w2, acc);
+            epi(IC<1>{}, PC, acc);
+#ifdef RN_STAMPS
+            const unsigned long long tb0 = stamp23();
+#endif
+            wait_vmcnt<0>();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            raw_barrier();
+#ifdef RN_STAMPS
+            st_bar += stamp23() - tb0;
+#endif
+        };
+#ifdef RN_STAMPS
+        const unsigned long long st_loop0 = stamp23();
+#endif
+        int t = 0;
+        for (; t + 3 < nsteps; t += 4) {
+            step(IC<0>{}, t);
+            step(IC<1>{}, t + 1);
+            step(IC<2>{}, t + 2);
+            step(IC<3>{}, t + 3);
+        }
+        const int rem = nsteps - t;
+        if (rem > 0) step(IC<0>{}, t);
+        if (rem > 1) step(IC<1>{}, t + 1);
+        if (rem > 2) step(IC<2>{}, t + 2);
+        wait_vmcnt<0>();
+#ifdef RN_STAMPS
+        if (a.stamp_buf && lane == 0) {
+            const int64_t w = (static_cast<int64_t>(blockIdx.y) * gridDim.x + blockIdx.x) * 8 + wave;
+            a.stamp_buf[w * 4 + 0] = stamp23() - st_loop0;
+            a.stamp_buf[w * 4 + 1] = 0;
+            a.stamp_buf[w * 4 + 2] = st_bar;
+            a.stamp_buf[w * 4 + 3] = static_cast<unsigned long long>(nsteps);
+        }
+#endif
+        return;
+    }
+
+    // =================================================================== consumer: second stage, B ring -> HBM
+    __builtin_amdgcn_s_setprio(1);
+    i32x4 w3[KC];
+#pragma unroll
+    for (int kc = 0; kc < KC; ++kc) {
+        w3[kc] = a.wfrag3[kc * 64 + lane];
+        asm volatile("" : "+a"(w3[kc]));
+    }
+    const int xs0 = a.rlo[min(58 * wq, Wo - 1)];
     unsigned sk_goff[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -118,50 +290,49 @@ __global__ __launch_bounds__(256, 1) void stage23_kernel(const Stage23Args a) {
         const int p = q >> 2, c = q & 3;
         sk_goff[i] = static_cast<unsigned>(min(xs0 + p, W - 1) * 64 + ((c ^ swz4(p)) << 4));
     }
-    char* const skw = smem + F_SKIP_OFF + wave * (F_NSK * F_SKROW);
+    char* const skw = smem + F_SKIP_OFF + wq * (F_NSK * F_SKROW);
+    const unsigned skw_lds = lds_addr(skw);
     auto issue_skip_row = [&](int y, int slot) __attribute__((always_inline)) {
-        const char* row = in_img + static_cast<int64_t>(y) * in_row_bytes;
+        const char* row = in_img + static_cast<int64_t>(y) * static_cast<int64_t>(W * 64);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) dma16(row + sk_goff[i], skw + slot * F_SKROW + i * 1024);
+        for (int i = 0; i < 4; ++i) {
+            unsigned off = sk_goff[i];
+            asm volatile("" : "+v"(off));
+            dma16(row + off, skw + slot * F_SKROW + i * 1024);
+        }
     };
-    auto ylo_of = [&](int yo) __attribute__((always_inline)) {
-        // TF-1.13 compute_interpolation_weights: src = yo * scale (fp32), lo = int(src)
-        return static_cast<int>(mul_rounded(static_cast<float>(yo), a.rscale));
+    struct VLerp {
+        int ylo;
+        float yl;
     };
-    const int ylo_base = ylo_of(yo0);
-    int sk_fetched = ylo_base - 1;                    // highest skip row whose DMA has been issued
-
-    // ---- lane constants of this wave's two column tiles (tile gT covers conv columns 29 gT .. 29 gT + 31)
-    unsigned baseA[2][3][2], baseB[2][3][2];          // LDS address of the (kx, channel-pair) fragment in ring slot 0
-    unsigned wbB[2];                                  // B-ring write address of this lane's pixel (slot 0, chunk 0)
-    int voff[2];                                      // byte offset of this lane's first 16-byte output chunk
-    int a_off[2][4];                                  // transposed skip reads (residual), relative to a skip slot
-    i32x4 bw[2][2];                                   // interpolation matrix (one 16-bit operand, see res_quant_lerp)
-    constexpr int OOB = 0x40000000;
-    const unsigned ringA_lds = lds_addr(ringA), ringB_lds = lds_addr(ringB), skw_lds = lds_addr(skw);
+    auto vlerp_of = [&](int yo) __attribute__((always_inline)) -> VLerp {
+        const float src = mul_rounded(static_cast<float>(yo), a.rscale);
+        const int ylo = static_cast<int>(src);
+        VLerp v;
+        v.ylo = __builtin_amdgcn_readfirstlane(ylo);
+        v.yl = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(src - static_cast<float>(ylo))));
+        return v;
+    };
+    unsigned baseB[2][3][2], a_off[2][2];
+    int voff[2];
+    i32x4 bw[2][2];
 #pragma unroll
     for (int T = 0; T < 2; ++T) {
-        const int x_t = 29 * (2 * wave + T);
+        const int x_t = 29 * (2 * wq + T);
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx)
 #pragma unroll
             for (int cc = 0; cc < 2; ++cc) {
-                const int ca = min(x_t + r + kx, W - 1), cb = min(x_t + r + kx, Wb - 1);
-                baseA[T][kx][cc] = ringA_lds + static_cast<unsigned>(ca * 64 + (((cc * 2 + hh) ^ swz4(ca)) << 4));
+                const int cb = min(x_t + r + kx, Wb - 1);
                 baseB[T][kx][cc] = ringB_lds + static_cast<unsigned>(cb * 64 + (((cc * 2 + hh) ^ swz4(cb)) << 4));
             }
         const int xo = x_t + r;
-        const int colw = (r < 29 && xo < Wb) ? xo : F_BDUMMY;
-        wbB[T] = ringB_lds + static_cast<unsigned>(colw * 64 + (swz4(colw) << 4) + hh * 8);
         voff[T] = (r < 29 && xo < Wo) ? (xo * 32 + 8 * hh) * 2 : OOB;
-        // residual: R[cout][x_out] = Skip^T[cout][x_in] * Wx[x_in][x_out], K = 32 skip columns from the tile's first
-        // source column (see rn_stage_rw.hip)
         const int xo_t0 = min(x_t, Wo - 1);
         const int xs_t = a.rlo[xo_t0] - xs0;
         const int xq = min(xo, Wo - 1);
         const int plo = a.rlo[xq] - xs0, phi = a.rhi[xq] - xs0;
-        const float xl = a.rlerp[xq];
-        const float xlq = res_quant_lerp<DT>(xl);
+        const float xlq = res_quant_lerp<DT>(a.rlerp[xq]);
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
             unsigned short wh[8];
@@ -179,270 +350,140 @@ __global__ __launch_bounds__(256, 1) void stage23_kernel(const Stage23Args a) {
         }
         const int grp = lane >> 4, li = lane & 15, q = li >> 2, pp = li & 3;
 #pragma unroll
-        for (int c = 0; c < 2; ++c)
-#pragma unroll
-            for (int t2 = 0; t2 < 2; ++t2) {
-                const int pix = min(max(xs_t + 16 * c + 8 * (grp >> 1) + 4 * t2 + q, 0), 63);
-                const int ch = 2 * (grp & 1) + (pp >> 1);
-                a_off[T][2 * c + t2] = (pix * 4 + (ch ^ swz4(pix))) * 16 + (pp & 1) * 8;
-            }
+        for (int t2 = 0; t2 < 2; ++t2) {
+            const int pix = xs_t + 8 * (grp >> 1) + 4 * t2 + q;
+            const int ch = 2 * (grp & 1) + (pp >> 1);
+            a_off[T][t2] = skw_lds + static_cast<unsigned>((pix * 4 + (ch ^ swz4(pix))) * 16 + (pp & 1) * 8);
+        }
     }
+    asm volatile("" : "+a"(bw[0][0]), "+a"(bw[0][1]), "+a"(bw[1][0]), "+a"(bw[1][1]));
     const int out_row_bytes = Wo * 64;
-    const char* const out_img = reinterpret_cast<const char*>(a.out + static_cast<int64_t>(n) * Wo * Wo * 32);
-    auto out_row_rsrc = [&](int yo) __attribute__((always_inline)) {
-        return __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(out_img) + static_cast<int64_t>(yo) * out_row_bytes, 0,
-                                                 out_row_bytes, 0x00020000);
-    };
-
-    // band matrix of the pool MFMA (see rn_stage_rw.hip, POOLM)
-    i32x4 pmw[2];
+    const char* out_row = reinterpret_cast<const char*>(a.out + static_cast<int64_t>(n) * Wo * Wo * 32) + static_cast<int64_t>(yo0) * out_row_bytes;
+    i32x4 hp[2][2], q0[2][2], q1[2][2];
 #pragma unroll
-    for (int c = 0; c < 2; ++c)
-#pragma unroll
-        for (int d = 0; d < 4; ++d) {
-            unsigned w = 0;
-#pragma unroll
-            for (int e2 = 0; e2 < 2; ++e2) {
-                const int j8 = 2 * d + e2;
-                const int x = (j8 & 3) + 8 * (j8 >> 2) + 16 * c + 4 * hh;
-                w |= ((x >= r && x < r + 4) ? 0x3C00u : 0u) << (16 * e2);      // fp16 1.0
-            }
-            pmw[c][d] = static_cast<int>(w);
-        }
-
-    // ---- pooling state of the four jobs (job = 2 * stage + tile)
-    // (previous row's ReLU6 output as fp16 pairs + the pair-sum rows q_{j-1}, q_{j-2}: 24 registers per job)
-    i32x4 hprev[4][2], qp0[4][2], qp1[4][2];
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-        hprev[j][0] = hprev[j][1] = qp0[j][0] = qp0[j][1] = qp1[j][0] = qp1[j][1] = i32x4{0, 0, 0, 0};
-    f32x16 acc[2];
-#pragma unroll
-    for (int g = 0; g < 16; ++g) acc[0][g] = acc[1][g] = 0.f;
-
-    // ---- prologue: A row 0
-    [&]<int... II>(std::integer_sequence<int, II...>) {
-        (issue_A_piece(IC<II>{}, a_row_ptr(0), 0), ...);
-    }(std::make_integer_sequence<int, 4>{});
-    wait_vmcnt<0>();
-    lds_barrier();
-
-    // B fragment of K-chunk kc for job J in ring phase P (inline asm, BAHEAD chunks ahead, counted lgkmcnt)
-    auto b_read = [&](auto JC, auto PC, auto KCC, float dep) __attribute__((always_inline)) -> i32x4 {
-        constexpr int J = decltype(JC)::value, P = decltype(PC)::value, kc = decltype(KCC)::value;
-        constexpr int S = J >> 1, T = J & 1;
-        constexpr int tap = kc / 2, cc = kc % 2, ky = tap / 3, kx = tap % 3;
-        // stage 1 of the pair reads A rows t-2 .. t (slot = row mod 4), stage 2 reads B rows t-8 .. t-6
-        constexpr int slot = S == 0 ? (P + 2 + ky) % F_NA : (P + ky) % F_NB;
-        constexpr int off = slot * (S == 0 ? F_ROWA : F_ROWB);
-        const unsigned base = S == 0 ? baseA[T][kx][cc] : baseB[T][kx][cc];
-        i32x4 v;
-        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(base), "n"(off), "v"(dep));
-        return v;
-    };
-    auto mma_chain = [&](auto JC, auto PC, f32x16& accn, auto&& slotfn) __attribute__((always_inline)) {
-        constexpr int J = decltype(JC)::value;
-        const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        i32x4 bq[KC];
-        [&]<int... I>(std::integer_sequence<int, I...>) {
-            ((bq[I] = b_read(JC, PC, IC<I>{}, 0.f)), ...);
-        }(std::make_integer_sequence<int, BAHEAD>{});
-        [&]<int... I>(std::integer_sequence<int, I...>) {
-            (([&] {
-                 if constexpr (I + BAHEAD < KC)
-                     bq[I + BAHEAD] = b_read(JC, PC, IC<(I + BAHEAD < KC ? I + BAHEAD : 0)>{}, I == 0 ? 0.f : accn[0]);
-                 constexpr int newer = (KC - 1 - I) < BAHEAD ? (KC - 1 - I) : BAHEAD;
-                 asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(bq[I]) : "n"(newer));
-                 if constexpr (J < 2)
-                     accn = mfma32<DT>(bq[I], w2[I], I == 0 ? zero : accn);      // D'[pixel][cout]
-                 else
-                     accn = mfma32<DT>(bq[I], w3[I], I == 0 ? zero : accn);
-                 slotfn(IC<I>{});
-             }()),
-             ...);
-        }(std::make_integer_sequence<int, KC>{});
-    };
-
-    // ---- epilogue state (one epilogue is in flight at a time: that of the previous job)
-    using TQ = i32x2[8];
-    TQ tq;
-    f32x16 H, r_lo, r_hi;
-    i32x4 qp[2];
-    uint2 pk[4];
-    float yv[16];
-    struct RowCtx {                 // per-step scalars of the second stage's epilogue
+    for (int T = 0; T < 2; ++T) hp[T][0] = hp[T][1] = q0[T][0] = q0[T][1] = q1[T][0] = q1[T][1] = i32x4{0, 0, 0, 0};
+    struct RowCtx {
         float yl;
-        unsigned sk_lo, sk_hi;      // LDS addresses of the two staged skip rows
+        unsigned sk_lo, sk_hi;
         __amdgpu_buffer_rsrc_t rs;
-        int emit_mask;              // 0: store, OOB: drop
+        int emit_mask;
     };
-    auto tr_read = [&](unsigned addr) __attribute__((always_inline)) -> i32x2 {
-        i32x2 v;
-        asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(addr));
-        return v;
-    };
-    // micro-op k of job J's epilogue; PR = parity of the job's conv row; DRAIN: no chain around it (explicit waits)
-    constexpr int M_RES_RD = 0, M_FRONT = 1, NF = 8, M_RES_MM = M_FRONT + NF, M_POOL = M_RES_MM + 1, M_BN = M_POOL + 3,
-                  M_STORE = M_BN + 8, NM = M_STORE + 1;
-    auto mop = [&](auto JC, auto PRC, auto PWC, auto DRAINC, auto KK, const f32x16& acce, const RowCtx& cx)
-                   __attribute__((always_inline)) {
-        constexpr int J = decltype(JC)::value, PR = decltype(PRC)::value, PW = decltype(PWC)::value, k = decltype(KK)::value;
-        constexpr bool DRAIN = decltype(DRAINC)::value != 0;
-        constexpr int S = J >> 1, T = J & 1;
-        constexpr bool RES = S == 1;
-        if constexpr (k == M_RES_RD) {
-            if constexpr (RES) {
-#pragma unroll
-                for (int qq = 0; qq < 4; ++qq) {
-                    tq[qq] = tr_read(cx.sk_lo + static_cast<unsigned>(a_off[T][qq]));
-                    tq[4 + qq] = tr_read(cx.sk_hi + static_cast<unsigned>(a_off[T][qq]));
-                }
-            }
-        } else if constexpr (k >= M_FRONT && k < M_FRONT + NF) {
-            constexpr int i2 = 2 * (k - M_FRONT);
-            // ReLU6 -> fp16 pair -> vertical pair sum q_j = v_{j-1} + v_j (packed fp16 add)
-            const int vp = static_cast<int>(pack2<RN_DTYPE_F16>(relu6f(acce[i2]), relu6f(acce[i2 + 1])));
-            qp[i2 / 8][(i2 % 8) / 2] = pk_add_f16(hprev[J][i2 / 8][(i2 % 8) / 2], vp);
-            hprev[J][i2 / 8][(i2 % 8) / 2] = vp;
-        } else if constexpr (k == M_RES_MM) {
-            if constexpr (RES) {
-                if constexpr (DRAIN) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                asm volatile("" : "+v"(tq[0]), "+v"(tq[1]), "+v"(tq[2]), "+v"(tq[3]), "+v"(tq[4]), "+v"(tq[5]), "+v"(tq[6]), "+v"(tq[7]));
-                const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                const i32x4 al0 = {tq[0][0], tq[0][1], tq[1][0], tq[1][1]}, al1 = {tq[2][0], tq[2][1], tq[3][0], tq[3][1]};
-                const i32x4 ah0 = {tq[4][0], tq[4][1], tq[5][0], tq[5][1]}, ah1 = {tq[6][0], tq[6][1], tq[7][0], tq[7][1]};
-                r_lo = mfma32<DT>(al0, bw[T][0], zero);
-                r_hi = mfma32<DT>(ah0, bw[T][0], zero);
-                r_lo = mfma32<DT>(al1, bw[T][1], r_lo);
-                r_hi = mfma32<DT>(ah1, bw[T][1], r_hi);
-            }
-        } else if constexpr (k == M_POOL) {
-            const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            i32x4(&qold)[2] = PR == 0 ? qp0[J] : qp1[J];
-            H = mfma32<RN_DTYPE_F16>(qold[0], pmw[0], zero);
-            H = mfma32<RN_DTYPE_F16>(qold[1], pmw[1], H);
-            H = mfma32<RN_DTYPE_F16>(qp[0], pmw[0], H);
-            H = mfma32<RN_DTYPE_F16>(qp[1], pmw[1], H);
-            qold[0] = qp[0];
-            qold[1] = qp[1];
-        } else if constexpr (k >= M_BN && k < M_BN + 8) {
-            constexpr int g = (k - M_BN) / 2, h2 = (k - M_BN) % 2;
-            const float* pt_g = tab + (RES ? 64 : 0) + 4 * hh + 8 * g;
-            const f32x4 sc1 = *reinterpret_cast<const f32x4*>(pt_g);
-            const f32x4 sh1 = *reinterpret_cast<const f32x4*>(pt_g + 32);
-            f32x4 sc2 = {0.f, 0.f, 0.f, 0.f};
-            if constexpr (RES) sc2 = *reinterpret_cast<const f32x4*>(pt_g + 64);
-#pragma unroll
-            for (int jj = 2 * h2; jj < 2 * h2 + 2; ++jj) {
-                float y = fmaf(H[4 * g + jj], sc1[jj], sh1[jj]);
-                if constexpr (RES) {
-                    const float lo = r_lo[4 * g + jj];
-                    const float rs = lo + (r_hi[4 * g + jj] - lo) * cx.yl;
-                    y = fmaf(rs, sc2[jj], y);
-                }
-                yv[4 * g + jj] = y;
-            }
-            if constexpr (h2 == 0)
-                pk[g].x = pack2<DT>(yv[4 * g], yv[4 * g + 1]);
-            else
-                pk[g].y = pack2<DT>(yv[4 * g + 2], yv[4 * g + 3]);
-        } else if constexpr (k == M_STORE) {
-            if constexpr (!RES) {
-                // B-row segment -> ring slot of B row t-5: this lane's pixel, channels 8g + 4hh .. +3 per write
-                constexpr int off = ((PW + 3) % F_NB) * F_ROWB;
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const i32x2 d = {static_cast<int>(pk[g].x), static_cast<int>(pk[g].y)};
-                    asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(wbB[T] ^ static_cast<unsigned>(g << 4)), "v"(d), "n"(off) : "memory");
-                }
-            } else {
-                i32x4 vv[2];
-#pragma unroll
-                for (int kk = 0; kk < 4; kk += 2) {
-                    const auto sx = __builtin_amdgcn_permlane32_swap(pk[kk].x, pk[kk + 1].x, false, false);
-                    const auto sy = __builtin_amdgcn_permlane32_swap(pk[kk].y, pk[kk + 1].y, false, false);
-                    vv[kk / 2][0] = static_cast<int>(sx[0]);
-                    vv[kk / 2][1] = static_cast<int>(sy[0]);
-                    vv[kk / 2][2] = static_cast<int>(sx[1]);
-                    vv[kk / 2][3] = static_cast<int>(sy[1]);
-                }
-                const int vo = voff[T] | cx.emit_mask;
-                __builtin_amdgcn_raw_buffer_store_b128(vv[0], cx.rs, vo, 0, 0);
-                __builtin_amdgcn_raw_buffer_store_b128(vv[1], cx.rs, vo + 32, 0, 0);
-            }
-        }
-    };
-
+    const int ylo_base = vlerp_of(yo0).ylo;
+    int sk_fetched = ylo_base - 1, sk_fetched_slot = F_NSK - 1;
+    VLerp vl_cur = vlerp_of(yo0);
+    int slot_cur = 0;
     RowCtx cx_cur{}, cx_prev{};
     cx_cur.emit_mask = cx_prev.emit_mask = OOB;
-    cx_cur.sk_lo = cx_cur.sk_hi = cx_prev.sk_lo = cx_prev.sk_hi = skw_lds;
-    cx_cur.rs = cx_prev.rs = out_row_rsrc(yo0);
+    cx_cur.rs = cx_prev.rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(out_row), 0, out_row_bytes, 0x00020000);
+    f32x16 acc1;                                     // second tile's accumulator: its epilogue runs in the next step
+#pragma unroll
+    for (int g = 0; g < 16; ++g) acc1[g] = 0.f;
+    lds_barrier();
 
-    // One step (ring phase P = t mod 4).
+    const float* const tabl = tab + 64 + 4 * hh;
+    auto epi = [&](auto TC, auto PRC, const f32x16& acce, const RowCtx& cx) __attribute__((always_inline)) {
+        constexpr int T = decltype(TC)::value;
+        // residual: transposed reads of the staged skip pair, R_lo / R_hi = Skip^T * Wx on the matrix cores
+        i32x2 tq[8];
+        auto& ao = a_off;
+#pragma unroll
+        for (int t2 = 0; t2 < 2; ++t2) {
+            const unsigned alo = ao[T][t2] + cx.sk_lo, ahi = ao[T][t2] + cx.sk_hi;
+            asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(tq[t2]) : "v"(alo));
+            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:1024" : "=v"(tq[2 + t2]) : "v"(alo));
+            asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(tq[4 + t2]) : "v"(ahi));
+            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:1024" : "=v"(tq[6 + t2]) : "v"(ahi));
+        }
+        const f32x16 H = pool(PRC, acce, hp[T], q0[T], q1[T]);
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(tq[0]), "+v"(tq[1]), "+v"(tq[2]), "+v"(tq[3]), "+v"(tq[4]), "+v"(tq[5]), "+v"(tq[6]), "+v"(tq[7]));
+        const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        const i32x4 al0 = {tq[0][0], tq[0][1], tq[1][0], tq[1][1]}, al1 = {tq[2][0], tq[2][1], tq[3][0], tq[3][1]};
+        const i32x4 ah0 = {tq[4][0], tq[4][1], tq[5][0], tq[5][1]}, ah1 = {tq[6][0], tq[6][1], tq[7][0], tq[7][1]};
+        f32x16 r_lo = mfma32<DT>(al0, bw[T][0], zero);
+        f32x16 r_hi = mfma32<DT>(ah0, bw[T][0], zero);
+        r_lo = mfma32<DT>(al1, bw[T][1], r_lo);
+        r_hi = mfma32<DT>(ah1, bw[T][1], r_hi);
+        uint2 pk[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 sc1 = *reinterpret_cast<const f32x4*>(tabl + 8 * g);
+            const f32x4 sh1 = *reinterpret_cast<const f32x4*>(tabl + 32 + 8 * g);
+            const f32x4 sc2 = *reinterpret_cast<const f32x4*>(tabl + 64 + 8 * g);
+            float y[4];
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                y[jj] = fmaf(H[4 * g + jj], sc1[jj], sh1[jj]);
+                const float lo = r_lo[4 * g + jj];
+                const float rs = lo + (r_hi[4 * g + jj] - lo) * cx.yl;
+                y[jj] = fmaf(rs, sc2[jj], y[jj]);
+            }
+            pk[g].x = pack2<DT>(y[0], y[1]);
+            pk[g].y = pack2<DT>(y[2], y[3]);
+        }
+        i32x4 vv[2];
+#pragma unroll
+        for (int kk = 0; kk < 4; kk += 2) {
+            const auto sx = __builtin_amdgcn_permlane32_swap(pk[kk].x, pk[kk + 1].x, false, false);
+            const auto sy = __builtin_amdgcn_permlane32_swap(pk[kk].y, pk[kk + 1].y, false, false);
+            vv[kk / 2][0] = static_cast<int>(sx[0]);
+            vv[kk / 2][1] = static_cast<int>(sy[0]);
+            vv[kk / 2][2] = static_cast<int>(sx[1]);
+            vv[kk / 2][3] = static_cast<int>(sy[1]);
+        }
+        const int vo = voff[T] | cx.emit_mask;
+        __builtin_amdgcn_raw_buffer_store_b128(vv[0], cx.rs, vo, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(vv[1], cx.rs, vo + 32, 0, 0);
+    };
+#ifdef RN_STAMPS
+    unsigned long long st_bar = 0;
+#endif
     auto step = [&](auto PC, int t) __attribute__((always_inline)) {
         constexpr int P = decltype(PC)::value;
-        constexpr int PR = P & 1;                     // parity of both stages' conv rows (t-2, t-8)
-        // ---- scalars of this step's second-stage rows
+        constexpr int PR = P & 1;
         const int jo = t - F_LAG;
-        const int yo = yo0 + min(max(jo, 0), nrows - 1);
+        cx_cur.yl = vl_cur.yl;
+        cx_cur.sk_lo = static_cast<unsigned>(slot_cur * F_SKROW);
+        cx_cur.sk_hi = static_cast<unsigned>((vl_cur.ylo + 1 > W - 1 ? slot_cur : (slot_cur == F_NSK - 1 ? 0 : slot_cur + 1)) * F_SKROW);
+        cx_cur.rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(out_row), 0, out_row_bytes, 0x00020000);
+        cx_cur.emit_mask = jo >= 0 ? 0 : OOB;
+        if (jo >= 0 && jo < nrows - 1) out_row += out_row_bytes;
+        // deferred epilogue of the previous step's second tile (its conv row has the other parity)
+        epi(IC<1>{}, IC<1 - PR>{}, acc1, cx_prev);
+        // skip rows for the next step's residual (see stage23_kernel)
+        const VLerp vl_next = vlerp_of(yo0 + min(max(jo + 1, 0), nrows - 1));
         {
-            const float src = mul_rounded(static_cast<float>(yo), a.rscale);
-            const int ylo = static_cast<int>(src);
-            const int yhi = min(ylo + 1, W - 1);
-            cx_cur.yl = src - static_cast<float>(ylo);
-            cx_cur.sk_lo = skw_lds + static_cast<unsigned>(((ylo - ylo_base) % F_NSK) * F_SKROW);
-            cx_cur.sk_hi = skw_lds + static_cast<unsigned>(((yhi - ylo_base) % F_NSK) * F_SKROW);
-            cx_cur.rs = out_row_rsrc(yo);
-            cx_cur.emit_mask = jo >= 0 ? 0 : OOB;
-        }
-        const char* const a_next = a_row_ptr(t + 1);
-        // chain of job J with the micro-ops of job JE's epilogue behind its MFMAs (JE = J - 1; job 0 carries the
-        // deferred epilogue of the previous step's job 3, whose conv row has the other parity)
-        auto run = [&](auto JC, auto JEC, auto PREC, auto PWEC, const RowCtx& cxe) __attribute__((always_inline)) {
-            constexpr int J = decltype(JC)::value, JE = decltype(JEC)::value;
-            f32x16& accn = acc[J & 1];
-            const f32x16& acce = acc[JE & 1];
-            auto slotfn = [&](auto II) __attribute__((always_inline)) {
-                constexpr int I = decltype(II)::value;
-                if constexpr (J == 0) {
-                    // this step's A-row DMA (row t+1 -> slot (P+1) mod 4), one piece behind each of the first MFMAs
-                    if constexpr (I < 4) issue_A_piece(IC<(I < 4 ? I : 0)>{}, a_next, (P + 1) % F_NA);
-                }
-                [&]<int... K>(std::integer_sequence<int, K...>) {
-                    (([&] {
-                         if constexpr (K * KC / NM == I) mop(JEC, PREC, PWEC, IC<0>{}, IC<K>{}, acce, cxe);
-                     }()),
-                     ...);
-                }(std::make_integer_sequence<int, NM>{});
-                __builtin_amdgcn_sched_barrier(0);
-            };
-            mma_chain(JC, PC, accn, slotfn);
-        };
-        run(IC<0>{}, IC<3>{}, IC<1 - PR>{}, IC<(P + 3) % 4>{}, cx_prev);
-        // skip rows for the next step's residual: fetch while a slot is free (the deferred epilogue above was the
-        // last reader of the previous step's pair)
-        {
-            const int yo_next = yo0 + min(max(jo + 1, 0), nrows - 1);
-            const int need = min(ylo_of(yo_next) + 1, W - 1);
-            const int lowest = ylo_of(yo);
+            const int need = min(vl_next.ylo + 1, W - 1);
 #pragma unroll
             for (int it = 0; it < 2; ++it)
-                if (sk_fetched < need && sk_fetched - 2 < lowest) {
+                if (sk_fetched < need && sk_fetched - 2 < vl_cur.ylo) {
                     ++sk_fetched;
-                    issue_skip_row(sk_fetched, (sk_fetched - ylo_base) % F_NSK);
+                    sk_fetched_slot = sk_fetched_slot == F_NSK - 1 ? 0 : sk_fetched_slot + 1;
+                    issue_skip_row(sk_fetched, sk_fetched_slot);
                 }
         }
-        run(IC<1>{}, IC<0>{}, IC<PR>{}, IC<P>{}, cx_cur);
-        run(IC<2>{}, IC<1>{}, IC<PR>{}, IC<P>{}, cx_cur);
-        // everything this wave's DMA engine was asked for in this step (A row t+1, skip rows) has landed before the
-        // residual of this step reads the skip ring and before the barrier publishes the A row
-        wait_vmcnt<0>();
-        run(IC<3>{}, IC<2>{}, IC<PR>{}, IC<P>{}, cx_cur);
+        f32x16 acc0;
+        chain(IC<P>{}, IC<F_ROWB>{}, baseB[0], w3, acc0);       // conv row t-8: B rows t-8 .. t-6
+        wait_vmcnt<0>();                                       // this step's skip rows have landed
+        epi(IC<0>{}, IC<PR>{}, acc0, cx_cur);
+        chain(IC<P>{}, IC<F_ROWB>{}, baseB[1], w3, acc1);
         cx_prev = cx_cur;
+        {
+            int sl = slot_cur + (vl_next.ylo - vl_cur.ylo);
+            slot_cur = sl >= F_NSK ? sl - F_NSK : sl;
+            vl_cur = vl_next;
+        }
+#ifdef RN_STAMPS
+        const unsigned long long tb0 = stamp23();
+#endif
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         raw_barrier();
+#ifdef RN_STAMPS
+        st_bar += stamp23() - tb0;
+#endif
     };
-
+#ifdef RN_STAMPS
+    const unsigned long long st_loop0 = stamp23();
+#endif
     int t = 0;
     for (; t + 3 < nsteps; t += 4) {
         step(IC<0>{}, t);
@@ -450,21 +491,24 @@ __global__ __launch_bounds__(256, 1) void stage23_kernel(const Stage23Args a) {
         step(IC<2>{}, t + 2);
         step(IC<3>{}, t + 3);
     }
-    const int rem = nsteps - t;     // 0..3 steps left, phases 0, 1, 2
+    const int rem = nsteps - t;
     if (rem > 0) step(IC<0>{}, t);
     if (rem > 1) step(IC<1>{}, t + 1);
     if (rem > 2) step(IC<2>{}, t + 2);
-    // drain: the epilogue of the last step's job 3 (its conv row has the parity of the last step)
-    auto drain = [&](auto PRC) __attribute__((always_inline)) {
-        [&]<int... K>(std::integer_sequence<int, K...>) {
-            (mop(IC<3>{}, PRC, IC<0>{}, IC<1>{}, IC<K>{}, acc[1], cx_prev), ...);
-        }(std::make_integer_sequence<int, NM>{});
-    };
     if (((nsteps - 1) & 1) == 0)
-        drain(IC<0>{});
+        epi(IC<1>{}, IC<0>{}, acc1, cx_prev);
     else
-        drain(IC<1>{});
+        epi(IC<1>{}, IC<1>{}, acc1, cx_prev);
     wait_vmcnt<0>();
+#ifdef RN_STAMPS
+    if (a.stamp_buf && lane == 0) {
+        const int64_t w = (static_cast<int64_t>(blockIdx.y) * gridDim.x + blockIdx.x) * 8 + wave;
+        a.stamp_buf[w * 4 + 0] = stamp23() - st_loop0;
+        a.stamp_buf[w * 4 + 1] = 0;
+        a.stamp_buf[w * 4 + 2] = st_bar;
+        a.stamp_buf[w * 4 + 3] = static_cast<unsigned long long>(nsteps);
+    }
+#endif
 }
 
 }  // namespace
@@ -480,10 +524,10 @@ int rn_stage23_launch(int dtype, hipStream_t s, const Stage23Args& a, int n) {
             RN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             attr_devices.fetch_or(1ull << (dev & 63), std::memory_order_release);
         }
-        hipLaunchKernelGGL(kern, dim3(a.n_bands, n), dim3(256), F_LDS, s, a);
+        hipLaunchKernelGGL(kern, dim3(a.n_bands, n), dim3(512), F_LDS, s, a);
         RN_CHECK_LAUNCH();
         return RN_OK;
     };
-    if (dtype == RN_DTYPE_BF16) return launch(stage23_kernel<RN_DTYPE_BF16>);
-    return launch(stage23_kernel<RN_DTYPE_F16>);
+    if (dtype == RN_DTYPE_BF16) return launch(stage23pc_kernel<RN_DTYPE_BF16>);
+    return launch(stage23pc_kernel<RN_DTYPE_F16>);
 }
