@@ -181,6 +181,12 @@ RN_API int rn_timing(rn_handle* h, rn_stage_ms* out);
 /* Name of the kernel that dominates the forward pass of this handle (for
  * matching rocprofv3 rows) and the stage index it belongs to. */
 RN_API int rn_dominant_stage(const rn_handle* h);
+/* Launch grouping of the conv stages: the index of the stage under which the launch that
+ * computes `stage` reports its time in rn_stage_ms (== stage when the stage has a launch of
+ * its own; the last stage of the group when stages are fused across their boundary --
+ * the depth loop of conv_block, reference network.py:183-203, is then one kernel).
+ * Returns a negative code for a bad argument. */
+RN_API int rn_stage_launch(const rn_handle* h, int stage);
 
 /* ---- simple device memory helpers (so a host language without a HIP binding
  * can keep batches resident in HBM) ---------------------------------------- */

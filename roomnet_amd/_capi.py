@@ -33,7 +33,7 @@ EXPORTED_SYMBOLS = (
     "rn_create", "rn_destroy", "rn_last_error", "rn_device_count", "rn_version",
     "rn_forward_u8", "rn_forward_f32", "rn_forward_u8_device", "rn_forward_f32_device", "rn_sync",
     "rn_set_stream", "rn_node_count", "rn_node_info_get", "rn_tap", "rn_set_profiling", "rn_timing",
-    "rn_dominant_stage", "rn_device_malloc", "rn_device_free", "rn_memcpy_h2d", "rn_memcpy_d2h",
+    "rn_dominant_stage", "rn_stage_launch", "rn_device_malloc", "rn_device_free", "rn_memcpy_h2d", "rn_memcpy_d2h",
     "rn_crop_resize_u8_device", "rn_classify_images_u8",
 )
 
@@ -120,6 +120,8 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.rn_timing.restype = i32
     lib.rn_dominant_stage.argtypes = [vp]
     lib.rn_dominant_stage.restype = i32
+    lib.rn_stage_launch.argtypes = [vp, i32]
+    lib.rn_stage_launch.restype = i32
     lib.rn_device_malloc.argtypes = [vp, sz, C.POINTER(vp)]
     lib.rn_device_malloc.restype = i32
     lib.rn_device_free.argtypes = [vp, vp]
@@ -374,3 +376,14 @@ class Engine:
 
     def dominant_stage(self) -> int:
         return int(self.lib.rn_dominant_stage(self.handle))
+
+    def launch_groups(self):
+        """Conv stages grouped by launch: [[0], [1], [2, 3], [4], ...] when stages 2 and 3 run as one kernel.  A group's
+        time is reported under its last stage in `timing()["stage_ms"]`."""
+        groups = {}
+        for i in range(len(self.graph.stages)):
+            rep = int(self.lib.rn_stage_launch(self.handle, i))
+            if rep < 0:
+                raise RoomNetLibraryError(self.lib.rn_last_error().decode())
+            groups.setdefault(rep, []).append(i)
+        return [groups[k] for k in sorted(groups)]

@@ -815,6 +815,15 @@ extern "C" int rn_dominant_stage(const rn_handle* h) {
     return best;
 }
 
+extern "C" int rn_stage_launch(const rn_handle* h, int stage) {
+    if (!h || stage < 0 || stage >= static_cast<int>(h->stages.size())) {
+        rn_set_error("rn_stage_launch: bad argument");
+        return RN_E_RANGE;
+    }
+    const int pf = fused_mode(h) ? rn_fused_pair_first(h) : -1;
+    return (pf >= 0 && stage == pf) ? pf + 1 : stage;
+}
+
 extern "C" int rn_device_malloc(rn_handle* h, size_t bytes, void** d_ptr) {
     if (!h || !d_ptr) {
         rn_set_error("rn_device_malloc: bad argument");

@@ -184,6 +184,7 @@ class RoomNet:
             raise ValueError("Cannot feed value of shape %s for Tensor 'input_x_tensor:0', which has shape "
                              "'(?, %d, %d, 3)'" % (im.shape, self.im_side, self.im_side))
         eng = self._engine()
+        im = self._as_feed(im)
         if im.dtype == np.uint8:
             ids, probs = eng.forward_u8(im)
         else:
@@ -193,6 +194,19 @@ class RoomNet:
         if self.optimized_inference:
             return ids, probs
         return ids
+
+    def _as_feed(self, im):
+        """The reference takes any numeric array (network.py:128-135).  The 16-bit engines fuse the uint8 ->
+        [-1, 1] table into their first kernel and only take uint8: integral-valued arrays in [0, 255] are cast
+        (same values, same table), anything else is refused here with the reason instead of a library error."""
+        if im.dtype == np.uint8 or self.dtype == "f32":
+            return im
+        if im.size and (np.issubdtype(im.dtype, np.integer) or bool(np.all(im == np.rint(im)))) \
+                and im.min() >= 0 and im.max() <= 255:
+            return im.astype(np.uint8)
+        raise ValueError("RoomNet(dtype=%r) takes uint8 images (or integral values in [0, 255]); got %s with "
+                         "non-integral or out-of-range values -- construct with dtype='f32' for float feeds"
+                         % (self.dtype, im.dtype))
 
     def center_crop(self, x):
         """network.py:137-146."""
@@ -216,7 +230,7 @@ class RoomNet:
         h, w, _ = im.shape
         if h != self.im_side or w != self.im_side:
             im = resize_linear_u8(im, self.im_side, self.im_side)
-        im = np.ascontiguousarray(im)
+        im = self._as_feed(np.ascontiguousarray(im))
         if im.dtype == np.uint8:
             out_label_idx, out_label_conf = eng.forward_u8(im[None])
         else:

@@ -83,9 +83,15 @@ def all_gather_outputs(ids, probs, n_total: int, group=None):
 class DataParallelRoomNet:
     """Wraps a model exposing ``infer(batch) -> (ids, probs)`` (``RoomNet`` in optimized mode).
     Every rank calls ``infer`` with the same full batch (or only needs its own shard to be
-    valid); each classifies its shard and the outputs are all-gathered."""
+    valid); each classifies its shard and the outputs are all-gathered.
+
+    With a real ``RoomNet`` the shard stays on the GPU: it is uploaded once, classified with
+    ``rn_forward_u8_device`` straight into the packed result buffer and that buffer is what the collective
+    moves -- library kernels and the all-gather run on one explicit stream, so they are stream-ordered without a
+    host synchronisation.  Models without an engine (the gloo tests' stand-ins) go through ``infer`` on the host."""
 
     def __init__(self, model, group=None, forward: Optional[Callable] = None, device=None):
+        import torch
         import torch.distributed as dist
         if not dist.is_initialized():
             raise RuntimeError("torch.distributed is not initialised")
@@ -94,19 +100,49 @@ class DataParallelRoomNet:
         self.world_size = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
         self._forward = forward or model.infer
-        self.device = device
+        self._engine = None
+        self._stream = None
+        if forward is None and hasattr(model, "_engine") and hasattr(model, "graph"):
+            self._engine = model._engine()
+            if device is None:
+                device = torch.device("cuda", int(getattr(model, "device", 0)))
+            self._stream = torch.cuda.Stream(device)
+            self._engine.set_stream(self._stream.cuda_stream)
+        self.device = device if device is not None else "cpu"
 
     def infer(self, im_batch) -> Tuple[np.ndarray, np.ndarray]:
         import torch
         n = len(im_batch)
         lo, hi = shard_bounds(n, self.world_size, self.rank)
+        ncls = getattr(self.model, "num_classes", 6)
+        if self._engine is not None:
+            return self._infer_device(im_batch, n, lo, hi, ncls)
         if hi > lo:
             ids, probs = self._forward(im_batch[lo:hi])
         else:
-            ncls = getattr(self.model, "num_classes", 6)
             ids, probs = np.zeros((0,), np.int64), np.zeros((0, ncls), np.float32)
-        dev = self.device if self.device is not None else "cpu"
-        t_ids = torch.as_tensor(np.ascontiguousarray(ids), dtype=torch.int64).to(dev)
-        t_probs = torch.as_tensor(np.ascontiguousarray(probs), dtype=torch.float32).to(dev)
+        t_ids = torch.as_tensor(np.ascontiguousarray(ids), dtype=torch.int64).to(self.device)
+        t_probs = torch.as_tensor(np.ascontiguousarray(probs), dtype=torch.float32).to(self.device)
         g_ids, g_probs = all_gather_outputs(t_ids, t_probs, n, self.group)
         return g_ids.cpu().numpy(), g_probs.cpu().numpy()
+
+    def _infer_device(self, im_batch, n, lo, hi, ncls):
+        import torch
+        eng = self._engine
+        counts = shard_counts(n, self.world_size)
+        cmax = max(counts) if counts else 0
+        if cmax > eng.max_batch:
+            raise ValueError("shard of %d images exceeds the engine's max_batch %d" % (cmax, eng.max_batch))
+        shard = np.ascontiguousarray(np.asarray(im_batch[lo:hi], dtype=np.uint8))
+        with torch.cuda.stream(self._stream):
+            combo, probs, ids = result_buffers(cmax, ncls, self.device)
+            combo.zero_()
+            if hi > lo:
+                d_ims = torch.from_numpy(shard).to(self.device, non_blocking=False)
+                eng.forward_u8_device(d_ims.data_ptr(), hi - lo, probs.data_ptr(), ids.data_ptr())
+            packed = all_gather_packed(combo, self.group)
+            parts = [unpack_results(packed[r], cmax, ncls) for r in range(self.world_size)]
+            out_i = torch.cat([parts[r][0][:counts[r]] for r in range(self.world_size)])
+            out_p = torch.cat([parts[r][1][:counts[r]] for r in range(self.world_size)])
+            out_i, out_p = out_i.cpu(), out_p.cpu()
+        return out_i.numpy(), out_p.numpy()

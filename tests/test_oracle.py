@@ -106,70 +106,15 @@ def test_argmax_lowest_index_on_ties():
 
 
 def test_torch_cpu_cross_check(weights, parity_images):
-    """Third, independent restatement with torch-CPU library ops."""
-    torch = pytest.importorskip("torch")
-    import torch.nn.functional as F
-    torch.set_num_threads(4)
+    """Third, independent restatement with torch-CPU library ops (oracle/torch_ref.py)."""
+    pytest.importorskip("torch")
+    from oracle import torch_ref
     idx = [14, 30]
-    x = torch.from_numpy(R.preprocess_batch(parity_images[idx])).permute(0, 3, 1, 2).contiguous()
-    w = {k: torch.from_numpy(np.asarray(v)) for k, v in weights.items()}
-
-    def nm(base, i):
-        return base if i == 0 else "%s_%d" % (base, i)
-
-    state = {"conv": 0, "bn": 0}
-
-    def bn(t):
-        n = nm("batch_normalization", state["bn"])
-        state["bn"] += 1
-        inv = torch.rsqrt(w[n + "/moving_variance"] + 1e-3) * w[n + "/gamma"]
-        shape = (1, -1, 1, 1) if t.dim() == 4 else (1, -1)
-        if t.dim() == 4:
-            return (t - w[n + "/moving_mean"].view(shape)) * inv.view(shape) + w[n + "/beta"].view(shape)
-        return t * inv.view(shape) + (w[n + "/beta"] - w[n + "/moving_mean"] * inv).view(shape)
-
-    def legacy_resize(t, out):
-        _, _, h, wd = t.shape
-        ylo, yhi, yl = R.resize_tables(h, out)
-        xlo, xhi, xl = R.resize_tables(wd, out)
-        yl = torch.from_numpy(yl).view(1, 1, -1, 1)
-        xl = torch.from_numpy(xl).view(1, 1, 1, -1)
-        rows0, rows1 = t[:, :, torch.from_numpy(ylo)], t[:, :, torch.from_numpy(yhi)]
-        xlo_t, xhi_t = torch.from_numpy(xlo), torch.from_numpy(xhi)
-        top = rows0[..., xlo_t] + (rows0[..., xhi_t] - rows0[..., xlo_t]) * xl
-        bot = rows1[..., xlo_t] + (rows1[..., xhi_t] - rows1[..., xlo_t]) * xl
-        return top + (bot - top) * yl
-
-    def block(t, pooling=True, k=3, s=1, depth=1):
-        first = None
-        for d in range(depth):
-            kern = w[nm("conv2d", state["conv"]) + "/kernel"].permute(3, 2, 0, 1).contiguous()
-            state["conv"] += 1
-            t = torch.clamp(F.conv2d(t, kern), 0.0, 6.0)
-            if pooling:
-                t = F.avg_pool2d(t, k, s)
-            t = bn(t)
-            if d == 0:
-                first = t
-        if depth > 1:
-            t = bn(t + legacy_resize(first, t.shape[2]))
-        return t
-
-    with torch.no_grad():
-        t = block(x)
-        t = block(t, k=4, s=1, depth=3)
-        t = block(t, k=4, s=2, depth=2)
-        t = block(t, pooling=False)
-        t = block(t, k=4, s=2, depth=3)
-        t = t.permute(0, 2, 3, 1).reshape(t.shape[0], -1)
-        for i in range(3):
-            t = bn(torch.clamp(t @ w[nm("dense", i) + "/kernel"], 0.0, 6.0))
-        logits = torch.clamp(t @ w["dense_3/kernel"] + w["dense_3/bias"], 0.0, 6.0)
-        probs = torch.softmax(logits, dim=-1)
+    got = torch_ref.infer(weights, parity_images[idx], threads=4)
     rc = c_oracle.infer(weights, parity_images[idx])
-    np.testing.assert_allclose(logits.numpy(), rc["logits"], atol=TOL_LOGITS_F32, rtol=0)
-    np.testing.assert_allclose(probs.numpy(), rc["probs"], atol=TOL_PROBS_F32, rtol=0)
-    np.testing.assert_array_equal(probs.argmax(-1).numpy(), rc["ids"])
+    np.testing.assert_allclose(got["logits"], rc["logits"], atol=TOL_LOGITS_F32, rtol=0)
+    np.testing.assert_allclose(got["probs"], rc["probs"], atol=TOL_PROBS_F32, rtol=0)
+    np.testing.assert_array_equal(got["ids"], rc["ids"])
 
 
 def test_600_variant_golden(weights):

@@ -115,3 +115,24 @@ def test_bf16_model_through_the_python_surface(weights, parity_images, golden_pa
     safe = golden_parity["top2_margin"][:8] > 0.2
     np.testing.assert_array_equal(ids[safe], golden_parity["ids"][:8][safe])
     net.sess.close()
+
+
+def test_16bit_model_takes_integral_feeds_and_refuses_fractional_ones(parity_images):
+    """The reference accepts any numeric array (network.py:128-135).  A 16-bit model fuses the uint8 table into its
+    first kernel: integral arrays in [0, 255] are the same feed, anything else is refused with the reason."""
+    from roomnet_amd.network import RoomNet
+    net = RoomNet(num_classes=6, im_side=224, compute_bn_mean_var=False, optimized_inference=True, max_batch=4, dtype="bf16")
+    net.load(MODEL_PREFIX)
+    try:
+        ims = parity_images[[9, 30]]
+        ids, probs = net.infer(ims)
+        for other in (ims.astype(np.int32), ims.astype(np.float64)):
+            ids2, probs2 = net.infer(other)
+            np.testing.assert_array_equal(probs2, probs)
+            np.testing.assert_array_equal(ids2, ids)
+        with pytest.raises(ValueError, match="dtype='f32'"):
+            net.infer(ims.astype(np.float32) + 0.25)
+        with pytest.raises(ValueError):
+            net.infer(ims.astype(np.int32) - 1)
+    finally:
+        net.sess.close()
