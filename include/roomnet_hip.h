@@ -42,9 +42,19 @@ extern "C" {
 #define RN_E_STATE (-4)     /* call not valid in the handle's current state        */
 #define RN_E_RANGE (-5)     /* n exceeds max_batch, bad node id, buffer too small  */
 
-/* storage / MFMA input type of activations and conv weights.  Accumulation,
- * ReLU6, pooling, BN, the residual resize-add and the dense head are always
- * float32. */
+/* storage / MFMA input type of activations and conv weights.  float32 everywhere on
+ * RN_DTYPE_F32 handles.  On the 16-bit handles: conv accumulation, ReLU6, BN, the vertical
+ * part of the residual interpolation, the dense head and the softmax are float32; what is
+ * NOT float32 (all inside the tolerances of tests/test_hip_fused.py):
+ *   - stage 0 feeds its MFMA fp16 inputs in BOTH 16-bit modes (bf16 cannot hold the 256
+ *     input levels);
+ *   - avg-pool 4x4 stride 1 (stages 1-3): ReLU6 outputs are rounded to fp16, vertical pair
+ *     sums are fp16 adds, and the window sums run on the matrix cores (fp16 x 0/1 band
+ *     matrix, exact float32 accumulation); stride-2 pools are float32 VALU sums;
+ *   - residual resize: the horizontal interpolation is an MFMA against the interpolation
+ *     matrix in the storage type -- stage 3: one operand, lerp fraction rounded to 2^-8
+ *     (bf16) / 2^-11 (fp16) so that both weights are exact; stages 5, 9: hi + lo split
+ *     (~16-bit weights). */
 #define RN_DTYPE_F32 0      /* reference arithmetic type (TensorFlow float32)      */
 #define RN_DTYPE_BF16 1
 #define RN_DTYPE_F16 2

@@ -21,6 +21,11 @@ def imread(path: str) -> Optional[np.ndarray]:
         from PIL import Image, ImageOps
         with Image.open(path) as im:
             im = ImageOps.exif_transpose(im)
+            if im.mode in ("I;16", "I;16B", "I;16L", "I"):
+                # 16-bit grey: cv2.imread(IMREAD_COLOR) scales to 8 bits by >> 8 (Pillow's convert() would clip)
+                a = np.asarray(im)
+                a8 = (a.astype(np.int64).clip(0, 65535) >> 8).astype(np.uint8)    # libpng strip_16: the high byte
+                return np.ascontiguousarray(np.repeat(a8[:, :, None], 3, axis=2))
             if im.mode in ("RGBA", "LA", "P"):
                 im = im.convert("RGBA").convert("RGB") if im.mode != "P" else im.convert("RGB")
             elif im.mode != "RGB":

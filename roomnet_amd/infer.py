@@ -64,7 +64,9 @@ def _infer_files(nn, fpaths, batch_size):
         batch = np.stack([p[2] for p in pending], 0)
         outs = nn.infer(batch)
         ids, probs = outs if isinstance(outs, tuple) else (outs, None)
-        res = [(p[0], p[1], int(ids[k]), (float(probs[k][ids[k]]) if probs is not None else float('nan')))
+        # the confidence stays an np.float32 scalar like infer_outs[1][0][idx] of the reference (infer.py:84): its
+        # printed form, round(conf * 100, 2) and str(conf) are float32 results
+        res = [(p[0], p[1], int(ids[k]), (probs[k][ids[k]] if probs is not None else np.float32('nan')))
                for k, p in enumerate(pending)]
         pending.clear()
         return res
@@ -124,8 +126,10 @@ def classify_im_dir(nn, imgs_dir, overlay=True, batch_size=64):
     sheet = excel_file.add_sheet('classification_results')
     sheet.write(0, 0, 'IMAGE_NAME')
     sheet.write(0, 1, 'PREDICTED_LABEL')
+    row = 0      # unreadable files are skipped (the reference crashes on them): rows stay contiguous
     for i, im, idx, pred_conf in _infer_files(nn, all_im_paths, batch_size):
         fpath = all_im_paths[i]
+        row += 1
         pred_label = CLASS_LABELS[idx]
         out_fpath_dir = out_dir + os.sep + pred_label
         print(fpath, '--->', pred_label, pred_conf)
@@ -137,9 +141,9 @@ def classify_im_dir(nn, imgs_dir, overlay=True, batch_size=64):
             imwrite(out_fpath_dir + os.sep + fpath.split(os.sep)[-1], im)
         else:
             shutil.copy(fpath, out_fpath_dir)
-        sheet.write(i + 1, 0, fpath.split(os.sep)[-1])
-        sheet.write(i + 1, 1, pred_label)
-        sheet.write(i + 1, 2, str(np.float32(pred_conf)))
+        sheet.write(row, 0, fpath.split(os.sep)[-1])
+        sheet.write(row, 1, pred_label)
+        sheet.write(row, 2, str(pred_conf))
     excel_file.save(xl_fpath)
     return xl_fpath
 

@@ -183,3 +183,79 @@ def test_roomnet_init_load_save_semantics(tmp_path, weights, capsys, monkeypatch
         nn.train_step(None, None)
     x = np.arange(4 * 7 * 3).reshape(4, 7, 3)
     np.testing.assert_array_equal(nn.center_crop(x), x[:, 1:5, :])
+
+
+def test_imread_16bit_grey_takes_the_high_byte(tmp_path):
+    """cv2.imread(path) (IMREAD_COLOR) strips 16-bit samples to their high byte; Pillow's convert() would clip."""
+    from PIL import Image
+    from roomnet_amd.imageio import imread
+    a = (np.arange(64 * 48, dtype=np.uint32).reshape(48, 64) * 21 % 65536).astype(np.uint16)
+    p = str(tmp_path / "g16.png")
+    Image.fromarray(a).save(p)
+    im = imread(p)
+    assert im.shape == (48, 64, 3) and im.dtype == np.uint8
+    np.testing.assert_array_equal(im[:, :, 0], (a >> 8).astype(np.uint8))
+    np.testing.assert_array_equal(im[:, :, 1], im[:, :, 2])
+
+
+def test_xls_workbook_structure_follows_ms_xls(tmp_path):
+    """Structural check of the BIFF8 stream against [MS-XLS] -- independent of tests/xls_reader.py's cell decoding:
+    globals substream BOF(0x0005) ... EOF, one BOUNDSHEET8 per sheet whose lbPlyPos points at that sheet's BOF(0x0010),
+    SST total / unique counts, DIMENSIONS bounds, every LABELSST index inside the SST, BOF/EOF strictly paired."""
+    import struct
+    from roomnet_amd import xls
+    from xls_reader import workbook_stream
+    wb = xls.Workbook()
+    sh = wb.add_sheet("classification_results")
+    sh.write(0, 0, "IMAGE_NAME")
+    sh.write(0, 1, "PREDICTED_LABEL")
+    names = ["img_%03d.png" % i for i in range(300)]            # > 8224 bytes of strings: SST spills into CONTINUE
+    for i, nm in enumerate(names):
+        sh.write(i + 1, 0, nm)
+        sh.write(i + 1, 1, ["Kitchen", "Bedroom"][i % 2])
+        sh.write(i + 1, 2, str(np.float32(0.5 + i / 1000.0)))
+    p = str(tmp_path / "s.xls")
+    wb.save(p)
+    stream = workbook_stream(p)
+    recs, off = [], 0
+    while off < len(stream):
+        rid, ln = struct.unpack_from("<HH", stream, off)
+        recs.append((rid, off, stream[off + 4:off + 4 + ln]))
+        off += 4 + ln
+        assert ln <= 8224, "record %04x longer than the BIFF8 limit" % rid
+    assert off == len(stream)
+    ids = [r[0] for r in recs]
+    # BOF / EOF pairing: globals substream first, then one worksheet substream
+    assert ids[0] == 0x0809 and struct.unpack_from("<HH", recs[0][2])[:2] == (0x0600, 0x0005)
+    depth, substreams = 0, []
+    for rid, roff, body in recs:
+        if rid == 0x0809:
+            assert depth == 0
+            depth = 1
+            substreams.append((struct.unpack_from("<H", body, 2)[0], roff))
+        elif rid == 0x000A:
+            assert depth == 1
+            depth = 0
+    assert depth == 0 and [t for t, _ in substreams] == [0x0005, 0x0010]
+    # BOUNDSHEET8: stream offset of the sheet's BOF, visible worksheet, name
+    bs = [body for rid, _, body in recs if rid == 0x0085]
+    assert len(bs) == 1
+    lbplypos, hs, dt, cch, fhigh = struct.unpack_from("<IBBBB", bs[0])
+    assert lbplypos == substreams[1][1] and hs == 0 and dt == 0
+    nm = bs[0][8:8 + cch * (2 if fhigh else 1)].decode("utf-16-le" if fhigh else "latin-1")
+    assert nm == "classification_results"
+    # SST: total references and unique strings
+    sst = [body for rid, _, body in recs if rid == 0x00FC]
+    assert len(sst) == 1
+    total, unique = struct.unpack_from("<II", sst[0])
+    n_label = sum(1 for rid in ids if rid == 0x00FD)
+    assert total == n_label == 2 + 3 * 300
+    assert unique == 2 + 300 + 2 + 300                          # headers + names + 2 labels + 300 distinct confidences
+    assert any(rid == 0x003C for rid in ids), "an SST this large must continue in CONTINUE records"
+    for rid, _, body in recs:
+        if rid == 0x00FD:
+            r, c, xf, isst = struct.unpack_from("<HHHI", body)
+            assert isst < unique and r <= 300 and c <= 2
+    # DIMENSIONS of the sheet: rows [0, 301), columns [0, 3)
+    dim = [body for rid, roff, body in recs if rid == 0x0200 and roff > substreams[1][1]]
+    assert struct.unpack_from("<IIHH", dim[0]) == (0, 301, 0, 3)

@@ -136,3 +136,35 @@ def test_16bit_model_takes_integral_feeds_and_refuses_fractional_ones(parity_ima
             net.infer(ims.astype(np.int32) - 1)
     finally:
         net.sess.close()
+
+
+def test_groundtruth_validation_from_a_list_file(nn, weights, parity_images, tmp_path, capsys):
+    """The batched validation driver (reference infer.py:41-57 with train.py:146-152's metrics): a list file whose
+    paths contain spaces -> predictions equal to the oracle's ids -> accuracy / precision / recall / f-score equal to
+    sklearn on those ids."""
+    from sklearn.metrics import accuracy_score, precision_recall_fscore_support
+    from roomnet_amd.infer import groundtruth_validation, read_fpaths
+    d = tmp_path / "val set with spaces"
+    d.mkdir()
+    pick = list(range(3, 35, 2))                               # 16 images
+    ref_ids = c_oracle.infer(weights, parity_images[pick])["ids"]
+    rng = np.random.default_rng(5)
+    truth = [int(ref_ids[k]) if rng.random() < 0.7 else int(rng.integers(0, 6)) for k in range(len(pick))]
+    lines = []
+    for k, i in enumerate(pick):
+        p = d / ("room %02d.png" % k)
+        assert imageio.imwrite(str(p), parity_images[i])
+        lines.append("%s %d" % (p, truth[k]))
+    lst = tmp_path / "val_list.txt"
+    lst.write_text("\n".join(lines) + "\n")
+    paths, labels, n = read_fpaths(str(lst))
+    assert n == 16 and labels == truth and all(" " in p for p in paths)
+    stats = groundtruth_validation(nn, str(lst), batch_size=5)
+    out = capsys.readouterr().out
+    assert "Inferring Images..." in out and "accuracy" in out
+    acc = accuracy_score(truth, ref_ids)
+    prec, rec, fsc, _ = precision_recall_fscore_support(truth, ref_ids, zero_division=0)
+    assert stats["accuracy"] == pytest.approx(float(acc))
+    np.testing.assert_allclose(stats["precisions"], prec)
+    np.testing.assert_allclose(stats["recalls"], rec)
+    np.testing.assert_allclose(stats["f-scores"], fsc)

@@ -3,7 +3,17 @@
 import struct
 
 
+def workbook_stream(path):
+    """The raw BIFF8 `Workbook` stream of an OLE2 compound document."""
+    return _open(path)
+
+
 def read_xls(path):
+    stream = _open(path)
+    return _decode(stream)
+
+
+def _open(path):
     data = open(path, "rb").read()
     assert data[:8] == b"\xD0\xCF\x11\xE0\xA1\xB1\x1A\xE1", "not an OLE2 compound document"
     sect_shift, = struct.unpack_from("<H", data, 30)
@@ -38,6 +48,10 @@ def read_xls(path):
             assert size >= cutoff, "Workbook stream would live in the mini stream"
             stream = chain(start)[:size]
     assert stream is not None, "no Workbook stream"
+    return stream
+
+
+def _decode(stream):
 
     def records(buf, pos=0):
         while pos + 4 <= len(buf):
