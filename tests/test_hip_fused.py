@@ -333,3 +333,59 @@ def test_600_variant_vs_golden(weights, dtype, tol):
                 assert rel <= STAGE_TOL[dtype] * 1.5, (name, rel)
     finally:
         e.close()
+
+
+@pytest.mark.parametrize("dtype", ["f16", "bf16"])
+def test_600_variant_at_baseline_size_64_images(weights, dtype):
+    """BASELINE config 5 at its per-GPU size (64 x 600x600, 16-bit) through size-independent properties: every image's
+    result equals, bit for bit, what the same image gets in the batch of 4 that the golden file pins; a permuted batch
+    gives the permuted results; a second pass is identical; a ragged tail (63 + 1) is identical; stage outputs do not
+    depend on the launch geometry (bands x column blocks differ between batch 1, 4 and 64)."""
+    import os
+    from conftest import GOLDEN
+    from oracle import roomnet_ref as R
+    from roomnet_amd.synth import parity_batch
+    g = np.load(os.path.join(GOLDEN, "parity_600.npz"))
+    w = dict(weights)
+    w["dense/kernel"] = R.synth_dense_kernel_600()
+    pool = parity_batch(600, seed=1)
+    gi = [int(i) for i in g["image_indices"]]
+    rng = np.random.default_rng(64)
+    pick = np.concatenate([gi, rng.integers(0, len(pool), 60)])
+    ims = pool[pick]
+    big = _capi.Engine(build_graph(6, 600), w, device=0, dtype=dtype, max_batch=64)
+    small = _capi.Engine(build_graph(6, 600), w, device=0, dtype=dtype, max_batch=4)
+    try:
+        ids, probs = big.forward_u8(ims)
+        s3, s5, s7 = big.tap("s3.bn2", 64)[:4], big.tap("s5.bn2", 64)[:4], big.tap("s7.bn", 64)
+        assert np.isfinite(s7).all()
+        ids4, probs4 = small.forward_u8(pool[gi])
+        np.testing.assert_array_equal(probs[:4], probs4)
+        np.testing.assert_array_equal(ids[:4], ids4)
+        np.testing.assert_array_equal(small.tap("s3.bn2", 4), s3)          # 64-image vs 4-image launch geometry
+        np.testing.assert_array_equal(small.tap("s5.bn2", 4), s5)
+        logits4 = small.tap("d3.relu", 4)
+        assert np.abs(logits4 - g["logits_f64"]).max() <= TOL_LOGITS
+        safe = g["top2_margin"] > MARGIN
+        np.testing.assert_array_equal(ids[:4][safe], g["ids"][safe])
+        # every other image against its batch-of-4 result
+        for c0 in range(4, 64, 4):
+            _, p4 = small.forward_u8(ims[c0:c0 + 4])
+            np.testing.assert_array_equal(probs[c0:c0 + 4], p4)
+        _, p1 = small.forward_u8(ims[7:8])                                  # batch of one: yet another geometry
+        np.testing.assert_array_equal(p1[0], probs[7])
+        np.testing.assert_array_equal(small.tap("s3.bn2", 1)[0], big.tap("s3.bn2", 64)[7])
+        perm = rng.permutation(64)
+        ids_p, probs_p = big.forward_u8(ims[perm])
+        np.testing.assert_array_equal(probs_p, probs[perm])
+        np.testing.assert_array_equal(ids_p, ids[perm])
+        np.testing.assert_array_equal(big.tap("s7.bn", 64), s7[perm])
+        _, probs_2 = big.forward_u8(ims[perm])
+        np.testing.assert_array_equal(probs_2, probs_p)
+        _, probs_r = big.forward_u8(ims[:63])
+        np.testing.assert_array_equal(probs_r, probs[:63])
+        _, probs_1 = big.forward_u8(ims[63:])
+        np.testing.assert_array_equal(probs_1, probs[63:])
+    finally:
+        big.close()
+        small.close()
