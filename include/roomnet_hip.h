@@ -198,6 +198,33 @@ RN_API int rn_dominant_stage(const rn_handle* h);
  * Returns a negative code for a bad argument. */
 RN_API int rn_stage_launch(const rn_handle* h, int stage);
 
+/* ---- several GPUs from one process ------------------------------------------------
+ * The reference is one tf.Session on one device (network.py:89).  A group is one rn_handle
+ * per device; a batch is split contiguously (device d gets images [d*n/N, (d+1)*n/N), the
+ * first n % N devices one more) and the ONLY exchange on the data path is one RCCL
+ * all-gather of every device's packed results over xGMI: per device `slot_bytes` =
+ * max_batch_per_device * (num_classes * 4 + 8) bytes = probs [cap, C] float32 followed by
+ * ids [cap] int64 (32 bytes per image).  librccl is loaded on the first rn_group_create.
+ * One host thread drives all devices; calls on one group must be serialised by the caller. */
+typedef struct rn_group rn_group;
+/* devices == NULL: devices 0 .. ndev-1.  Weights are replicated (0.7 MB). */
+RN_API int rn_group_create(const rn_weights* w, int ndev, const int* devices, int dtype, int max_batch_per_device,
+                           unsigned flags, rn_group** out);
+RN_API void rn_group_destroy(rn_group* g);
+RN_API int rn_group_size(const rn_group* g);
+RN_API rn_handle* rn_group_handle(rn_group* g, int index);     /* the per-device handle (profiling, taps) */
+/* RoomNet.infer(im_batch) (reference network.py:128-135) over all devices: host BGR uint8
+ * [n,S,S,3] in, (softmax [n,C], argmax [n]) on the host out; n <= ndev * max_batch_per_device.
+ * Blocks until the results are in probs/ids. */
+RN_API int rn_group_forward_u8(rn_group* g, const uint8_t* bgr_nhwc, int n, float* probs, int64_t* ids);
+/* Device-resident form: d_shards[d] = device d's images already in its HBM, counts[d] of them.
+ * Asynchronous: enqueues the forward passes and the all-gather on the devices' streams;
+ * afterwards rn_group_result_buffer(g, d, ...) on ANY device holds all devices' packed results
+ * ([ndev][slot_bytes], device d's slot at d * slot_bytes).  rn_group_sync waits for all of it. */
+RN_API int rn_group_forward_u8_device(rn_group* g, const uint8_t* const* d_shards, const int* counts);
+RN_API int rn_group_result_buffer(rn_group* g, int index, void** d_gathered, size_t* slot_bytes);
+RN_API int rn_group_sync(rn_group* g);
+
 /* ---- simple device memory helpers (so a host language without a HIP binding
  * can keep batches resident in HBM) ---------------------------------------- */
 RN_API int rn_device_malloc(rn_handle* h, size_t bytes, void** d_ptr);

@@ -35,6 +35,8 @@ EXPORTED_SYMBOLS = (
     "rn_set_stream", "rn_node_count", "rn_node_info_get", "rn_tap", "rn_set_profiling", "rn_timing",
     "rn_dominant_stage", "rn_stage_launch", "rn_device_malloc", "rn_device_free", "rn_memcpy_h2d", "rn_memcpy_d2h",
     "rn_crop_resize_u8_device", "rn_classify_images_u8",
+    "rn_group_create", "rn_group_destroy", "rn_group_size", "rn_group_handle", "rn_group_forward_u8",
+    "rn_group_forward_u8_device", "rn_group_result_buffer", "rn_group_sync",
 )
 
 
@@ -134,6 +136,22 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.rn_crop_resize_u8_device.restype = i32
     lib.rn_classify_images_u8.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_int), C.POINTER(C.c_int), i32, vp, vp]
     lib.rn_classify_images_u8.restype = i32
+    lib.rn_group_create.argtypes = [C.POINTER(rn_weights), i32, C.POINTER(C.c_int), i32, i32, C.c_uint, C.POINTER(vp)]
+    lib.rn_group_create.restype = i32
+    lib.rn_group_destroy.argtypes = [vp]
+    lib.rn_group_destroy.restype = None
+    lib.rn_group_size.argtypes = [vp]
+    lib.rn_group_size.restype = i32
+    lib.rn_group_handle.argtypes = [vp, i32]
+    lib.rn_group_handle.restype = vp
+    lib.rn_group_forward_u8.argtypes = [vp, vp, i32, vp, vp]
+    lib.rn_group_forward_u8.restype = i32
+    lib.rn_group_forward_u8_device.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_int)]
+    lib.rn_group_forward_u8_device.restype = i32
+    lib.rn_group_result_buffer.argtypes = [vp, i32, C.POINTER(vp), C.POINTER(sz)]
+    lib.rn_group_result_buffer.restype = i32
+    lib.rn_group_sync.argtypes = [vp]
+    lib.rn_group_sync.restype = i32
     if path is None:
         _lib = lib
     return lib
@@ -387,3 +405,49 @@ class Engine:
                 raise RoomNetLibraryError(self.lib.rn_last_error().decode())
             groups.setdefault(rep, []).append(i)
         return [groups[k] for k in sorted(groups)]
+
+
+class Group:
+    """One rn_group: the model replicated on several GPUs of this process, batches sharded contiguously, one RCCL
+    all-gather of the packed results (the C ABI's multi-GPU entry, include/roomnet_hip.h)."""
+
+    def __init__(self, graph: Graph, weights: Dict[str, np.ndarray], devices: Sequence[int], dtype="bf16",
+                 max_batch_per_device: int = 64, lib_path: Optional[str] = None):
+        self.lib = load_library(lib_path)
+        self.graph = graph
+        self.devices = [int(d) for d in devices]
+        self.cap = int(max_batch_per_device)
+        packed = _Packed(graph, weights)
+        dt = DTYPES[dtype] if isinstance(dtype, str) else int(dtype)
+        devs = (C.c_int * len(self.devices))(*self.devices)
+        g = C.c_void_p()
+        rc = self.lib.rn_group_create(C.byref(packed.w), len(self.devices), devs, dt, self.cap, 0, C.byref(g))
+        _check(self.lib, rc, "rn_group_create")
+        self._g = g
+
+    def forward_u8(self, bgr_nhwc: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
+        s = self.graph.im_side
+        x = np.ascontiguousarray(bgr_nhwc, dtype=np.uint8)
+        if x.ndim != 4 or x.shape[1:] != (s, s, 3):
+            raise ValueError("expected uint8 [n,%d,%d,3], got %s" % (s, s, x.shape))
+        n = x.shape[0]
+        probs = np.empty((n, self.graph.num_classes), np.float32)
+        ids = np.empty((n,), np.int64)
+        step = self.cap * len(self.devices)
+        for i in range(0, n, step):
+            m = min(step, n - i)
+            rc = self.lib.rn_group_forward_u8(self._g, x[i:i + m].ctypes.data, m, probs[i:i + m].ctypes.data,
+                                              ids[i:i + m].ctypes.data)
+            _check(self.lib, rc, "rn_group_forward_u8")
+        return ids, probs
+
+    def close(self) -> None:
+        if self._g:
+            self.lib.rn_group_destroy(self._g)
+            self._g = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

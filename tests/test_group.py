@@ -1,0 +1,43 @@
+"""The C ABI's multi-GPU entry (rn_group_*, include/roomnet_hip.h): one handle per device, contiguous shards, one RCCL
+all-gather of the packed results.  The GPU boxes of this pool have ONE MI355X, so what runs here is the one-device
+group (RCCL communicator of size 1, the same code path); more devices are unmeasured on hardware."""
+import numpy as np
+import pytest
+
+from roomnet_amd import _capi
+from roomnet_amd.graph import build_graph
+
+pytestmark = pytest.mark.gpu
+
+
+def test_one_device_group_matches_the_plain_handle(weights, parity_images):
+    g = build_graph(6, 224)
+    grp = _capi.Group(g, weights, devices=[0], dtype="bf16", max_batch_per_device=8)
+    eng = _capi.Engine(g, weights, device=0, dtype="bf16", max_batch=8)
+    try:
+        for idx in ([3], list(range(5, 13)), list(range(0, 19))):          # 1, 8 (= capacity) and 19 (chunked) images
+            ims = parity_images[idx]
+            ids_g, probs_g = grp.forward_u8(ims)
+            ids_e, probs_e = eng.forward_u8(ims)
+            np.testing.assert_array_equal(probs_g, probs_e)
+            np.testing.assert_array_equal(ids_g, ids_e)
+    finally:
+        grp.close()
+        eng.close()
+
+
+def test_group_argument_checks(weights):
+    g = build_graph(6, 224)
+    with pytest.raises(ValueError):
+        _capi.Group(g, weights, devices=[0, 0], dtype="bf16", max_batch_per_device=2)      # a device listed twice
+    with pytest.raises(ValueError):
+        _capi.Group(g, weights, devices=[0], dtype="bf16", max_batch_per_device=0)
+    grp = _capi.Group(g, weights, devices=[0], dtype="f16", max_batch_per_device=2)
+    try:
+        assert grp.lib.rn_group_size(grp._g) == 1
+        buf = np.zeros((3, 224, 224, 3), np.uint8)
+        probs, ids = np.zeros((3, 6), np.float32), np.zeros((3,), np.int64)
+        rc = grp.lib.rn_group_forward_u8(grp._g, buf.ctypes.data, 3, probs.ctypes.data, ids.ctypes.data)    # > capacity
+        assert rc < 0 and b"out of range" in grp.lib.rn_last_error()
+    finally:
+        grp.close()
