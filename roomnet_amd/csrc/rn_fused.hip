@@ -830,7 +830,7 @@ int rn_fused_forward(rn_handle* h, const uint8_t* d_bgr, const float* d_rgb, int
             static unsigned long long* stamp_host23 = nullptr;
             const size_t nwaves23 = static_cast<size_t>(fa.n_bands) * n * 8;
             if (!stamp_host23) (void)hipHostMalloc(reinterpret_cast<void**>(&stamp_host23), 16u << 20, 0);
-            std::memset(stamp_host23, 0, nwaves23 * 32);
+            std::memset(stamp_host23, 0, nwaves23 * 96);
             fa.stamp_buf = stamp_host23;
 #endif
             int rc = rn_stage23_launch(h->dtype, h->stream, fa, n);
@@ -843,6 +843,20 @@ int rn_fused_forward(rn_handle* h, const uint8_t* d_bgr, const float* d_rgb, int
                     wtot[k & 7] += stamp_host23[k * 4];
                     wbar[k & 7] += stamp_host23[k * 4 + 2];
                     wsteps[k & 7] += stamp_host23[k * 4 + 3];
+                }
+                {
+                    double seg[2][6] = {{0}, {0}};
+                    double st[2] = {0, 0};
+                    const unsigned long long* base = stamp_host23 + nwaves23 * 4;
+                    for (size_t k = 0; k < nwaves23; ++k) {
+                        const int role = (k & 7) < 4 ? 0 : 1;
+                        st[role] += stamp_host23[k * 4 + 3];
+                        for (int j = 0; j < 6; ++j) seg[role][j] += base[k * 8 + j];
+                    }
+                    fprintf(stderr, "[stamps]   producer segments (chain0 epi0 chain1 epi1): %.0f %.0f %.0f %.0f\n", seg[0][0] / st[0], seg[0][1] / st[0],
+                            seg[0][2] / st[0], seg[0][3] / st[0]);
+                    fprintf(stderr, "[stamps]   consumer segments (epi1' fetch chain0 dma-wait epi0 chain1): %.0f %.0f %.0f %.0f %.0f %.0f\n", seg[1][0] / st[1],
+                            seg[1][1] / st[1], seg[1][2] / st[1], seg[1][3] / st[1], seg[1][4] / st[1], seg[1][5] / st[1]);
                 }
                 for (int w8 = 0; w8 < 8; ++w8)
                     if (wsteps[w8] > 0)

@@ -226,17 +226,36 @@ __global__ __launch_bounds__(512, 2) void stage23pc_kernel(const Stage23Args a) 
             }
         };
 #ifdef RN_STAMPS
-        unsigned long long st_bar = 0;
+        unsigned long long st_bar = 0, st_seg[6] = {0, 0, 0, 0, 0, 0};
 #endif
         auto step = [&](auto PC, int t) __attribute__((always_inline)) {
             constexpr int P = decltype(PC)::value;
             if (t < nrows + 9) a_next += W * 64;
             issue_A_row(a_next, (P + 1) % F_NA);            // A row t+1
             f32x16 acc;
+#ifdef RN_STAMPS
+            const unsigned long long tp0 = stamp23();
+#endif
             chain(IC<(P + 2) % 4>{}, IC<F_ROWA>{}, baseA[0], w2, acc);     // conv row t-2: A rows t-2 .. t
+#ifdef RN_STAMPS
+            const unsigned long long tp1 = stamp23();
+#endif
             epi(IC<0>{}, PC, acc);
+#ifdef RN_STAMPS
+            const unsigned long long tp2 = stamp23();
+#endif
             chain(IC<(P + 2) % 4>{}, IC<F_ROWA>{}, baseA[1], w2, acc);
+#ifdef RN_STAMPS
+            const unsigned long long tp3 = stamp23();
+#endif
             epi(IC<1>{}, PC, acc);
+#ifdef RN_STAMPS
+            const unsigned long long tp4 = stamp23();
+            st_seg[0] += tp1 - tp0;
+            st_seg[1] += tp2 - tp1;
+            st_seg[2] += tp3 - tp2;
+            st_seg[3] += tp4 - tp3;
+#endif
 #ifdef RN_STAMPS
             const unsigned long long tb0 = stamp23();
 #endif
@@ -269,6 +288,8 @@ __global__ __launch_bounds__(512, 2) void stage23pc_kernel(const Stage23Args a) 
             a.stamp_buf[w * 4 + 1] = 0;
             a.stamp_buf[w * 4 + 2] = st_bar;
             a.stamp_buf[w * 4 + 3] = static_cast<unsigned long long>(nsteps);
+            unsigned long long* sg = a.stamp_buf + static_cast<int64_t>(gridDim.x) * gridDim.y * 32 + w * 8;
+            for (int k = 0; k < 6; ++k) sg[k] = st_seg[k];
         }
 #endif
         return;
@@ -380,7 +401,7 @@ __global__ __launch_bounds__(512, 2) void stage23pc_kernel(const Stage23Args a) 
     for (int g = 0; g < 16; ++g) acc1[g] = 0.f;
     lds_barrier();
 
-    const float* const tabl = tab + 64 + 4 * hh;
+    const unsigned tabl_lds = lds_addr(tab + 64 + 4 * hh);
     auto epi = [&](auto TC, auto PRC, const f32x16& acce, const RowCtx& cx) __attribute__((always_inline)) {
         constexpr int T = decltype(TC)::value;
         // residual: transposed reads of the staged skip pair, R_lo / R_hi = Skip^T * Wx on the matrix cores
@@ -404,11 +425,37 @@ __global__ __launch_bounds__(512, 2) void stage23pc_kernel(const Stage23Args a) 
         r_lo = mfma32<DT>(al1, bw[T][1], r_lo);
         r_hi = mfma32<DT>(ah1, bw[T][1], r_hi);
         uint2 pk[4];
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const f32x4 sc1 = *reinterpret_cast<const f32x4*>(tabl + 8 * g);
-            const f32x4 sh1 = *reinterpret_cast<const f32x4*>(tabl + 32 + 8 * g);
-            const f32x4 sc2 = *reinterpret_cast<const f32x4*>(tabl + 64 + 8 * g);
+        // folded-BN table entries of channel group g: read by inline asm one group ahead of their use and retired by a
+        // counted wait (compiler-visible LDS loads are waited for with lgkmcnt(0) right before use: four exposed LDS
+        // round trips per epilogue on the wave the whole step waits for)
+        f32x4 tsc1[4], tsh1[4], tsc2[4];
+        auto tab_issue = [&](auto GC) __attribute__((always_inline)) {
+            constexpr int g = decltype(GC)::value;
+            auto& t1 = tsc1;
+            auto& t2 = tsh1;
+            auto& t3 = tsc2;
+            const unsigned ta = tabl_lds;        // (named outside the asm: implicit capture)
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(t1[g]) : "v"(ta), "n"(32 * g));
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(t2[g]) : "v"(ta), "n"(128 + 32 * g));
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(t3[g]) : "v"(ta), "n"(256 + 32 * g));
+        };
+        tab_issue(IC<0>{});
+        [&]<int... G>(std::integer_sequence<int, G...>) {
+            (([&] {
+                 constexpr int g = G;
+                 auto& t1 = tsc1;
+                 auto& t2 = tsh1;
+                 auto& t3 = tsc2;
+                 if constexpr (g + 1 < 4) {
+                     tab_issue(IC<(g + 1 < 4 ? g + 1 : 0)>{});
+                     asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(t1[g]), "+v"(t2[g]), "+v"(t3[g]));
+                 } else {
+                     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(t1[g]), "+v"(t2[g]), "+v"(t3[g]));
+                 }
+             }(),
+             [&] {
+            constexpr int g = G;
+            const f32x4 sc1 = tsc1[g], sh1 = tsh1[g], sc2 = tsc2[g];
             float y[4];
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj) {
@@ -419,7 +466,9 @@ __global__ __launch_bounds__(512, 2) void stage23pc_kernel(const Stage23Args a) 
             }
             pk[g].x = pack2<DT>(y[0], y[1]);
             pk[g].y = pack2<DT>(y[2], y[3]);
-        }
+             }()),
+             ...);
+        }(std::make_integer_sequence<int, 4>{});
         i32x4 vv[2];
 #pragma unroll
         for (int kk = 0; kk < 4; kk += 2) {
@@ -435,7 +484,7 @@ __global__ __launch_bounds__(512, 2) void stage23pc_kernel(const Stage23Args a) 
         __builtin_amdgcn_raw_buffer_store_b128(vv[1], cx.rs, vo + 32, 0, 0);
     };
 #ifdef RN_STAMPS
-    unsigned long long st_bar = 0;
+    unsigned long long st_bar = 0, st_seg[6] = {0, 0, 0, 0, 0, 0};
 #endif
     auto step = [&](auto PC, int t) __attribute__((always_inline)) {
         constexpr int P = decltype(PC)::value;
@@ -447,8 +496,17 @@ __global__ __launch_bounds__(512, 2) void stage23pc_kernel(const Stage23Args a) 
         cx_cur.rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(out_row), 0, out_row_bytes, 0x00020000);
         cx_cur.emit_mask = jo >= 0 ? 0 : OOB;
         if (jo >= 0 && jo < nrows - 1) out_row += out_row_bytes;
+#ifdef RN_STAMPS
+        const unsigned long long tc0 = stamp23();
+#endif
+#ifndef RN_X_NODEFER
         // deferred epilogue of the previous step's second tile (its conv row has the other parity)
         epi(IC<1>{}, IC<1 - PR>{}, acc1, cx_prev);
+#endif
+#ifdef RN_STAMPS
+        const unsigned long long tc1 = stamp23();
+        st_seg[0] += tc1 - tc0;
+#endif
         // skip rows for the next step's residual (see stage23_kernel)
         const VLerp vl_next = vlerp_of(yo0 + min(max(jo + 1, 0), nrows - 1));
         {
@@ -461,11 +519,33 @@ __global__ __launch_bounds__(512, 2) void stage23pc_kernel(const Stage23Args a) 
                     issue_skip_row(sk_fetched, sk_fetched_slot);
                 }
         }
+#ifdef RN_STAMPS
+        const unsigned long long tc2 = stamp23();
+        st_seg[1] += tc2 - tc1;
+#endif
         f32x16 acc0;
         chain(IC<P>{}, IC<F_ROWB>{}, baseB[0], w3, acc0);       // conv row t-8: B rows t-8 .. t-6
+#ifdef RN_STAMPS
+        const unsigned long long tc3 = stamp23();
+        st_seg[2] += tc3 - tc2;
+#endif
         wait_vmcnt<0>();                                       // this step's skip rows have landed
+#ifdef RN_STAMPS
+        const unsigned long long tc4 = stamp23();
+        st_seg[3] += tc4 - tc3;
+#endif
         epi(IC<0>{}, IC<PR>{}, acc0, cx_cur);
+#ifdef RN_STAMPS
+        const unsigned long long tc5 = stamp23();
+        st_seg[4] += tc5 - tc4;
+#endif
         chain(IC<P>{}, IC<F_ROWB>{}, baseB[1], w3, acc1);
+#ifdef RN_X_NODEFER
+        epi(IC<1>{}, IC<PR>{}, acc1, cx_cur);
+#endif
+#ifdef RN_STAMPS
+        st_seg[5] += stamp23() - tc5;
+#endif
         cx_prev = cx_cur;
         {
             int sl = slot_cur + (vl_next.ylo - vl_cur.ylo);
@@ -495,10 +575,12 @@ __global__ __launch_bounds__(512, 2) void stage23pc_kernel(const Stage23Args a) 
     if (rem > 0) step(IC<0>{}, t);
     if (rem > 1) step(IC<1>{}, t + 1);
     if (rem > 2) step(IC<2>{}, t + 2);
+#ifndef RN_X_NODEFER
     if (((nsteps - 1) & 1) == 0)
         epi(IC<1>{}, IC<0>{}, acc1, cx_prev);
     else
         epi(IC<1>{}, IC<1>{}, acc1, cx_prev);
+#endif
     wait_vmcnt<0>();
 #ifdef RN_STAMPS
     if (a.stamp_buf && lane == 0) {
@@ -507,6 +589,8 @@ __global__ __launch_bounds__(512, 2) void stage23pc_kernel(const Stage23Args a) 
         a.stamp_buf[w * 4 + 1] = 0;
         a.stamp_buf[w * 4 + 2] = st_bar;
         a.stamp_buf[w * 4 + 3] = static_cast<unsigned long long>(nsteps);
+        unsigned long long* sg = a.stamp_buf + static_cast<int64_t>(gridDim.x) * gridDim.y * 32 + w * 8;
+        for (int k = 0; k < 6; ++k) sg[k] = st_seg[k];
     }
 #endif
 }
