@@ -51,9 +51,16 @@ def test_hbm_traffic_summary_is_reproducible_from_the_pmc_passes():
                          text=True, check=True).stdout
     assert json.loads(out) == json.load(open(tj))
     t = json.load(open(tj))
-    # every big stage moves its algorithmic bytes once (stage 5's input is partly served on-die)
-    for s in t["stages"][:8]:
-        assert 0.55 <= s["traffic_over_algorithmic"] <= 1.05, s
+    # every big stage moves its algorithmic bytes once (stage 5's input is partly served on-die); a cross-stage fused
+    # launch moves LESS than the stage-boundary model credits it with (its intermediate tensor stays in LDS) but not less
+    # than its input + output
+    for s in t["stages"]:
+        if s["stage"] >= 8:
+            continue
+        if len(s.get("stages", [s["stage"]])) > 1:
+            assert 0.39 <= s["traffic_over_algorithmic"] <= 0.62, s
+        else:
+            assert 0.55 <= s["traffic_over_algorithmic"] <= 1.05, s
     b = json.load(open(os.path.join(PROF, tag + "_bench.json")))
     dom = [s for s in t["stages"] if s["algorithmic_bytes"] == b["roofline"]["algorithmic_bytes_per_launch"]]
     assert dom and abs(dom[0]["traffic_bytes"] - b["roofline"]["traffic"]) <= 1e-3 * dom[0]["traffic_bytes"]

@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
-"""Per-stage HBM traffic from the two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE) vs the stage-boundary byte model.
-usage: tools/hbm_traffic.py profiles/<tag>_pmc_fetch_size.csv profiles/<tag>_pmc_write_size.csv > profiles/<tag>_hbm_traffic.json
-Counters are KiB per dispatch; gfx950: FETCH_SIZE under-reports 16 B/lane streaming reads by exactly 2x (MI355X_MICROARCH.md)."""
+"""Per-launch HBM traffic from the two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE) vs the stage-boundary byte model.
+usage: tools/hbm_traffic.py <fetch.csv> <write.csv> [batch side dtype] > profiles/<tag>_hbm_traffic.json
+Counters are KiB per dispatch; gfx950: FETCH_SIZE under-reports 16 B/lane streaming reads by exactly 2x (MI355X_MICROARCH.md).
+A cross-stage fused launch (stage23pc_kernel) is listed with the stages it computes: its algorithmic bytes are the
+stage-boundary model's bytes of both stages (what two launches would move), its traffic is what it really moves."""
 import csv, json, sys, collections, os
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 from roomnet_amd.graph import build_graph
@@ -12,21 +14,30 @@ def per_kernel(path, counter):
         agg.setdefault(r['Kernel_Name'], []).append(float(r['Counter_Value']))
     return agg
 fetch = per_kernel(sys.argv[1], 'FETCH_SIZE'); write = per_kernel(sys.argv[2], 'WRITE_SIZE')
-B, side, elem = 256, 224, 2
+B = int(sys.argv[3]) if len(sys.argv) > 3 else 256
+side = int(sys.argv[4]) if len(sys.argv) > 4 else 224
+dtype = sys.argv[5] if len(sys.argv) > 5 else "bf16"
+elem = 2
 g = build_graph(6, side)
-stage_kernels = [k for k in fetch if 'stage' in k]
-out = {"note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) of `python3 bench.py --steps 3 --warmup 1` (batch 256, "
-               "224x224, bf16). KiB per dispatch, mean over dispatches. gfx950 correction: FETCH_SIZE doubled (wide streaming reads are "
-               "tallied at half size), WRITE_SIZE exact. traffic_bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024; algorithmic_bytes = "
-               "stage-boundary model (SURVEY.md 8d) x batch.",
-       "batch": B, "im_side": side, "dtype": "bf16", "stages": []}
-for i, k in enumerate(stage_kernels[:len(g.stages)]):
+def model_bytes(i):
     s = g.stages[i]
     alg = s.in_side * s.in_side * s.cin * (1 if i == 0 else elem) + s.out_side * s.out_side * s.cout * elem
     if s.residual: alg += s.skip_side * s.skip_side * s.cout * elem
-    alg *= B
+    return alg * B
+stage_kernels = [k for k in fetch if 'stage' in k]
+out = {"note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) of `python3 bench.py --steps 3 --warmup 1` (batch %d, "
+               "%dx%d, %s). KiB per dispatch, mean over dispatches. gfx950 correction: FETCH_SIZE doubled (wide streaming reads are "
+               "tallied at half size), WRITE_SIZE exact. traffic_bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024; algorithmic_bytes = "
+               "stage-boundary model (SURVEY.md 8d) x batch, summed over the stages a launch computes." % (B, side, side, dtype),
+       "batch": B, "im_side": side, "dtype": dtype, "stages": []}
+i = 0
+for k in stage_kernels:
+    if i >= len(g.stages): break
+    stages = [i, i + 1] if 'stage23' in k else [i]
+    alg = sum(model_bytes(j) for j in stages)
     f = sum(fetch[k]) / len(fetch[k]); w = sum(write[k]) / len(write[k])
     t = int((2 * f + w) * 1024)
-    out["stages"].append({"stage": i, "kernel": k[k.find('stage'):][:60], "fetch_size_kib": f, "write_size_kib": w, "traffic_bytes": t,
-                          "algorithmic_bytes": alg, "traffic_over_algorithmic": round(t / alg, 3)})
+    out["stages"].append({"stage": stages[-1], "stages": stages, "kernel": k[k.find('stage'):][:60], "fetch_size_kib": f, "write_size_kib": w,
+                          "traffic_bytes": t, "algorithmic_bytes": alg, "traffic_over_algorithmic": round(t / alg, 3)})
+    i = stages[-1] + 1
 print(json.dumps(out, indent=1))
