@@ -726,8 +726,10 @@ extern "C" int rn_tap(rn_handle* h, int node_id, float* out, size_t cap_elems, s
         return RN_E_STATE;
     }
     if (fused_mode(h)) {
-        const int pf = rn_fused_pair_first(h);
-        if (pf >= 0 && node_id == h->stages[pf].node_bn) {
+        bool fused_away = false;
+        for (size_t i = 0; i < h->stages.size(); ++i)
+            fused_away |= node_id == h->stages[i].node_bn && rn_fused_launch_rep(h, static_cast<int>(i)) != static_cast<int>(i);
+        if (fused_away) {
             rn_set_error("rn_tap: node %s is fused into its successor's kernel on this handle and never written "
                          "(create with RN_FLAG_STAGE_LAUNCHES)", nb.info.name);
             return RN_E_STATE;
@@ -820,8 +822,7 @@ extern "C" int rn_stage_launch(const rn_handle* h, int stage) {
         rn_set_error("rn_stage_launch: bad argument");
         return RN_E_RANGE;
     }
-    const int pf = fused_mode(h) ? rn_fused_pair_first(h) : -1;
-    return (pf >= 0 && stage == pf) ? pf + 1 : stage;
+    return fused_mode(h) ? rn_fused_launch_rep(h, stage) : stage;
 }
 
 extern "C" int rn_device_malloc(rn_handle* h, size_t bytes, void** d_ptr) {

@@ -9,8 +9,8 @@ int rn_fused_prepare(rn_handle* h, const rn_weights* w);
 int rn_fused_forward(rn_handle* h, const uint8_t* d_bgr, const float* d_rgb, int n, float* d_probs,
                      int64_t* d_ids);
 void rn_fused_release(rn_handle* h);
-// index of the first stage of the cross-stage fused pair, or -1
-int rn_fused_pair_first(const rn_handle* h);
+// the stage under which the launch that computes `stage` reports its time (== stage for a launch of its own)
+int rn_fused_launch_rep(const rn_handle* h, int stage);
 // head launcher shared with the unfused path (defined in rn_api.hip)
 int rn_run_head(rn_handle* h, int n, float* d_probs, int64_t* d_ids);
 void rn_record_event(rn_handle* h, int idx);

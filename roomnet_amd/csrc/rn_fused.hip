@@ -541,6 +541,10 @@ constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 
 struct FusedState {
     std::vector<FusedStage> st;
+    // cross-stage fusion: launch_rep[i] = the stage under which the launch that computes stage i reports its time
+    // (== i for a launch of its own)
+    std::vector<int> launch_rep;
+    bool fuse_s0 = false;        // stage 0 is computed inside stage 1's kernel (rn_stage_rw.hip, S0F)
     // cross-stage fused pair (rn_stage23.hip): stages pair_first, pair_first + 1 run as one launch
     int pair_first = -1;
     float* pair_ptab = nullptr;  // [5][32]: the first stage's scale, shift | the second stage's scale', shift', scale2
@@ -734,12 +738,27 @@ int rn_fused_prepare(rn_handle* h, const rn_weights* w) {
             fs->pair_first = static_cast<int>(i);
             break;
         }
+    // stage 0 inside stage 1's kernel: the 8-channel register-weights variant computes stage 0 for its own ring columns
+    // (network.py:226 feeding :227's first step); needs the arithmetic form of the pre-processing table
+    if (!(h->flags & (RN_FLAG_STAGE_LAUNCHES | RN_FLAG_GENERIC_KERNELS)) && h->stages.size() > 1) {
+        const StagePlan& s1 = h->stages[1];
+        bool feeds_others = false;
+        for (size_t k = 2; k < h->stages.size(); ++k) feeds_others |= h->stages[k].skip_stage == 0;
+        fs->fuse_s0 = fs->st[1].use_rw && fs->st[1].rw.variant == 0 && s1.skip_stage < 0 && fs->s0_lut_arith && !feeds_others;
+#ifdef RN_X_NO_S0F      // (A/B timing builds)
+        fs->fuse_s0 = false;
+#endif
+    }
+    fs->launch_rep.resize(h->stages.size());
+    for (size_t i = 0; i < h->stages.size(); ++i) fs->launch_rep[i] = static_cast<int>(i);
+    if (fs->fuse_s0) fs->launch_rep[0] = 1;
+    if (fs->pair_first >= 0) fs->launch_rep[fs->pair_first] = fs->pair_first + 1;
     return RN_OK;
 }
 
-int rn_fused_pair_first(const rn_handle* h) {
+int rn_fused_launch_rep(const rn_handle* h, int stage) {
     const FusedState* fs = static_cast<const FusedState*>(h->fused);
-    return fs ? fs->pair_first : -1;
+    return fs && stage >= 0 && stage < static_cast<int>(fs->launch_rep.size()) ? fs->launch_rep[stage] : stage;
 }
 
 int rn_fused_forward(rn_handle* h, const uint8_t* d_bgr, const float* d_rgb, int n, float* d_probs,
@@ -754,8 +773,10 @@ int rn_fused_forward(rn_handle* h, const uint8_t* d_bgr, const float* d_rgb, int
         return RN_E_STATE;
     }
     const int dti = h->dtype == RN_DTYPE_BF16 ? 0 : 1;
-    // stage 0
-    {
+    // stage 0 (a launch of its own unless stage 1's kernel computes it)
+    if (fs->fuse_s0) {
+        rn_record_event(h, 2);
+    } else {
         const StagePlan& s = h->stages[0];
         Stage0Args a0{};
         a0.bgr = d_bgr;
@@ -898,6 +919,12 @@ int rn_fused_forward(rn_handle* h, const uint8_t* d_bgr, const float* d_rgb, int
 #ifdef RN_DIAG
             if (const char* dbg = getenv("RN_DEBUG_FLAGS")) a.dbg_flags = atoi(dbg);   // diagnostic builds only
 #endif
+            if (i == 1 && fs->fuse_s0) {
+                a.s0_bgr = d_bgr;
+                a.s0_wfrag = fs->s0_wfrag;
+                a.s0_ptab = fs->s0_ptab;
+                a.s0_S = h->stages[0].in_side;
+            }
             a.ptab = f.ptab;
             a.skipcols = f.rw.skipcols;
             a.n_colblocks = f.rw.n_colblocks;

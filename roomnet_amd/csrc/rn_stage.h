@@ -191,6 +191,11 @@ struct StageArgs {
     int dbg_flags;                // timing experiments only: bit 0 = skip output stores, bit 1 = skip MFMAs
     unsigned long long* stamp_buf; // diagnostic build (-DRN_STAMPS) only: per-wave phase cycle sums
     float rscale;                 // residual resize scale = float(Ss) / float(Ho), fp32 as TF computes it
+    // stage-0 fusion (8-channel rw variant only; s0_bgr == nullptr: the stage reads `in` as usual)
+    const uint8_t* s0_bgr;        // [N, S, S, 3] uint8 image batch
+    const i32x4* s0_wfrag;        // [3 (ky)][64 lanes] stage-0 A fragments (fp16, K = (kx < 4, c < 4))
+    const float* s0_ptab;         // [2][8] stage-0 folded BN: scale (inv / 9), shift
+    int s0_S;                     // image side
 };
 
 // launch arguments of the cross-stage fused kernel (rn_stage23.hip): the last two steps of a depth-3 conv_block

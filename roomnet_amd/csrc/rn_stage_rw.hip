@@ -50,13 +50,17 @@ constexpr int rw_tile_stride(int pk, int ps) { return pk ? rw_tile_nout(pk, ps) 
 #endif
 constexpr int RW_SKIPBUF = 3;   // staged skip-row pairs (residual): 1 being read + 2 in flight
 
-template <int DT, int CIN, int COUT, int PK, int PS, bool RES, int NPT, int KS = 1>
+template <int DT, int CIN, int COUT, int PK, int PS, bool RES, int NPT, int KS = 1, bool S0F_ = false>
 struct RwCfg {
+    // S0F: stage 0 (uint8 image -> conv 3->8 -> ReLU6 -> pool 3/1 -> BN) is computed by the SAME wave, row by row,
+    // straight into its private ring: the 8-channel tensor between stages 0 and 1 never reaches HBM (see s0_feed)
+    static constexpr bool S0F = S0F_;
+    static_assert(!S0F || (CIN == 8 && !RES && KS == 1 && COUT == 32), "stage-0 fusion feeds the 8-channel private-ring variant");
     // Ring depth: at step s the DMA for input row s + AHEAD is issued; NSLOT = AHEAD + 1 slots
     // (3 live rows + AHEAD - 2 in flight).  Rows of the 8-channel stage are only ~3.8 KB, so it
     // keeps 9 of them in flight to cover the HBM latency (Little's law), the others 3.
     // (7 instead of 5 for the private-ring 32-channel stage measured the same: it is not latency-bound)
-    static constexpr int AHEAD = CIN == 8 ? 11 : 5;
+    static constexpr int AHEAD = S0F ? 3 : (CIN == 8 ? 11 : 5);       // S0F: rows are produced in place, nothing in flight
     static constexpr int NSLOT = AHEAD + 1;
     static constexpr int CP = CIN / 8;
     static constexpr int KC = (9 * CIN + 15) / 16;
@@ -152,9 +156,9 @@ __device__ __forceinline__ unsigned long long stamp() {
 }
 #endif
 
-template <int DT, int CIN, int COUT, int PK, int PS, bool RES, int NPT, int KS>
+template <int DT, int CIN, int COUT, int PK, int PS, bool RES, int NPT, int KS, bool S0F>
 __global__ __launch_bounds__(64 * NPT * ((COUT + 31) / 32) * KS, 1) void stage_rw_kernel(const StageArgs a) {
-    using C = RwCfg<DT, CIN, COUT, PK, PS, RES, NPT, KS>;
+    using C = RwCfg<DT, CIN, COUT, PK, PS, RES, NPT, KS, S0F>;
     constexpr int CP = C::CP, KC = C::KC, CT = C::CT, CPO = C::CPO, TSTRIDE = C::TSTRIDE, NOUT_T = C::NOUT_T;
     constexpr int RINGCOLS = C::RINGCOLS, ROWB = C::ROWB, NTHREADS = C::NTHREADS, LPT = C::LPT, SLPT = C::SLPT;
     constexpr int PIXB = CIN * 2, NG = C::NG;
@@ -301,9 +305,115 @@ __global__ __launch_bounds__(64 * NPT * ((COUT + 31) / 32) * KS, 1) void stage_r
         }
     };
 
-    // ---- prologue: rows 0 .. RW_AHEAD-1 in flight (clamped: a no-pool band can be shorter)
+    // ---- stage-0 fusion (S0F): this wave computes stage 0 for its own 34 ring columns, one row per call, on the matrix
+    // cores with the im2col in registers exactly like stage0_kernel (rn_fused.hip; same instruction sequence, so the
+    // ring holds bit for bit what the two-launch path reads back from HBM).  34 output columns = 36 conv columns = two
+    // 32-column MFMA tiles: tile 0 at the ring origin gives output columns 0..28 (conv column 31 of a tile is not
+    // computable: its right neighbour pixel sits in the other half-wave), tile 1 at +29 gives 29..33.
+    // s0_feed(i, slot): takes image row yc0 + i; from i = 2 a conv row (i - 2) is complete, from i = 4 output row
+    // i - 4 = ReLU6 -> 3x3 sums -> BN, written as 8-byte lane pieces into ring slot `slot`.
+    constexpr int S0_AHEAD = 4;            // image rows prefetched per tile: a circular queue indexed by row mod 4, which
+                                           // is a compile-time phase inside the row loop (unrolled by the ring depth 4)
+    i32x4 s0_w[3];
+    f32x4 s0_scale = {0.f, 0.f, 0.f, 0.f}, s0_shift = {0.f, 0.f, 0.f, 0.f};
+    const uint8_t* s0_src[2] = {nullptr, nullptr};
+    int s0_sh[2] = {0, 0};
+    unsigned s0_pw[2][S0_AHEAD];
+    i32x4 s0_bfr[2][3];
+    float s0_h1[2][4], s0_h2[2][4];
+    int s0_wr[2] = {0, 0};                 // byte offset of this lane's 8-byte piece inside a ring row, or -1
+    const int s0_rows = nin + 4;           // image rows this band reads
+    if constexpr (C::S0F) {
 #pragma unroll
-    for (int j = 0; j < RW_AHEAD; ++j) issue_row(min(j, nin - 1), j);
+        for (int ky = 0; ky < 3; ++ky) s0_w[ky] = a.s0_wfrag[ky * 64 + lane];
+        s0_scale = *reinterpret_cast<const f32x4*>(a.s0_ptab + 4 * hh);
+        s0_shift = *reinterpret_cast<const f32x4*>(a.s0_ptab + 8 + 4 * hh);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int xt0 = x_ring0 + 29 * u;                          // first conv / image column of the tile
+            const int px = min(xt0 + r + 2 * hh, a.s0_S - 1);           // this lane's image column (clamped at the edge)
+            s0_sh[u] = px == a.s0_S - 1 ? 8 : 0;                        // last column: load one byte early and shift
+            s0_src[u] = a.s0_bgr + (static_cast<int64_t>(n) * a.s0_S * a.s0_S + static_cast<int64_t>(yc0) * a.s0_S + px) * 3 - (s0_sh[u] >> 3);
+            const int oc = 29 * u + r;                                  // ring column of this lane's output pixel
+            s0_wr[u] = (r < (u == 0 ? 29 : 5) && oc < RINGCOLS) ? oc * PIXB + 8 * hh : -1;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) s0_h1[u][j] = s0_h2[u][j] = 0.f;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) s0_bfr[u][i] = i32x4{0, 0, 0, 0};
+        }
+    }
+    auto s0_load = [&](int u, int j) __attribute__((always_inline)) -> unsigned {
+        unsigned w;
+        __builtin_memcpy(&w, s0_src[u] + static_cast<int64_t>(min(j, s0_rows - 1)) * (a.s0_S * 3), 4);   // unaligned dword
+        return w;
+    };
+    auto s0_feed = [&](auto STEADYC, auto QC, int i, int slot) __attribute__((always_inline)) {
+        constexpr bool STEADY = decltype(STEADYC)::value != 0;          // i >= 4 is known: no start-up branches
+        constexpr int Q = decltype(QC)::value;                          // i mod S0_AHEAD
+        if constexpr (C::S0F) {
+            const unsigned nb_mask = hh ? 0u : 0xffffffffu;
+            const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                // ((x / 255.) * 2) - 1 of network.py:129 as one fp32 fma (the host checked that it rounds to the same
+                // fp16 as the float64 expression for all 256 inputs, rn_fused_prepare)
+                const unsigned w = s0_pw[u][Q] >> s0_sh[u];              // bytes: B, G, R
+                const float fb = fmaf(static_cast<float>(w & 0xff), 2.0f / 255.0f, -1.0f);
+                const float fg = fmaf(static_cast<float>((w >> 8) & 0xff), 2.0f / 255.0f, -1.0f);
+                const float fr = fmaf(static_cast<float>((w >> 16) & 0xff), 2.0f / 255.0f, -1.0f);
+                const int d0 = static_cast<int>(pack2<RN_DTYPE_F16>(fr, fg));
+                const int d1 = static_cast<int>(pack2<RN_DTYPE_F16>(fb, 0.f));
+                s0_pw[u][Q] = s0_load(u, i + S0_AHEAD);
+                i32x4 f;
+                f[0] = d0;
+                f[1] = d1;
+                f[2] = static_cast<int>(static_cast<unsigned>(__builtin_amdgcn_update_dpp(0, d0, 0x130, 0xf, 0xf, true)) & nb_mask);
+                f[3] = static_cast<int>(static_cast<unsigned>(__builtin_amdgcn_update_dpp(0, d1, 0x130, 0xf, 0xf, true)) & nb_mask);
+                s0_bfr[u][2] = f;
+                if (STEADY || i >= 2) {
+                    f32x16 acc = mfma32<RN_DTYPE_F16>(s0_w[0], s0_bfr[u][0], zero);
+                    acc = mfma32<RN_DTYPE_F16>(s0_w[1], s0_bfr[u][1], acc);
+                    acc = mfma32<RN_DTYPE_F16>(s0_w[2], s0_bfr[u][2], acc);
+                    float y[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float v = relu6f(acc[j]);
+                        const float v1 = lane_next(v);
+                        const float hs = (v + v1) + lane_next(v1);
+                        y[j] = fmaf((s0_h2[u][j] + s0_h1[u][j]) + hs, s0_scale[j], s0_shift[j]);
+                        s0_h2[u][j] = s0_h1[u][j];
+                        s0_h1[u][j] = hs;
+                    }
+                    if ((STEADY || i >= 4) && s0_wr[u] >= 0)
+                        *reinterpret_cast<uint2*>(ring + slot * ROWB + s0_wr[u]) = pack4<DT>(y[0], y[1], y[2], y[3]);
+                }
+                if (STEADY || i >= 1) {
+                    s0_bfr[u][0] = s0_bfr[u][1];
+                    s0_bfr[u][1] = s0_bfr[u][2];
+                } else {
+                    s0_bfr[u][1] = s0_bfr[u][2];
+                }
+            }
+        }
+    };
+    // ---- prologue: rows 0 .. RW_AHEAD-1 in flight (clamped: a no-pool band can be shorter)
+    if constexpr (C::S0F) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int k = 0; k < S0_AHEAD; ++k) s0_pw[u][k] = s0_load(u, k);
+        static_assert(!C::S0F || (RW_NSLOT == 4 && S0_AHEAD == 4 && RW_AHEAD == 3), "queue phase = ring phase");
+        s0_feed(IC<0>{}, IC<0>{}, 0, 0);
+        s0_feed(IC<0>{}, IC<1>{}, 1, 0);
+        s0_feed(IC<0>{}, IC<2>{}, 2, 0);
+        s0_feed(IC<0>{}, IC<3>{}, 3, 0);
+        s0_feed(IC<1>{}, IC<0>{}, 4, 0);                   // emits ring rows 0 .. RW_AHEAD-1
+        s0_feed(IC<1>{}, IC<1>{}, 5, 1);
+        s0_feed(IC<1>{}, IC<2>{}, 6, 2);
+    } else {
+#pragma unroll
+        for (int j = 0; j < RW_AHEAD; ++j) issue_row(min(j, nin - 1), j);
+    }
 
     // ---- lane constants of this wave's pixel tile
     const int pm = C::GAP ? r - 2 * (r >> 4) : r;            // conv column of this lane inside the tile
@@ -844,7 +954,7 @@ __global__ __launch_bounds__(64 * NPT * ((COUT + 31) / 32) * KS, 1) void stage_r
         const char* const in_row_next = in_img + static_cast<int64_t>(yc0 + min(s + RW_AHEAD, nin - 1)) * in_row_bytes;
         auto slot = [&](auto II) __attribute__((always_inline)) {
             constexpr int I = decltype(II)::value;
-            if constexpr (MMA && RN_SPREAD_DMA) {
+            if constexpr (MMA && RN_SPREAD_DMA && !C::S0F) {
                 [&]<int... PI>(std::integer_sequence<int, PI...>) {
                     (([&] {
                          constexpr int at = PI * DSTEP < KCW ? PI * DSTEP : KCW - 1;
@@ -871,7 +981,9 @@ __global__ __launch_bounds__(64 * NPT * ((COUT + 31) / 32) * KS, 1) void stage_r
         if constexpr (MMA) {
             // (past the end of the band the last row is fetched again into a free slot: the number of
             //  DMA pieces per step stays constant, so the counted waits and the code path do too)
-            if constexpr (!RN_SPREAD_DMA) issue_row(min(s + RW_AHEAD, nin - 1), (P + RW_AHEAD) % RW_NSLOT);
+            if constexpr (!RN_SPREAD_DMA && !C::S0F) issue_row(min(s + RW_AHEAD, nin - 1), (P + RW_AHEAD) % RW_NSLOT);
+            // S0F: image row s + RW_AHEAD + 4 completes stage-0 output row s + RW_AHEAD -> the slot the DMA would fill
+            if constexpr (C::S0F) s0_feed(IC<1>{}, IC<(P + RW_AHEAD + 4) % 4>{}, s + RW_AHEAD + 4, (P + RW_AHEAD) % RW_NSLOT);
             if constexpr (RES && (PS == 1 || (P & 1) == 0)) {
                 // pair for the epilogue of conv row s+1 (runs in step s+2): e = (s + 1 - 3) / PS
                 // (stride 2: only odd conv rows emit, so pairs are issued on even steps)
@@ -911,7 +1023,7 @@ __global__ __launch_bounds__(64 * NPT * ((COUT + 31) / 32) * KS, 1) void stage_r
 #ifdef RN_STAMPS
         const unsigned long long ts1 = stamp();
 #endif
-        if constexpr (MMA) {
+        if constexpr (MMA && !C::S0F) {
             // retire the DMA of input row s+3 (and of the skip pair the next epilogue reads)
             wait_vmcnt<C::vmcnt_steady(P)>();
         }
@@ -970,10 +1082,10 @@ __global__ __launch_bounds__(64 * NPT * ((COUT + 31) / 32) * KS, 1) void stage_r
 #endif
 }
 
-template <int DT, int CIN, int COUT, int PK, int PS, bool RES, int NPT, int KS = 1>
+template <int DT, int CIN, int COUT, int PK, int PS, bool RES, int NPT, int KS = 1, bool S0F = false>
 int launch_rw(hipStream_t s, const StageArgs& a, dim3 grid) {
-    using C = RwCfg<DT, CIN, COUT, PK, PS, RES, NPT, KS>;
-    auto kern = stage_rw_kernel<DT, CIN, COUT, PK, PS, RES, NPT, KS>;
+    using C = RwCfg<DT, CIN, COUT, PK, PS, RES, NPT, KS, S0F>;
+    auto kern = stage_rw_kernel<DT, CIN, COUT, PK, PS, RES, NPT, KS, S0F>;
     // the attribute is per device: remember which devices of this process have it (one handle per GPU per process
     // is the normal deployment, several handles on several GPUs / threads in one process must work too)
     static std::atomic<unsigned long long> attr_devices{0};
@@ -999,10 +1111,10 @@ int launch_rw(hipStream_t s, const StageArgs& a, dim3 grid) {
     return RN_OK;
 }
 
-template <int CIN, int COUT, int PK, int PS, bool RES, int NPT, int KS = 1>
+template <int CIN, int COUT, int PK, int PS, bool RES, int NPT, int KS = 1, bool S0F = false>
 int launch_rw_dt(int dtype, hipStream_t s, const StageArgs& a, dim3 grid) {
-    if (dtype == RN_DTYPE_BF16) return launch_rw<RN_DTYPE_BF16, CIN, COUT, PK, PS, RES, NPT, KS>(s, a, grid);
-    return launch_rw<RN_DTYPE_F16, CIN, COUT, PK, PS, RES, NPT, KS>(s, a, grid);
+    if (dtype == RN_DTYPE_BF16) return launch_rw<RN_DTYPE_BF16, CIN, COUT, PK, PS, RES, NPT, KS, S0F>(s, a, grid);
+    return launch_rw<RN_DTYPE_F16, CIN, COUT, PK, PS, RES, NPT, KS, S0F>(s, a, grid);
 }
 
 }  // namespace
@@ -1056,8 +1168,12 @@ bool rn_rw_supported(int cin, int cout, int pool_k, int pool_s, bool res, int ou
 
 int rn_rw_launch(const RwPlan& p, int dtype, hipStream_t s, const StageArgs& a, dim3 grid) {
     switch (p.variant * 16 + p.npt) {
-        case 0 * 16 + 4: return launch_rw_dt<8, 32, 4, 1, false, 4>(dtype, s, a, grid);
-        case 0 * 16 + 8: return launch_rw_dt<8, 32, 4, 1, false, 8>(dtype, s, a, grid);
+        case 0 * 16 + 4:
+            if (a.s0_bgr) return launch_rw_dt<8, 32, 4, 1, false, 4, 1, true>(dtype, s, a, grid);
+            return launch_rw_dt<8, 32, 4, 1, false, 4>(dtype, s, a, grid);
+        case 0 * 16 + 8:
+            if (a.s0_bgr) return launch_rw_dt<8, 32, 4, 1, false, 8, 1, true>(dtype, s, a, grid);
+            return launch_rw_dt<8, 32, 4, 1, false, 8>(dtype, s, a, grid);
         case 1 * 16 + 4: return launch_rw_dt<32, 32, 4, 1, false, 4>(dtype, s, a, grid);
         case 1 * 16 + 8: return launch_rw_dt<32, 32, 4, 1, false, 8>(dtype, s, a, grid);
         case 2 * 16 + 4: return launch_rw_dt<32, 32, 4, 1, true, 4>(dtype, s, a, grid);

@@ -40,7 +40,9 @@ def _stage_out_names(g):
     return ["s%d.%s" % (s.index, "bn2" if s.residual else "bn") for s in g.stages]
 
 
-FUSED_AWAY = {"s2.bn"}      # written only to LDS by the cross-stage fused kernel (rn_stage23.hip)
+# never written to HBM on a default handle: s0.bn lives in the private LDS rings of stage 1's kernel (rn_stage_rw.hip,
+# S0F), s2.bn in the B ring of the fused stage pair (rn_stage23.hip)
+FUSED_AWAY = {"s0.bn", "s2.bn"}
 
 
 def _check_stage_outputs(engine, weights, parity_images, skip=()):
@@ -85,6 +87,9 @@ def test_cross_stage_fusion_is_bit_identical_to_stage_launches(weights, parity_i
         try:
             ids_f, probs_f = fused.forward_u8(ims)
             ids_p, probs_p = plain.forward_u8(ims)
+            a1, b1 = fused.tap("s1.bn", nb), plain.tap("s1.bn", nb)
+            bad = np.argwhere(a1 != b1)
+            assert bad.size == 0, ("s1", dtype, len(bad), bad[:8].tolist(), float(np.abs(a1 - b1).max()))
             a, b = fused.tap("s3.bn2", nb), plain.tap("s3.bn2", nb)
             bad = np.argwhere(a != b)
             assert bad.size == 0, (dtype, len(bad), bad[:8].tolist(), float(np.abs(a - b).max()))
@@ -175,8 +180,9 @@ def test_timing(engine, parity_images):
     engine.forward_u8(parity_images[:8])
     t = engine.timing()
     engine.set_profiling(False)
-    # (stage 2 runs inside stage 3's launch: its own slot reads ~0)
-    assert len(t["stage_ms"]) == 10 and all(x > 0 for i, x in enumerate(t["stage_ms"]) if i != 2)
+    # (stage 0 runs inside stage 1's launch and stage 2 inside stage 3's: their own slots read ~0)
+    assert len(t["stage_ms"]) == 10 and all(x > 0 for i, x in enumerate(t["stage_ms"]) if i not in (0, 2))
+    assert engine.launch_groups() == [[0, 1], [2, 3], [4], [5], [6], [7], [8], [9]]
 
 
 # ------------------------------------------------------------------ full size (BASELINE configs 3/4: batch 256)
@@ -328,6 +334,8 @@ def test_600_variant_vs_golden(weights, dtype, tol):
             e.forward_u8(ims[1:2])
             for s in e.graph.stages:
                 name = "s%d.%s" % (s.index, "bn2" if s.residual else "bn")
+                if name == "s0.bn":          # computed inside stage 1's kernel at every size (s2.bn is a launch at 600)
+                    continue
                 got, want = e.tap(name, 1), np.asarray(ref["taps"][name])
                 rel = float(np.abs(got - want).max() / max(np.abs(want).max(), 1e-6))
                 assert rel <= STAGE_TOL[dtype] * 1.5, (name, rel)
