@@ -411,7 +411,11 @@ def main():
             else:
                 achieved = dom_bytes / dom_s
                 s0 = graph.stages[dom_stages[0]]
-                if len(dom_stages) > 1:
+                if len(dom_stages) > 1 and dom_stages[0] == 0:
+                    kname = "stage_rw_kernel (S0F), stages 0+1 fused (3->8->32 ch)"
+                elif len(dom_stages) > 1 and dom_stages[-1] == len(graph.stages) - 1:
+                    kname = "tail_kernel, stages %s + dense head fused" % "+".join(map(str, dom_stages))
+                elif len(dom_stages) > 1:
                     kname = "stage23pc_kernel, stages %s fused (%d->%d ch x%d + residual)" % (
                         "+".join(map(str, dom_stages)), s0.cin, s0.cout, len(dom_stages))
                 elif dom_stages[0] == 0:

@@ -12,7 +12,7 @@ FLAGS=(--offload-arch=gfx950 -O3 -std=c++20 -fno-slp-vectorize -fPIC -shared -fv
 OBJ="$ROOT/build/obj"
 mkdir -p "$OBJ"
 CFLAGS=("${FLAGS[@]/-shared/}")
-for f in rn_api rn_kernels_f32 rn_fused rn_imageops rn_group; do
+for f in rn_api rn_kernels_f32 rn_fused rn_imageops rn_group rn_tail; do
     "$HIPCC" "${CFLAGS[@]}" -c "$HERE/$f.hip" -o "$OBJ/$f.o" &
 done
 # MFMA results stay in VGPRs: the epilogue reads every accumulator with the VALU, and AGPR
@@ -21,6 +21,6 @@ done
 "$HIPCC" "${CFLAGS[@]}" ${RN_RW_FLAGS:--mllvm -amdgpu-mfma-vgpr-form} -c "$HERE/rn_stage_rw.hip" -o "$OBJ/rn_stage_rw.o" &
 "$HIPCC" "${CFLAGS[@]}" ${RN_RW_FLAGS:--mllvm -amdgpu-mfma-vgpr-form} -c "$HERE/rn_stage23.hip" -o "$OBJ/rn_stage23.o" &
 wait
-"$HIPCC" --offload-arch=gfx950 -shared -fPIC "$OBJ"/rn_api.o "$OBJ"/rn_kernels_f32.o "$OBJ"/rn_fused.o "$OBJ"/rn_imageops.o "$OBJ"/rn_group.o "$OBJ"/rn_stage_rw.o "$OBJ"/rn_stage23.o -ldl \
+"$HIPCC" --offload-arch=gfx950 -shared -fPIC "$OBJ"/rn_api.o "$OBJ"/rn_kernels_f32.o "$OBJ"/rn_fused.o "$OBJ"/rn_imageops.o "$OBJ"/rn_group.o "$OBJ"/rn_tail.o "$OBJ"/rn_stage_rw.o "$OBJ"/rn_stage23.o -ldl \
     ${RN_EXTRA_FLAGS:-} -o "$OUT/libroomnet_hip.so"
 echo "built $OUT/libroomnet_hip.so"

@@ -330,8 +330,8 @@ void record(rn_handle* h, int idx) {
     if (h->profiling && idx < static_cast<int>(h->events.size())) (void)hipEventRecord(h->events[idx], h->stream);
 }
 
-int run_head(rn_handle* h, int n, float* d_probs, int64_t* d_ids) {
-    HeadArgs a{};
+void fill_head_args(rn_handle* h, HeadArgs& a) {
+    a = HeadArgs{};
     a.n_dense = static_cast<int>(h->dense.size());
     for (int d = 0; d < a.n_dense; ++d) {
         const DensePlan& p = h->dense[d];
@@ -345,6 +345,11 @@ int run_head(rn_handle* h, int n, float* d_probs, int64_t* d_ids) {
         a.tap_relu[d] = static_cast<float*>(h->nodes[p.node_relu].ptr);
         a.tap_bn[d] = p.node_bn >= 0 ? static_cast<float*>(h->nodes[p.node_bn].ptr) : nullptr;
     }
+}
+
+int run_head(rn_handle* h, int n, float* d_probs, int64_t* d_ids) {
+    HeadArgs a;
+    fill_head_args(h, a);
     const NodeBuf& flat = h->nodes[h->node_flat];
     return rn_launch_head(h->stream, flat.ptr, flat.dtype, n, a, d_probs, d_ids);
 }
@@ -408,6 +413,7 @@ int check_call(rn_handle* h, int n, const void* a, const void* b, const void* c)
 }  // namespace
 
 int rn_run_head(rn_handle* h, int n, float* d_probs, int64_t* d_ids) { return run_head(h, n, d_probs, d_ids); }
+void rn_fill_head_args(rn_handle* h, HeadArgs* a) { fill_head_args(h, *a); }
 void rn_record_event(rn_handle* h, int idx) { record(h, idx); }
 
 // ---------------------------------------------------------------------------- API
@@ -728,7 +734,7 @@ extern "C" int rn_tap(rn_handle* h, int node_id, float* out, size_t cap_elems, s
     if (fused_mode(h)) {
         bool fused_away = false;
         for (size_t i = 0; i < h->stages.size(); ++i)
-            fused_away |= node_id == h->stages[i].node_bn && rn_fused_launch_rep(h, static_cast<int>(i)) != static_cast<int>(i);
+            fused_away |= node_id == h->stages[i].node_bn && rn_fused_stage_elided(h, static_cast<int>(i));
         if (fused_away) {
             rn_set_error("rn_tap: node %s is fused into its successor's kernel on this handle and never written "
                          "(create with RN_FLAG_STAGE_LAUNCHES)", nb.info.name);

@@ -11,9 +11,17 @@ int rn_fused_forward(rn_handle* h, const uint8_t* d_bgr, const float* d_rgb, int
 void rn_fused_release(rn_handle* h);
 // the stage under which the launch that computes `stage` reports its time (== stage for a launch of its own)
 int rn_fused_launch_rep(const rn_handle* h, int stage);
+// the stage's output tensor is never written to HBM on this handle (it only exists in LDS inside a fused launch)
+bool rn_fused_stage_elided(const rn_handle* h, int stage);
 // head launcher shared with the unfused path (defined in rn_api.hip)
 int rn_run_head(rn_handle* h, int n, float* d_probs, int64_t* d_ids);
 void rn_record_event(rn_handle* h, int idx);
+void rn_fill_head_args(rn_handle* h, HeadArgs* a);
+
+// ---- the last two conv stages + flatten + dense head + softmax/argmax in one launch (rn_tail.hip)
+bool rn_tail_supported(const rn_handle* h);
+int rn_tail_launch(rn_handle* h, const rnk::i32x4* wfrag_a, const rnk::i32x4* wfrag_b, const HeadArgs& head, int n, float* d_probs,
+                   int64_t* d_ids);
 
 // ---- register-weights stage kernels (rn_stage_rw.hip)
 struct RwPlan {

@@ -545,6 +545,7 @@ struct FusedState {
     // (== i for a launch of its own)
     std::vector<int> launch_rep;
     bool fuse_s0 = false;        // stage 0 is computed inside stage 1's kernel (rn_stage_rw.hip, S0F)
+    bool use_tail = false;       // last two stages + head in one launch (rn_tail.hip)
     // cross-stage fused pair (rn_stage23.hip): stages pair_first, pair_first + 1 run as one launch
     int pair_first = -1;
     float* pair_ptab = nullptr;  // [5][32]: the first stage's scale, shift | the second stage's scale', shift', scale2
@@ -749,11 +750,23 @@ int rn_fused_prepare(rn_handle* h, const rn_weights* w) {
         fs->fuse_s0 = false;
 #endif
     }
+    fs->use_tail = !(h->flags & (RN_FLAG_STAGE_LAUNCHES | RN_FLAG_GENERIC_KERNELS)) && rn_tail_supported(h);
+#ifdef RN_X_NO_TAIL     // (A/B timing builds)
+    fs->use_tail = false;
+#endif
     fs->launch_rep.resize(h->stages.size());
     for (size_t i = 0; i < h->stages.size(); ++i) fs->launch_rep[i] = static_cast<int>(i);
     if (fs->fuse_s0) fs->launch_rep[0] = 1;
+    if (fs->use_tail) fs->launch_rep[h->stages.size() - 2] = static_cast<int>(h->stages.size()) - 1;
     if (fs->pair_first >= 0) fs->launch_rep[fs->pair_first] = fs->pair_first + 1;
     return RN_OK;
+}
+
+// true when the stage's output tensor is never written to HBM on this handle (it lives in LDS inside a fused launch)
+bool rn_fused_stage_elided(const rn_handle* h, int stage) {
+    const FusedState* fs = static_cast<const FusedState*>(h->fused);
+    if (!fs) return false;
+    return (fs->fuse_s0 && stage == 0) || (fs->pair_first >= 0 && stage == fs->pair_first);
 }
 
 int rn_fused_launch_rep(const rn_handle* h, int stage) {
@@ -810,6 +823,18 @@ int rn_fused_forward(rn_handle* h, const uint8_t* d_bgr, const float* d_rgb, int
         const StagePlan& s = h->stages[i];
         const FusedStage& f = fs->st[i];
         const StagePlan& prev = h->stages[i - 1];
+        if (fs->use_tail && i + 2 == h->stages.size()) {
+            // the last two stages, the flatten, the dense head, softmax and argmax in one launch: reported under the last
+            // stage, the head's own slot reads ~0
+            rn_record_event(h, 2 + static_cast<int>(i));
+            HeadArgs head;
+            rn_fill_head_args(h, &head);
+            int rc = rn_tail_launch(h, fs->st[i].wfrag, fs->st[i + 1].wfrag, head, n, d_probs, d_ids);
+            if (rc != RN_OK) return rc;
+            rn_record_event(h, 2 + static_cast<int>(i) + 1);
+            rn_record_event(h, 2 + static_cast<int>(h->stages.size()));
+            return RN_OK;
+        }
         if (static_cast<int>(i) == fs->pair_first) {
             // both stages of the pair in one launch; the event of the first stage is recorded in front of it, so
             // rn_timing reports the whole launch under the second stage

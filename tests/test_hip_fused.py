@@ -93,7 +93,9 @@ def test_cross_stage_fusion_is_bit_identical_to_stage_launches(weights, parity_i
             a, b = fused.tap("s3.bn2", nb), plain.tap("s3.bn2", nb)
             bad = np.argwhere(a != b)
             assert bad.size == 0, (dtype, len(bad), bad[:8].tolist(), float(np.abs(a - b).max()))
+            np.testing.assert_array_equal(fused.tap("s8.bn", nb), plain.tap("s8.bn", nb))      # tail kernel (rn_tail.hip)
             np.testing.assert_array_equal(fused.tap("s9.bn2", nb), plain.tap("s9.bn2", nb))
+            np.testing.assert_array_equal(fused.tap("d3.relu", nb), plain.tap("d3.relu", nb))
             np.testing.assert_array_equal(probs_f, probs_p)
             np.testing.assert_array_equal(ids_f, ids_p)
         finally:
@@ -180,9 +182,10 @@ def test_timing(engine, parity_images):
     engine.forward_u8(parity_images[:8])
     t = engine.timing()
     engine.set_profiling(False)
-    # (stage 0 runs inside stage 1's launch and stage 2 inside stage 3's: their own slots read ~0)
-    assert len(t["stage_ms"]) == 10 and all(x > 0 for i, x in enumerate(t["stage_ms"]) if i not in (0, 2))
-    assert engine.launch_groups() == [[0, 1], [2, 3], [4], [5], [6], [7], [8], [9]]
+    # (stage 0 runs inside stage 1's launch, stage 2 inside stage 3's, stage 8 and the head inside stage 9's: their
+    #  own slots read ~0)
+    assert len(t["stage_ms"]) == 10 and all(x > 0 for i, x in enumerate(t["stage_ms"]) if i not in (0, 2, 8))
+    assert engine.launch_groups() == [[0, 1], [2, 3], [4], [5], [6], [7], [8, 9]]
 
 
 # ------------------------------------------------------------------ full size (BASELINE configs 3/4: batch 256)
