@@ -2,9 +2,9 @@
 reference makes (``cv2.imread`` ``infer.py:81``, ``cv2.putText`` ``infer.py:89-92``,
 ``cv2.imwrite`` ``infer.py:93``).  OpenCV is not installed on the MI355X hosts; Pillow is.
 
-Differences from OpenCV that cannot be removed without its sources/fonts are limited to
-pixels that never reach the network: the overlay text is drawn with Pillow's built-in font
-instead of the Hershey simplex strokes (same anchor, colours, scale rule, anti-aliased).
+The overlay text is drawn with the same Hershey simplex strokes, anchor, scale rule and colours as
+``cv2.putText`` (``roomnet_amd/hershey.py``); the anti-aliasing filter is not OpenCV's, so overlay pixel values are
+close to, not equal to, OpenCV's -- pixels that never reach the network.
 """
 from __future__ import annotations
 
@@ -58,14 +58,7 @@ def imwrite(path: str, im_bgr: np.ndarray) -> bool:
 def put_text(im_bgr: np.ndarray, text: str, org: Tuple[int, int], font_scale: float,
              color_bgr: Tuple[int, int, int]) -> None:
     """In-place overlay like ``cv2.putText(im, text, org, FONT_HERSHEY_SIMPLEX, font_scale,
-    color, 1, LINE_AA)``: ``org`` is the bottom-left corner of the text."""
-    from PIL import Image, ImageDraw, ImageFont
-    size = max(6, int(round(30.0 * font_scale)))      # Hershey simplex is ~30 px tall at scale 1
-    try:
-        font = ImageFont.load_default(size=size)
-    except TypeError:                                  # very old Pillow: fixed-size bitmap font
-        font = ImageFont.load_default()
-    img = Image.fromarray(np.ascontiguousarray(im_bgr[:, :, ::-1]))
-    draw = ImageDraw.Draw(img)
-    draw.text((org[0], org[1]), text, fill=(color_bgr[2], color_bgr[1], color_bgr[0]), font=font, anchor="ls")
-    im_bgr[:, :, :] = np.asarray(img, dtype=np.uint8)[:, :, ::-1]
+    color, 1, LINE_AA)``: ``org`` is the bottom-left corner of the text on its baseline.  Drawn with the Hershey
+    simplex strokes OpenCV uses (``roomnet_amd/hershey.py``)."""
+    from . import hershey
+    hershey.put_text(im_bgr, text, org, font_scale, color_bgr, 1)

@@ -259,3 +259,39 @@ def test_xls_workbook_structure_follows_ms_xls(tmp_path):
     # DIMENSIONS of the sheet: rows [0, 301), columns [0, 3)
     dim = [body for rid, roff, body in recs if rid == 0x0200 and roff > substreams[1][1]]
     assert struct.unpack_from("<IIHH", dim[0]) == (0, 301, 0, 3)
+
+
+def test_overlay_text_is_hershey_simplex_strokes_at_the_cv2_anchor():
+    """cv2.putText(img, text, org, FONT_HERSHEY_SIMPLEX, scale, color, 1, LINE_AA) (reference infer.py:89-92): org is the
+    bottom-left corner on the baseline, font unit (x, y) lands on (org.x + x * scale, org.y - y * scale), capitals are
+    21 units tall, descenders reach 7 units below, a glyph advances the pen by its table width."""
+    from roomnet_amd import hershey
+    from roomnet_amd.imageio import put_text
+    scale = 2.0
+    im = np.zeros((160, 700, 3), np.uint8)
+    org = (20, 100)
+    put_text(im, "Predicted Class: Bedroom", org, scale, (0, 255, 0))
+    ys, xs = np.nonzero(im[:, :, 1])
+    assert (im[:, :, 0] == 0).all() and (im[:, :, 2] == 0).all()            # pure green
+    assert abs(ys.min() - (org[1] - 21 * scale)) <= 1.5                       # cap height ('P', 'C', 'B', 'd')
+    assert ys.max() <= org[1] + 1                                             # nothing in this text descends
+    assert abs(xs.min() - (org[0] + 4 * scale)) <= 1.5                        # 'P' starts at font x = 4
+    assert xs.max() <= org[0] + hershey.text_width("Predicted Class: Bedroom", scale)
+    assert ((im[:, :, 1] > 0) & (im[:, :, 1] < 255)).any()                    # anti-aliased edges
+    im2 = np.zeros((160, 300, 3), np.uint8)
+    put_text(im2, "gy", (10, 100), scale, (255, 255, 255))
+    assert abs(np.nonzero(im2[:, :, 0])[0].max() - (100 + 7 * scale)) <= 1.5  # descenders: 7 units below the baseline
+    # a one-stroke glyph: 'l' is the segment (4,21)-(4,0): a vertical line one pixel wide at x = org.x + 4 * scale
+    im3 = np.zeros((80, 40, 3), np.uint8)
+    put_text(im3, "l", (5, 60), 1.0, (0, 0, 255))
+    col = im3[:, :, 2].sum(0)
+    assert col.argmax() in (9, 10) and (col > 0).sum() <= 3
+    rows = np.nonzero(im3[:, :, 2].sum(1))[0]
+    assert abs(rows.min() - 39) <= 1.5 and abs(rows.max() - 60) <= 1.5
+    # characters outside the table are drawn as '?', like OpenCV does; text off the image is clipped, not an error
+    a, b = np.zeros((60, 60, 3), np.uint8), np.zeros((60, 60, 3), np.uint8)
+    put_text(a, "é", (5, 50), 1.0, (9, 9, 9))
+    put_text(b, "?", (5, 50), 1.0, (9, 9, 9))
+    np.testing.assert_array_equal(a, b)
+    put_text(a, "Kitchen", (50, 500), 1.0, (1, 2, 3))
+    assert len(hershey.GLYPHS) >= 80 and all(len(s) >= 2 for _, strokes in hershey.GLYPHS.values() for s in strokes)
