@@ -273,7 +273,7 @@ def test_overlay_text_is_hershey_simplex_strokes_at_the_cv2_anchor():
     put_text(im, "Predicted Class: Bedroom", org, scale, (0, 255, 0))
     ys, xs = np.nonzero(im[:, :, 1])
     assert (im[:, :, 0] == 0).all() and (im[:, :, 2] == 0).all()            # pure green
-    assert abs(ys.min() - (org[1] - 21 * scale)) <= 1.5                       # cap height ('P', 'C', 'B', 'd')
+    assert abs(ys.min() - (org[1] - 22 * scale)) <= 1.5                       # capitals reach 21 units, the dot of 'i' 22
     assert ys.max() <= org[1] + 1                                             # nothing in this text descends
     assert abs(xs.min() - (org[0] + 4 * scale)) <= 1.5                        # 'P' starts at font x = 4
     assert xs.max() <= org[0] + hershey.text_width("Predicted Class: Bedroom", scale)
