@@ -172,8 +172,12 @@ RN_API int rn_classify_images_u8(rn_handle* h, const uint8_t* const* images, con
 RN_API int rn_sync(rn_handle* h);
 
 /* Run on a caller-provided hipStream_t (e.g. the framework's current stream)
- * instead of the handle's own; NULL restores the handle's stream. */
+ * instead of the handle's own; NULL restores the handle's stream (a non-blocking stream,
+ * NOT ordered against the HIP null stream).  rn_set_stream_null selects the HIP null
+ * (legacy default) stream itself, which a NULL argument cannot express: use it when the
+ * caller's other work is on the default stream and must be ordered with the library's. */
 RN_API int rn_set_stream(rn_handle* h, void* hip_stream);
+RN_API int rn_set_stream_null(rn_handle* h);
 
 /* ---- introspection -----------------------------------------------------------
  * rn_tap copies graph node `node_id` of the last forward call to host float32

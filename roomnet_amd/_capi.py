@@ -32,7 +32,7 @@ LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libr
 EXPORTED_SYMBOLS = (
     "rn_create", "rn_destroy", "rn_last_error", "rn_device_count", "rn_version",
     "rn_forward_u8", "rn_forward_f32", "rn_forward_u8_device", "rn_forward_f32_device", "rn_sync",
-    "rn_set_stream", "rn_node_count", "rn_node_info_get", "rn_tap", "rn_set_profiling", "rn_timing",
+    "rn_set_stream", "rn_set_stream_null", "rn_node_count", "rn_node_info_get", "rn_tap", "rn_set_profiling", "rn_timing",
     "rn_dominant_stage", "rn_stage_launch", "rn_device_malloc", "rn_device_free", "rn_memcpy_h2d", "rn_memcpy_d2h",
     "rn_crop_resize_u8_device", "rn_classify_images_u8",
     "rn_group_create", "rn_group_destroy", "rn_group_size", "rn_group_handle", "rn_group_forward_u8",
@@ -110,6 +110,8 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.rn_sync.restype = i32
     lib.rn_set_stream.argtypes = [vp, vp]
     lib.rn_set_stream.restype = i32
+    lib.rn_set_stream_null.argtypes = [vp]
+    lib.rn_set_stream_null.restype = i32
     lib.rn_node_count.argtypes = [vp]
     lib.rn_node_count.restype = i32
     lib.rn_node_info_get.argtypes = [vp, i32, C.POINTER(rn_node_info)]
@@ -340,7 +342,14 @@ class Engine:
         _check(self.lib, self.lib.rn_sync(self.handle), "rn_sync")
 
     def set_stream(self, hip_stream: Optional[int]) -> None:
-        _check(self.lib, self.lib.rn_set_stream(self.handle, C.c_void_p(hip_stream or 0)), "rn_set_stream")
+        """Run on the given hipStream_t handle; ``None`` restores the engine's own (non-blocking) stream; ``0`` selects
+        the HIP null stream (what ``torch.cuda.current_stream().cuda_stream`` is when no stream context is active)."""
+        if hip_stream is None:
+            _check(self.lib, self.lib.rn_set_stream(self.handle, C.c_void_p(0)), "rn_set_stream")
+        elif hip_stream == 0:
+            _check(self.lib, self.lib.rn_set_stream_null(self.handle), "rn_set_stream_null")
+        else:
+            _check(self.lib, self.lib.rn_set_stream(self.handle, C.c_void_p(hip_stream)), "rn_set_stream")
 
     # -- device memory helpers
     def device_malloc(self, nbytes: int) -> int:

@@ -522,6 +522,15 @@ extern "C" int rn_set_stream(rn_handle* h, void* hip_stream) {
     return RN_OK;
 }
 
+extern "C" int rn_set_stream_null(rn_handle* h) {
+    if (!h) {
+        rn_set_error("null handle");
+        return RN_E_INVALID;
+    }
+    h->stream = nullptr;          // hipStream_t(0): the null stream
+    return RN_OK;
+}
+
 extern "C" int rn_sync(rn_handle* h) {
     if (!h) {
         rn_set_error("null handle");
