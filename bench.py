@@ -336,7 +336,7 @@ def main():
     stage_ms = np.zeros(n_st)
     head_ms = total_ms = 0.0
     event_ms = []
-    pcie_rate = None
+    pcie_rate = pcie_pipe_rate = None
     if not stub:
         # ---- per-stage device time (HIP events on the launch stream), separate from the timed region
         eng.set_profiling(True)
@@ -369,6 +369,15 @@ def main():
             for _ in range(max(3, args.steps // 4)):
                 eng.forward_u8(host_ims)
             pcie_rate = B * max(3, args.steps // 4) / (time.perf_counter() - t1)
+            # two-slot pipeline (rn_submit_u8 / rn_collect): the upload of batch k+1 overlaps the kernels of batch k
+            reps = max(4, args.steps // 4)
+            eng.submit_u8(host_ims, 0)
+            t1 = time.perf_counter()
+            for k in range(reps):
+                eng.submit_u8(host_ims, (k + 1) & 1)
+                eng.collect(k & 1)
+            pcie_pipe_rate = B * reps / (time.perf_counter() - t1)
+            eng.collect(reps & 1)
 
     if rank == 0:
         elem = 4 if args.dtype == "f32" else 2
@@ -441,6 +450,7 @@ def main():
                                                for j, g in enumerate(groups)]}
             if pcie_rate is not None:
                 out["path"]["pcie_inclusive_images_per_sec"] = pcie_rate
+                out["path"]["pcie_pipelined_images_per_sec"] = pcie_pipe_rate
             if world == 1 and not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline(weights, args.side)
         print(json.dumps(out), flush=True)

@@ -150,6 +150,15 @@ RN_API const char* rn_version(void);
  * Host buffers; blocks until the results are in probs/ids. */
 RN_API int rn_forward_u8(rn_handle* h, const uint8_t* bgr_nhwc, int n, float* probs, int64_t* ids);
 
+/* Two-slot pipelined form of rn_forward_u8 for a caller that classifies batch after batch from host memory (the
+ * directory driver, infer.py:79-82, at batch size): rn_submit_u8 uploads the batch into the slot's device buffer on a
+ * copy stream and enqueues its forward pass + result download behind it; rn_collect waits for that slot and copies the
+ * results out.  With  submit(0) submit(1) collect(0) submit(0) collect(1) ...  the upload of one batch overlaps the kernels
+ * of the previous one (from pageable memory the upload call itself blocks the calling thread, the GPU does not idle;
+ * from pinned memory it is asynchronous).  slot = 0 or 1; a slot must be collected before it is submitted again. */
+RN_API int rn_submit_u8(rn_handle* h, const uint8_t* bgr_nhwc, int n, int slot);
+RN_API int rn_collect(rn_handle* h, int slot, float* probs, int64_t* ids);
+
 /* rn_forward_f32 replaces sess.run(outs_final, {x_tensor: im}) (reference
  * network.py:133/:155) for an already pre-processed RGB float32 batch in [-1,1]. */
 RN_API int rn_forward_f32(rn_handle* h, const float* rgb_nhwc, int n, float* probs, int64_t* ids);

@@ -31,7 +31,7 @@ LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libr
 # every symbol include/roomnet_hip.h declares (tests check the .so exports all of them)
 EXPORTED_SYMBOLS = (
     "rn_create", "rn_destroy", "rn_last_error", "rn_device_count", "rn_version",
-    "rn_forward_u8", "rn_forward_f32", "rn_forward_u8_device", "rn_forward_f32_device", "rn_sync",
+    "rn_forward_u8", "rn_submit_u8", "rn_collect", "rn_forward_f32", "rn_forward_u8_device", "rn_forward_f32_device", "rn_sync",
     "rn_set_stream", "rn_set_stream_null", "rn_node_count", "rn_node_info_get", "rn_tap", "rn_set_profiling", "rn_timing",
     "rn_dominant_stage", "rn_stage_launch", "rn_device_malloc", "rn_device_free", "rn_memcpy_h2d", "rn_memcpy_d2h",
     "rn_crop_resize_u8_device", "rn_classify_images_u8",
@@ -106,6 +106,10 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
         fn = getattr(lib, name)
         fn.argtypes = [vp, vp, i32, vp, vp]
         fn.restype = i32
+    lib.rn_submit_u8.argtypes = [vp, vp, i32, i32]
+    lib.rn_submit_u8.restype = i32
+    lib.rn_collect.argtypes = [vp, i32, vp, vp]
+    lib.rn_collect.restype = i32
     lib.rn_sync.argtypes = [vp]
     lib.rn_sync.restype = i32
     lib.rn_set_stream.argtypes = [vp, vp]
@@ -340,6 +344,24 @@ class Engine:
 
     def sync(self) -> None:
         _check(self.lib, self.lib.rn_sync(self.handle), "rn_sync")
+
+    def submit_u8(self, bgr_nhwc: np.ndarray, slot: int) -> None:
+        """Upload + enqueue one batch (<= max_batch images) into pipeline slot 0 or 1 (``rn_submit_u8``)."""
+        s = self.graph.im_side
+        x = np.ascontiguousarray(bgr_nhwc, dtype=np.uint8)
+        if x.ndim != 4 or x.shape[1:] != (s, s, 3):
+            raise ValueError("expected uint8 [n,%d,%d,3], got %s" % (s, s, x.shape))
+        _check(self.lib, self.lib.rn_submit_u8(self.handle, x.ctypes.data, x.shape[0], slot), "rn_submit_u8")
+        self._slot_n = getattr(self, "_slot_n", {})
+        self._slot_n[slot] = x.shape[0]
+
+    def collect(self, slot: int) -> Tuple[np.ndarray, np.ndarray]:
+        """Wait for the batch in `slot` and return ``(ids, probs)`` (``rn_collect``)."""
+        n = getattr(self, "_slot_n", {}).get(slot, 0)
+        probs = np.empty((max(n, 1), self.graph.num_classes), np.float32)
+        ids = np.empty((max(n, 1),), np.int64)
+        _check(self.lib, self.lib.rn_collect(self.handle, slot, probs.ctypes.data, ids.ctypes.data), "rn_collect")
+        return ids[:n], probs[:n]
 
     def set_stream(self, hip_stream: Optional[int]) -> None:
         """Run on the given hipStream_t handle; ``None`` restores the engine's own (non-blocking) stream; ``0`` selects

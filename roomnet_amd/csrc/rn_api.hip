@@ -508,6 +508,16 @@ extern "C" void rn_destroy(rn_handle* h) {
         if (e) (void)hipEventDestroy(e);
     for (void* p : h->allocs) (void)hipFree(p);
     if (h->d_raw) (void)hipFree(h->d_raw);
+    for (auto& sl : h->slots) {
+        if (sl.d_in) (void)hipFree(sl.d_in);
+        if (sl.d_probs) (void)hipFree(sl.d_probs);
+        if (sl.d_ids) (void)hipFree(sl.d_ids);
+        if (sl.h_probs) (void)hipHostFree(sl.h_probs);
+        if (sl.h_ids) (void)hipHostFree(sl.h_ids);
+        if (sl.uploaded) (void)hipEventDestroy(sl.uploaded);
+        if (sl.done) (void)hipEventDestroy(sl.done);
+    }
+    if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
     rn_fused_release(h);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
     delete h;
@@ -598,6 +608,67 @@ extern "C" int rn_forward_u8(rn_handle* h, const uint8_t* bgr, int n, float* pro
                           h->stream));
     RN_HIP(hipMemcpyAsync(ids, h->d_ids, static_cast<size_t>(n) * 8, hipMemcpyDeviceToHost, h->stream));
     RN_HIP(hipStreamSynchronize(h->stream));
+    return RN_OK;
+}
+
+// ---- two-slot host pipeline: the upload of batch k+1 overlaps the forward pass of batch k
+extern "C" int rn_submit_u8(rn_handle* h, const uint8_t* bgr, int n, int slot) {
+    if (!h || !bgr || slot < 0 || slot > 1) {
+        rn_set_error("rn_submit_u8: bad argument");
+        return RN_E_INVALID;
+    }
+    if (n < 1 || n > h->max_batch) {
+        rn_set_error("rn_submit_u8: n = %d out of range (1..%d)", n, h->max_batch);
+        return RN_E_RANGE;
+    }
+    rn_handle::HostSlot& sl = h->slots[slot];
+    if (sl.busy) {
+        rn_set_error("rn_submit_u8: slot %d holds results that were not collected", slot);
+        return RN_E_STATE;
+    }
+    DeviceGuard guard(h->device);
+    if (!h->copy_stream) RN_HIP(hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
+    if (!sl.d_in) {
+        const size_t in_bytes = static_cast<size_t>(h->max_batch) * h->im_side * h->im_side * 3;
+        RN_HIP(hipMalloc(reinterpret_cast<void**>(&sl.d_in), in_bytes));
+        RN_HIP(hipMalloc(reinterpret_cast<void**>(&sl.d_probs), static_cast<size_t>(h->max_batch) * h->num_classes * 4));
+        RN_HIP(hipMalloc(reinterpret_cast<void**>(&sl.d_ids), static_cast<size_t>(h->max_batch) * 8));
+        RN_HIP(hipHostMalloc(reinterpret_cast<void**>(&sl.h_probs), static_cast<size_t>(h->max_batch) * h->num_classes * 4, 0));
+        RN_HIP(hipHostMalloc(reinterpret_cast<void**>(&sl.h_ids), static_cast<size_t>(h->max_batch) * 8, 0));
+        RN_HIP(hipEventCreateWithFlags(&sl.uploaded, hipEventDisableTiming));
+        RN_HIP(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
+    }
+    const size_t in_bytes = static_cast<size_t>(n) * h->im_side * h->im_side * 3;
+    // from pageable memory this call returns once the bytes are staged: the previous batch's kernels, enqueued earlier on
+    // the compute stream, run meanwhile; from pinned memory it is asynchronous outright
+    RN_HIP(hipMemcpyAsync(sl.d_in, bgr, in_bytes, hipMemcpyHostToDevice, h->copy_stream));
+    RN_HIP(hipEventRecord(sl.uploaded, h->copy_stream));
+    RN_HIP(hipStreamWaitEvent(h->stream, sl.uploaded, 0));
+    int rc = rn_forward_u8_device(h, sl.d_in, n, sl.d_probs, sl.d_ids);
+    if (rc != RN_OK) return rc;
+    RN_HIP(hipMemcpyAsync(sl.h_probs, sl.d_probs, static_cast<size_t>(n) * h->num_classes * 4, hipMemcpyDeviceToHost, h->stream));
+    RN_HIP(hipMemcpyAsync(sl.h_ids, sl.d_ids, static_cast<size_t>(n) * 8, hipMemcpyDeviceToHost, h->stream));
+    RN_HIP(hipEventRecord(sl.done, h->stream));
+    sl.n = n;
+    sl.busy = true;
+    return RN_OK;
+}
+
+extern "C" int rn_collect(rn_handle* h, int slot, float* probs, int64_t* ids) {
+    if (!h || !probs || !ids || slot < 0 || slot > 1) {
+        rn_set_error("rn_collect: bad argument");
+        return RN_E_INVALID;
+    }
+    rn_handle::HostSlot& sl = h->slots[slot];
+    if (!sl.busy) {
+        rn_set_error("rn_collect: nothing was submitted to slot %d", slot);
+        return RN_E_STATE;
+    }
+    DeviceGuard guard(h->device);
+    RN_HIP(hipEventSynchronize(sl.done));
+    std::memcpy(probs, sl.h_probs, static_cast<size_t>(sl.n) * h->num_classes * 4);
+    std::memcpy(ids, sl.h_ids, static_cast<size_t>(sl.n) * 8);
+    sl.busy = false;
     return RN_OK;
 }
 

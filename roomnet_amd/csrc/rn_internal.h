@@ -95,6 +95,19 @@ struct rn_handle {
     size_t raw_cap = 0;
     float* d_probs = nullptr;
     int64_t* d_ids = nullptr;
+    // two-slot host pipeline (rn_submit_u8 / rn_collect): allocated by the first submit
+    struct HostSlot {
+        uint8_t* d_in = nullptr;
+        float* d_probs = nullptr;
+        int64_t* d_ids = nullptr;
+        float* h_probs = nullptr;    // pinned
+        int64_t* h_ids = nullptr;    // pinned
+        hipEvent_t uploaded = nullptr, done = nullptr;
+        int n = 0;
+        bool busy = false;
+    };
+    HostSlot slots[2];
+    hipStream_t copy_stream = nullptr;
     std::vector<void*> allocs;   // everything to hipFree on destroy
     void* fused = nullptr;       // plan of the fused 16-bit path (rn_fused.hip)
     // profiling

@@ -400,3 +400,25 @@ def test_600_variant_at_baseline_size_64_images(weights, dtype):
     finally:
         big.close()
         small.close()
+
+
+def test_two_slot_host_pipeline_matches_the_blocking_entry(engine, parity_images):
+    """rn_submit_u8 / rn_collect: batches in flight in both slots, collected in order, give the blocking call's results;
+    misuse follows the error convention."""
+    batches = [parity_images[i:i + 8] for i in (0, 8, 16, 24, 32)] + [parity_images[3:6]]
+    want = [engine.forward_u8(b) for b in batches]
+    got = []
+    engine.submit_u8(batches[0], 0)
+    for k in range(len(batches)):
+        if k + 1 < len(batches):
+            engine.submit_u8(batches[k + 1], (k + 1) & 1)
+        got.append(engine.collect(k & 1))
+    for (ids_w, probs_w), (ids_g, probs_g) in zip(want, got):
+        np.testing.assert_array_equal(probs_g, probs_w)
+        np.testing.assert_array_equal(ids_g, ids_w)
+    with pytest.raises(_capi.RoomNetLibraryError):
+        engine.collect(0)                                        # nothing submitted
+    engine.submit_u8(batches[0], 1)
+    with pytest.raises(_capi.RoomNetLibraryError):
+        engine.submit_u8(batches[1], 1)                          # slot still holds uncollected results
+    engine.collect(1)
