@@ -58,7 +58,9 @@ def test_hbm_traffic_summary_is_reproducible_from_the_pmc_passes():
         if s["stage"] >= 8:
             continue
         if len(s.get("stages", [s["stage"]])) > 1:
-            assert 0.39 <= s["traffic_over_algorithmic"] <= 0.62, s
+            # stages 2+3: input + output is 0.40 of the model, + the residual's second look at its skip rows;
+            # stages 0+1: the 8-channel tensor between them (1.55 of 4.65 MB) is gone: 0.67
+            assert 0.39 <= s["traffic_over_algorithmic"] <= 0.70, s
         else:
             assert 0.55 <= s["traffic_over_algorithmic"] <= 1.05, s
     b = json.load(open(os.path.join(PROF, tag + "_bench.json")))
