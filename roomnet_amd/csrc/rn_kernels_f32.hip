@@ -147,18 +147,24 @@ __global__ __launch_bounds__(256) void convert_to_f32_kernel(const void* __restr
 
 // One 64-thread block (one wavefront) per image: flatten, dense chain, softmax, argmax.
 constexpr int HEAD_MAX_FLAT = 4096;
-__global__ __launch_bounds__(64) void head_kernel(const void* __restrict__ flat, int flat_dtype, HeadArgs a,
-                                                  float* __restrict__ probs, int64_t* __restrict__ ids) {
+// Launched with 64 threads (one wavefront) when the flatten is short (224 input: 64 values), with 256 when it is long
+// (600 input: 3136 values): the first dense layer's K loop is then split over 256 / nout partitions whose partial sums
+// meet in LDS -- with one wavefront the 3136-step dependent fma chain of that layer alone took 1.06 ms per launch at
+// 64 x 600x600 (21 % of the forward pass, profiles/r2_600_kernel_stats.csv).  Layers with nin <= 64 run as before.
+__global__ __launch_bounds__(256) void head_kernel(const void* __restrict__ flat, int flat_dtype, HeadArgs a,
+                                                   float* __restrict__ probs, int64_t* __restrict__ ids) {
     __shared__ float buf0[HEAD_MAX_FLAT];
     __shared__ float small[2][64];
+    __shared__ float part[256];
     // dense kernels staged in LDS with coalesced, independent loads (all layers that fit): read from global
     // inside the k loop, the 64 + 32 + 16 + 8 dependent steps each paid an L2 round trip (40 us per launch)
     constexpr int HEAD_W_LDS = 3072;
     __shared__ float wl[HEAD_W_LDS];
     const int img = blockIdx.x;
     const int lane = threadIdx.x;
+    const int nthr = blockDim.x;
     const int nin0 = a.nin[0];
-    for (int i = lane; i < nin0; i += 64) buf0[i] = load_as_f32(flat, flat_dtype, static_cast<int64_t>(img) * nin0 + i);
+    for (int i = lane; i < nin0; i += nthr) buf0[i] = load_as_f32(flat, flat_dtype, static_cast<int64_t>(img) * nin0 + i);
     int w_off[RN_MAX_DENSE];
     {
         int off = 0;
@@ -166,7 +172,7 @@ __global__ __launch_bounds__(64) void head_kernel(const void* __restrict__ flat,
             const int cnt = a.nin[d] * a.nout[d];
             if (off + cnt <= HEAD_W_LDS) {
                 w_off[d] = off;
-                for (int i = lane; i < cnt; i += 64) wl[off + i] = a.w[d][i];
+                for (int i = lane; i < cnt; i += nthr) wl[off + i] = a.w[d][i];
                 off += cnt;
             } else {
                 w_off[d] = -1;
@@ -178,10 +184,24 @@ __global__ __launch_bounds__(64) void head_kernel(const void* __restrict__ flat,
     for (int d = 0; d < a.n_dense; ++d) {
         const int nin = a.nin[d], nout = a.nout[d];
         float* dst = small[d & 1];
+        const float* wd = w_off[d] >= 0 ? wl + w_off[d] : a.w[d];
+        const int parts = (nthr > 64 && nin > 64) ? nthr / nout : 1;      // K partitions of this layer
+        if (parts > 1) {
+            // partition p takes k = p, p + parts, ...: lanes of one partition read consecutive outputs (coalesced)
+            const int o = lane % nout, p = lane / nout;
+            float v = 0.f;
+            if (p < parts)
+                for (int k = p; k < nin; k += parts) v = fmaf(cur[k], wd[k * nout + o], v);
+            part[lane] = v;
+            __syncthreads();
+        }
         if (lane < nout) {
             float v = 0.f;
-            const float* wd = w_off[d] >= 0 ? wl + w_off[d] : a.w[d];
-            for (int k = 0; k < nin; ++k) v = fmaf(cur[k], wd[k * nout + lane], v);
+            if (parts > 1) {
+                for (int p = 0; p < parts; ++p) v += part[p * nout + lane];
+            } else {
+                for (int k = 0; k < nin; ++k) v = fmaf(cur[k], wd[k * nout + lane], v);
+            }
             if (a.bias[d]) v = __fadd_rn(v, a.bias[d][lane]);
             if (a.tap_mm[d]) a.tap_mm[d][static_cast<int64_t>(img) * nout + lane] = v;
             v = relu6f(v);
@@ -195,7 +215,8 @@ __global__ __launch_bounds__(64) void head_kernel(const void* __restrict__ flat,
         __syncthreads();
         cur = dst;
     }
-    // softmax + argmax over the num_classes logits (wave-level: every lane holds one class)
+    // softmax + argmax over the num_classes logits (wave-level: every lane of the first wavefront holds one class)
+    if (lane >= 64) return;
     const int nc = a.nout[a.n_dense - 1];
     const float logit = lane < nc ? cur[lane] : -INFINITY;
     float mx = logit;
@@ -293,7 +314,8 @@ int rn_launch_head(hipStream_t s, const void* flat, int flat_dtype, int n, const
             rn_set_error("dense layer %d wider than 64 is not supported by the head kernel", d);
             return RN_E_INVALID;
         }
-    hipLaunchKernelGGL(head_kernel, dim3(n), dim3(64), 0, s, flat, flat_dtype, a, probs, ids);
+    const int threads = (a.nin[0] > 256 && a.nout[0] <= 64 && 256 % a.nout[0] == 0) ? 256 : 64;
+    hipLaunchKernelGGL(head_kernel, dim3(n), dim3(threads), 0, s, flat, flat_dtype, a, probs, ids);
     RN_CHECK_LAUNCH();
     return RN_OK;
 }
