@@ -71,8 +71,8 @@ __device__ __forceinline__ unsigned long long stamp23() {
 // epilogue micro-ops placed between its own MFMAs, in the history: a single wave pays ~5 cycles per non-MFMA
 // instruction and hides none of them behind its own dependent MFMAs; 5800 cycles per step against 5200 here, where
 // the consumer's serial instruction stream is the critical path and the producer waits ~1500 cycles at the barrier:
-// profiles/r2_stage23_stamps.txt.)  The consumer defers the epilogue of its second tile to the start of the next step,
-// which puts its chains opposite the producer's epilogues, and runs at s_setprio 1 (it is the wave the step waits for).
+// profiles/r2_b_stamps.txt.)  The consumer runs at s_setprio 1 (it is the wave the step waits for); deferring the
+// epilogue of its second tile to the next step, to put its chains opposite the producer's epilogues, measured the same.
 template <int DT>
 __global__ __launch_bounds__(512, 2) void stage23pc_kernel(const Stage23Args a) {
     constexpr int KC = 18, BAHEAD = 4;
@@ -158,6 +158,50 @@ __global__ __launch_bounds__(512, 2) void stage23pc_kernel(const Stage23Args a) 
         return H;
     };
 
+    // ---- residual skip rows (shared by both roles): consumer wave wq + 4 owns a private 3-row ring with the 64 columns of
+    // A its two tiles interpolate from.  Schedule (both roles run the same arithmetic, so they agree without talking): at
+    // the start of step t the ring holds rows ylo(t), ylo(t)+1 of that step's output row.  During step t the PRODUCER of
+    // the same tile pair fetches the one new row step t+1 needs (into the slot of row ylo(t)-1, which nobody reads any
+    // more; it lands before the producer's end-of-step wait and the barrier publishes it).  When the lo row jumps by 2
+    // (1 step in 20) a second new row is needed whose slot is still being read: the CONSUMER fetches that one itself at
+    // the start of step t+1 and waits for it before its first epilogue.
+    const int xs0 = a.rlo[min(58 * wq, Wo - 1)];
+    unsigned sk_goff[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int q = lane + 64 * i;
+        const int p = q >> 2, c = q & 3;
+        sk_goff[i] = static_cast<unsigned>(min(xs0 + p, W - 1) * 64 + ((c ^ swz4(p)) << 4));
+    }
+    char* const skw = smem + F_SKIP_OFF + wq * (F_NSK * F_SKROW);
+    const unsigned skw_lds = lds_addr(skw);
+    auto issue_skip_row = [&](int y, int slot) __attribute__((always_inline)) {
+        const char* row = in_img + static_cast<int64_t>(y) * static_cast<int64_t>(W * 64);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            unsigned off = sk_goff[i];
+            asm volatile("" : "+v"(off));
+            dma16(row + off, skw + slot * F_SKROW + i * 1024);
+        }
+    };
+    struct VLerp {
+        int ylo;
+        float yl;
+    };
+    auto vlerp_of = [&](int yo) __attribute__((always_inline)) -> VLerp {
+        const float src = mul_rounded(static_cast<float>(yo), a.rscale);
+        const int ylo = static_cast<int>(src);
+        VLerp v;
+        v.ylo = __builtin_amdgcn_readfirstlane(ylo);
+        v.yl = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(src - static_cast<float>(ylo))));
+        return v;
+    };
+    int sk_f = vlerp_of(yo0).ylo - 1;                 // highest skip row fetched so far (by either role)
+    int sk_slot = F_NSK - 1;                          // its ring slot (row y lives in slot (y - ylo(yo0)) mod 3)
+    auto ylo_step = [&](int t) __attribute__((always_inline)) {      // lo skip row of the output row step t finishes
+        return vlerp_of(yo0 + min(max(t - F_LAG, 0), nrows - 1)).ylo;
+    };
+
     if (wave < 4) {
         // =============================================================== producer: first stage, A ring -> B ring
         i32x4 w2[KC];
@@ -232,6 +276,20 @@ __global__ __launch_bounds__(512, 2) void stage23pc_kernel(const Stage23Args a) 
             constexpr int P = decltype(PC)::value;
             if (t < nrows + 9) a_next += W * 64;
             issue_A_row(a_next, (P + 1) % F_NA);            // A row t+1
+            {
+                // skip rows of the partner consumer (see the schedule above)
+                const int need_cur = min(ylo_step(t) + 1, W - 1);
+                if (sk_f < need_cur) {                      // the consumer fetches this one itself (lo row jumped by 2)
+                    ++sk_f;
+                    sk_slot = sk_slot == F_NSK - 1 ? 0 : sk_slot + 1;
+                }
+                const int need_next = min(ylo_step(t + 1) + 1, W - 1);
+                if (sk_f < need_next) {
+                    ++sk_f;
+                    sk_slot = sk_slot == F_NSK - 1 ? 0 : sk_slot + 1;
+                    issue_skip_row(sk_f, sk_slot);
+                }
+            }
             f32x16 acc;
 #ifdef RN_STAMPS
             const unsigned long long tp0 = stamp23();
@@ -303,37 +361,6 @@ __global__ __launch_bounds__(512, 2) void stage23pc_kernel(const Stage23Args a) 
         w3[kc] = a.wfrag3[kc * 64 + lane];
         asm volatile("" : "+a"(w3[kc]));
     }
-    const int xs0 = a.rlo[min(58 * wq, Wo - 1)];
-    unsigned sk_goff[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int q = lane + 64 * i;
-        const int p = q >> 2, c = q & 3;
-        sk_goff[i] = static_cast<unsigned>(min(xs0 + p, W - 1) * 64 + ((c ^ swz4(p)) << 4));
-    }
-    char* const skw = smem + F_SKIP_OFF + wq * (F_NSK * F_SKROW);
-    const unsigned skw_lds = lds_addr(skw);
-    auto issue_skip_row = [&](int y, int slot) __attribute__((always_inline)) {
-        const char* row = in_img + static_cast<int64_t>(y) * static_cast<int64_t>(W * 64);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            unsigned off = sk_goff[i];
-            asm volatile("" : "+v"(off));
-            dma16(row + off, skw + slot * F_SKROW + i * 1024);
-        }
-    };
-    struct VLerp {
-        int ylo;
-        float yl;
-    };
-    auto vlerp_of = [&](int yo) __attribute__((always_inline)) -> VLerp {
-        const float src = mul_rounded(static_cast<float>(yo), a.rscale);
-        const int ylo = static_cast<int>(src);
-        VLerp v;
-        v.ylo = __builtin_amdgcn_readfirstlane(ylo);
-        v.yl = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(src - static_cast<float>(ylo))));
-        return v;
-    };
     unsigned baseB[2][3][2], a_off[2][2];
     int voff[2];
     i32x4 bw[2][2];
@@ -389,14 +416,12 @@ __global__ __launch_bounds__(512, 2) void stage23pc_kernel(const Stage23Args a) 
         __amdgpu_buffer_rsrc_t rs;
         int emit_mask;
     };
-    const int ylo_base = vlerp_of(yo0).ylo;
-    int sk_fetched = ylo_base - 1, sk_fetched_slot = F_NSK - 1;
     VLerp vl_cur = vlerp_of(yo0);
     int slot_cur = 0;
-    RowCtx cx_cur{}, cx_prev{};
-    cx_cur.emit_mask = cx_prev.emit_mask = OOB;
-    cx_cur.rs = cx_prev.rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(out_row), 0, out_row_bytes, 0x00020000);
-    f32x16 acc1;                                     // second tile's accumulator: its epilogue runs in the next step
+    RowCtx cx_cur{};
+    cx_cur.emit_mask = OOB;
+    cx_cur.rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(out_row), 0, out_row_bytes, 0x00020000);
+    f32x16 acc1;
 #pragma unroll
     for (int g = 0; g < 16; ++g) acc1[g] = 0.f;
     lds_barrier();
@@ -499,29 +524,26 @@ __global__ __launch_bounds__(512, 2) void stage23pc_kernel(const Stage23Args a) 
 #ifdef RN_STAMPS
         const unsigned long long tc0 = stamp23();
 #endif
-#ifndef RN_X_NODEFER
-        // deferred epilogue of the previous step's second tile (its conv row has the other parity)
-        epi(IC<1>{}, IC<1 - PR>{}, acc1, cx_prev);
-#endif
+        // skip rows: the rare second new row of a step whose lo row jumped by 2 is fetched here; the regular one for the
+        // next step is fetched by the partner producer during this step (mirrored in sk_f / sk_slot)
+        const VLerp vl_next = vlerp_of(yo0 + min(max(jo + 1, 0), nrows - 1));
+        {
+            const int need_cur = min(vl_cur.ylo + 1, W - 1);
+            if (sk_f < need_cur) {
+                ++sk_f;
+                sk_slot = sk_slot == F_NSK - 1 ? 0 : sk_slot + 1;
+                issue_skip_row(sk_f, sk_slot);
+            }
+            const int need_next = min(vl_next.ylo + 1, W - 1);
+            if (sk_f < need_next) {
+                ++sk_f;
+                sk_slot = sk_slot == F_NSK - 1 ? 0 : sk_slot + 1;
+            }
+        }
 #ifdef RN_STAMPS
         const unsigned long long tc1 = stamp23();
         st_seg[0] += tc1 - tc0;
-#endif
-        // skip rows for the next step's residual (see stage23_kernel)
-        const VLerp vl_next = vlerp_of(yo0 + min(max(jo + 1, 0), nrows - 1));
-        {
-            const int need = min(vl_next.ylo + 1, W - 1);
-#pragma unroll
-            for (int it = 0; it < 2; ++it)
-                if (sk_fetched < need && sk_fetched - 2 < vl_cur.ylo) {
-                    ++sk_fetched;
-                    sk_fetched_slot = sk_fetched_slot == F_NSK - 1 ? 0 : sk_fetched_slot + 1;
-                    issue_skip_row(sk_fetched, sk_fetched_slot);
-                }
-        }
-#ifdef RN_STAMPS
-        const unsigned long long tc2 = stamp23();
-        st_seg[1] += tc2 - tc1;
+        const unsigned long long tc2 = tc1;
 #endif
         f32x16 acc0;
         chain(IC<P>{}, IC<F_ROWB>{}, baseB[0], w3, acc0);       // conv row t-8: B rows t-8 .. t-6
@@ -529,7 +551,7 @@ __global__ __launch_bounds__(512, 2) void stage23pc_kernel(const Stage23Args a) 
         const unsigned long long tc3 = stamp23();
         st_seg[2] += tc3 - tc2;
 #endif
-        wait_vmcnt<0>();                                       // this step's skip rows have landed
+        wait_vmcnt<0>();                                       // a skip row fetched at the top of this step has landed
 #ifdef RN_STAMPS
         const unsigned long long tc4 = stamp23();
         st_seg[3] += tc4 - tc3;
@@ -540,13 +562,10 @@ __global__ __launch_bounds__(512, 2) void stage23pc_kernel(const Stage23Args a) 
         st_seg[4] += tc5 - tc4;
 #endif
         chain(IC<P>{}, IC<F_ROWB>{}, baseB[1], w3, acc1);
-#ifdef RN_X_NODEFER
         epi(IC<1>{}, IC<PR>{}, acc1, cx_cur);
-#endif
 #ifdef RN_STAMPS
         st_seg[5] += stamp23() - tc5;
 #endif
-        cx_prev = cx_cur;
         {
             int sl = slot_cur + (vl_next.ylo - vl_cur.ylo);
             slot_cur = sl >= F_NSK ? sl - F_NSK : sl;
@@ -575,12 +594,6 @@ __global__ __launch_bounds__(512, 2) void stage23pc_kernel(const Stage23Args a) 
     if (rem > 0) step(IC<0>{}, t);
     if (rem > 1) step(IC<1>{}, t + 1);
     if (rem > 2) step(IC<2>{}, t + 2);
-#ifndef RN_X_NODEFER
-    if (((nsteps - 1) & 1) == 0)
-        epi(IC<1>{}, IC<0>{}, acc1, cx_prev);
-    else
-        epi(IC<1>{}, IC<1>{}, acc1, cx_prev);
-#endif
     wait_vmcnt<0>();
 #ifdef RN_STAMPS
     if (a.stamp_buf && lane == 0) {
