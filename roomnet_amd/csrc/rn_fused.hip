@@ -901,8 +901,8 @@ int rn_fused_forward(rn_handle* h, const uint8_t* d_bgr, const float* d_rgb, int
                     }
                     fprintf(stderr, "[stamps]   producer segments (chain0 epi0 chain1 epi1): %.0f %.0f %.0f %.0f\n", seg[0][0] / st[0], seg[0][1] / st[0],
                             seg[0][2] / st[0], seg[0][3] / st[0]);
-                    fprintf(stderr, "[stamps]   consumer segments (epi1' fetch chain0 dma-wait epi0 chain1): %.0f %.0f %.0f %.0f %.0f %.0f\n", seg[1][0] / st[1],
-                            seg[1][1] / st[1], seg[1][2] / st[1], seg[1][3] / st[1], seg[1][4] / st[1], seg[1][5] / st[1]);
+                    fprintf(stderr, "[stamps]   consumer segments (bookkeeping+own-fetch chain0 skip-wait epi0 chain1+epi1): %.0f %.0f %.0f %.0f %.0f\n", seg[1][0] / st[1],
+                            seg[1][2] / st[1], seg[1][3] / st[1], seg[1][4] / st[1], seg[1][5] / st[1]);
                 }
                 for (int w8 = 0; w8 < 8; ++w8)
                     if (wsteps[w8] > 0)

@@ -9,6 +9,16 @@ namespace rnk {
 using i32x4 = __attribute__((ext_vector_type(4))) int;
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 using f32x4 = __attribute__((ext_vector_type(4))) float;
+using f32x2 = __attribute__((ext_vector_type(2))) float;
+
+// Packed fp32 arithmetic (v_pk_fma_f32 / v_pk_add_f32: two IEEE fp32 operations per VALU slot, bit-identical to the
+// scalar forms).  The epilogues are bound by instruction issue, so BN and the residual lerp run on register pairs.
+__device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+// (hipcc splits a v2f32 fsub into two v_sub_f32, also when written as fma(b, -1, a); an inline-asm v_pk_add_f32 with
+//  neg modifiers cost the fused stage pair 15 spills: the subtraction stays two scalar instructions)
+__device__ __forceinline__ f32x2 pk_sub(f32x2 a, f32x2 b) { return a - b; }
+__device__ __forceinline__ f32x2 pk_add(f32x2 a, f32x2 b) { return a + b; }
+__device__ __forceinline__ f32x2 pk_splat(float v) { return f32x2{v, v}; }
 using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
 using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
 
@@ -41,7 +51,6 @@ __device__ __forceinline__ float from16(unsigned short u) {
 // two floats -> one dword of two 16-bit values, round-to-nearest-even (one v_cvt_pk_*)
 template <int DT>
 __device__ __forceinline__ unsigned pack2(float a, float b) {
-    using f32x2 = __attribute__((ext_vector_type(2))) float;
     const f32x2 v = {a, b};
     if constexpr (DT == RN_DTYPE_BF16) {
         using bf16x2 = __attribute__((ext_vector_type(2))) __bf16;

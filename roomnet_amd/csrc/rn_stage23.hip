@@ -210,27 +210,34 @@ __global__ __launch_bounds__(512, 2) void stage23pc_kernel(const Stage23Args a) 
             w2[kc] = a.wfrag2[kc * 64 + lane];
             asm volatile("" : "+a"(w2[kc]));
         }
-        const int ptid = wq * 64 + lane;                 // the four producer waves fetch the A rows
+        // ---- A rows: four DMA pieces per producer wave and row (a piece is 64 lanes x 16 B, the fourth is the masked W-192 tail)
+        const int ptid = wq * 64 + lane;
         const int tailn = W - 192;
         const unsigned long long tail_mask = (1ull << tailn) - 1ull;
-        unsigned ld_goff[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int q = i < 3 ? ptid + 256 * i : 768 + tailn * wq + min(lane, tailn - 1);
+        // pieces 0..2 cover pixels ptid/4 + 64 i (< 192 <= W - 1: never clamped), and the chunk swizzle has period 16 pixels:
+        // their source offsets differ by exactly 4096 bytes, which goes into the scalar row base -- one offset register
+        const unsigned ld_goff = static_cast<unsigned>((ptid >> 2) * 64 + (((ptid & 3) ^ swz4(ptid >> 2)) << 4));
+        unsigned ld_goff_tail;
+        {
+            const int q = 768 + tailn * wq + min(lane, tailn - 1);
             const int p = q >> 2, c = q & 3;
-            ld_goff[i] = static_cast<unsigned>(min(p, W - 1) * 64 + ((c ^ swz4(p)) << 4));
+            ld_goff_tail = static_cast<unsigned>(min(p, W - 1) * 64 + ((c ^ swz4(p)) << 4));
         }
-        auto issue_A_row = [&](const char* row, int slot) __attribute__((always_inline)) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                unsigned off = ld_goff[i];
-                asm volatile("" : "+v"(off));
-                if (i < 3)
-                    dma16(row + off, ringA + slot * F_ROWA + (i * 256 + wq * 64) * 16);
-                else
+        auto issue_A_pieces = [&](auto I0, auto I1, const char* row, int slot) __attribute__((always_inline)) {
+    #pragma unroll
+            for (int i = decltype(I0)::value; i < decltype(I1)::value; ++i) {
+                if (i < 3) {
+                    unsigned off = ld_goff;
+                    asm volatile("" : "+v"(off));
+                    dma16(row + i * 4096 + off, ringA + slot * F_ROWA + (i * 256 + wq * 64) * 16);
+                } else {
+                    unsigned off = ld_goff_tail;
+                    asm volatile("" : "+v"(off));
                     dma16_masked(row + off, ringA + slot * F_ROWA + (768 + tailn * wq) * 16, tail_mask);
+                }
             }
         };
+        const char* a_next = in_img + static_cast<int64_t>(yo0) * (W * 64);
         unsigned baseA[2][3][2], wbB[2];
 #pragma unroll
         for (int T = 0; T < 2; ++T) {
@@ -249,8 +256,7 @@ __global__ __launch_bounds__(512, 2) void stage23pc_kernel(const Stage23Args a) 
         i32x4 hp[2][2], q0[2][2], q1[2][2];
 #pragma unroll
         for (int T = 0; T < 2; ++T) hp[T][0] = hp[T][1] = q0[T][0] = q0[T][1] = q1[T][0] = q1[T][1] = i32x4{0, 0, 0, 0};
-        const char* a_next = in_img + static_cast<int64_t>(yo0) * (W * 64);
-        issue_A_row(a_next, 0);
+        issue_A_pieces(IC<0>{}, IC<4>{}, a_next, 0);
         wait_vmcnt<0>();
         lds_barrier();
 
@@ -264,8 +270,9 @@ __global__ __launch_bounds__(512, 2) void stage23pc_kernel(const Stage23Args a) 
             for (int g = 0; g < 4; ++g) {
                 const f32x4 sc = *reinterpret_cast<const f32x4*>(tabl + 8 * g);
                 const f32x4 sh = *reinterpret_cast<const f32x4*>(tabl + 32 + 8 * g);
-                const i32x2 d = {static_cast<int>(pack2<DT>(fmaf(H[4 * g], sc[0], sh[0]), fmaf(H[4 * g + 1], sc[1], sh[1]))),
-                                 static_cast<int>(pack2<DT>(fmaf(H[4 * g + 2], sc[2], sh[2]), fmaf(H[4 * g + 3], sc[3], sh[3])))};
+                const f32x2 y0 = pk_fma(f32x2{H[4 * g], H[4 * g + 1]}, f32x2{sc[0], sc[1]}, f32x2{sh[0], sh[1]});
+                const f32x2 y1 = pk_fma(f32x2{H[4 * g + 2], H[4 * g + 3]}, f32x2{sc[2], sc[3]}, f32x2{sh[2], sh[3]});
+                const i32x2 d = {static_cast<int>(pack2<DT>(y0[0], y0[1])), static_cast<int>(pack2<DT>(y1[0], y1[1]))};
                 asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(wb[T] ^ static_cast<unsigned>(g << 4)), "v"(d), "n"(off) : "memory");
             }
         };
@@ -275,7 +282,7 @@ __global__ __launch_bounds__(512, 2) void stage23pc_kernel(const Stage23Args a) 
         auto step = [&](auto PC, int t) __attribute__((always_inline)) {
             constexpr int P = decltype(PC)::value;
             if (t < nrows + 9) a_next += W * 64;
-            issue_A_row(a_next, (P + 1) % F_NA);            // A row t+1
+            issue_A_pieces(IC<0>{}, IC<4>{}, a_next, (P + 1) % F_NA);            // A row t+1
             {
                 // skip rows of the partner consumer (see the schedule above)
                 const int need_cur = min(ylo_step(t) + 1, W - 1);
@@ -481,16 +488,19 @@ __global__ __launch_bounds__(512, 2) void stage23pc_kernel(const Stage23Args a) 
              [&] {
             constexpr int g = G;
             const f32x4 sc1 = tsc1[g], sh1 = tsh1[g], sc2 = tsc2[g];
-            float y[4];
+            f32x2 y[2];
+            const f32x2 ylv = pk_splat(cx.yl);
 #pragma unroll
-            for (int jj = 0; jj < 4; ++jj) {
-                y[jj] = fmaf(H[4 * g + jj], sc1[jj], sh1[jj]);
-                const float lo = r_lo[4 * g + jj];
-                const float rs = lo + (r_hi[4 * g + jj] - lo) * cx.yl;
-                y[jj] = fmaf(rs, sc2[jj], y[jj]);
+            for (int jj = 0; jj < 4; jj += 2) {
+                const f32x2 h2 = {H[4 * g + jj], H[4 * g + jj + 1]};
+                const f32x2 lo = {r_lo[4 * g + jj], r_lo[4 * g + jj + 1]};
+                const f32x2 hi = {r_hi[4 * g + jj], r_hi[4 * g + jj + 1]};
+                const f32x2 y1 = pk_fma(h2, f32x2{sc1[jj], sc1[jj + 1]}, f32x2{sh1[jj], sh1[jj + 1]});
+                const f32x2 rs = pk_fma(pk_sub(hi, lo), ylv, lo);
+                y[jj / 2] = pk_fma(rs, f32x2{sc2[jj], sc2[jj + 1]}, y1);
             }
-            pk[g].x = pack2<DT>(y[0], y[1]);
-            pk[g].y = pack2<DT>(y[2], y[3]);
+            pk[g].x = pack2<DT>(y[0][0], y[0][1]);
+            pk[g].y = pack2<DT>(y[1][0], y[1][1]);
              }()),
              ...);
         }(std::make_integer_sequence<int, 4>{});

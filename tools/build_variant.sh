@@ -16,3 +16,4 @@ for f in rn_api rn_kernels_f32 rn_fused rn_imageops rn_group rn_tail rn_stage_rw
 done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC "${OBJS[@]}" -ldl -o "$ROOT/roomnet_amd/lib/libroomnet_hip_$NAME.so"
 echo "built libroomnet_hip_$NAME.so"
+"$ROOT/tools/spills.sh" "$OBJ/$FILE.o" | awk '$0 ~ /spills +[1-9]/ {print "  spills: " $0}' | cut -c1-70,95-200 || true
