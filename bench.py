@@ -186,6 +186,18 @@ class StubEngine:
         return [[i] for i in range(self.n_stages)]
 
 
+def _rendezvous(world):
+    """torch.distributed.run exports MASTER_ADDR / MASTER_PORT; a lone process (--force-collective without a launcher)
+    rendezvouses with itself on a free local port."""
+    if "MASTER_PORT" in os.environ:
+        return {}
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    return {"init_method": "tcp://127.0.0.1:%d" % port}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -201,6 +213,9 @@ def main():
     ap.add_argument("--stage-launches", action="store_true",
                     help="one launch per conv stage (RN_FLAG_STAGE_LAUNCHES): the unfused comparison arm")
     ap.add_argument("--stub-engine", action="store_true", help=argparse.SUPPRESS)    # CPU tensors + gloo (tests)
+    ap.add_argument("--force-collective", action="store_true",
+                    help="run the N > 1 code path (RCCL process group, per-step all-gather, barriers, gathered-block check) "
+                         "with however many ranks there are, also one: exercises it on a one-GPU box")
     ap.add_argument("--pcie", action="store_true",
                     help="also time the host-buffer entry point (rn_forward_u8: H2D copy + forward + D2H copy); reported as "
                          "path.pcie_inclusive_images_per_sec, never as `value`")
@@ -209,7 +224,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    multi = world > 1 or args.force_collective         # the distributed code path (normally: more than one rank)
+    if multi:
         # before anything initialises the HSA runtime: the host driver only supports dmabuf IPC
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -221,13 +237,13 @@ def main():
     stub = args.stub_engine
     if stub:
         dev = torch.device("cpu")
-        if world > 1:
-            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        if multi:
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world, **_rendezvous(world))
     else:
         torch.cuda.set_device(local_rank)
         dev = torch.device("cuda", local_rank)
-        if world > 1:
-            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
+        if multi:
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev, **_rendezvous(world))
 
     from roomnet_amd.graph import build_graph
     from roomnet_amd.synth import perf_batch
@@ -253,7 +269,7 @@ def main():
     # all-gather (32 bytes per image) instead of two latency-bound collectives
     from roomnet_amd.parallel import result_buffers, unpack_results
     combo, probs, ids = result_buffers(B, graph.num_classes, dev)
-    g_combo = torch.empty((world * combo.numel(),), dtype=torch.uint8, device=dev) if world > 1 else None
+    g_combo = torch.empty((world * combo.numel(),), dtype=torch.uint8, device=dev) if multi else None
 
     # ONE explicit stream for the library's kernels and the collective: torch's default stream is the null stream,
     # which the library's own (non-blocking) stream is not ordered against.
@@ -277,7 +293,7 @@ def main():
 
     def step():
         forward()
-        if world > 1:
+        if multi:
             dist.all_gather_into_tensor(g_combo, combo)
 
     def on_stream():
@@ -302,18 +318,22 @@ def main():
         for _ in range(args.warmup):
             step()
         sync()
-        if world > 1:
+        if multi:
             dist.barrier()
+            # librccl prints a version banner through C stdio when its first communicator comes up; on a pipe that
+            # sits in libc's buffer until exit and would land BEHIND the JSON line: push it out now
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
         sync()
         t0 = time.perf_counter()
         for _ in range(args.steps):
             step()
         sync()
-        if world > 1:
+        if multi:
             dist.barrier()
         sync()
         elapsed = time.perf_counter() - t0
-    if world > 1:
+    if multi:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -323,7 +343,7 @@ def main():
         p = probs.cpu().numpy()
         i = ids.cpu().numpy()
         assert np.allclose(p.sum(1), 1.0, atol=1e-4) and (p.argmax(1) == i).all()
-        if world > 1:
+        if multi:
             rows = g_combo.view(world, combo.numel())
             assert torch.equal(rows[rank], combo), "rank %d: its own block of the all-gather differs from its results" % rank
             for r in range(world):
@@ -399,7 +419,7 @@ def main():
                                    % (args.side, args.side, B,
                                       "float32 per-node correctness path (one launch per graph node; not a throughput path)" if f32
                                       else "%s storage / fp32 accumulate" % args.dtype,
-                                      ", RCCL all-gather of probs+ids" if world > 1 else ""),
+                                      ", RCCL all-gather of probs+ids" if multi else ""),
                        "images_per_gpu": B, "global_batch": world * B, "im_side": args.side,
                        "parallelism": "dp%d" % world},
             "parity": parity,
@@ -456,7 +476,7 @@ def main():
         print(json.dumps(out), flush=True)
     if not stub:
         eng.close()
-    if world > 1:
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -42,3 +42,28 @@ def test_bench_single_rank_stub_engine():
     assert r.returncode == 0, r.stderr[-2000:]
     d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
     assert d["n_gpus"] == 1 and d["config"]["global_batch"] == 3 and d["value"] > 0
+
+
+def test_bench_forced_collective_single_rank_gloo():
+    """--force-collective: the distributed code path with one rank and no launcher (self-rendezvous)."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--batch", "3",
+                        "--stub-engine", "--no-cpu-baseline", "--force-collective"], cwd=ROOT, capture_output=True, text=True,
+                       timeout=280)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert d["n_gpus"] == 1 and d["value"] > 0 and "all-gather" in d["config"]["workload"]
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(600)
+def test_bench_rccl_path_on_one_gpu():
+    """The N > 1 path on real hardware with the one GPU this pool's boxes have: RCCL process group of one rank, the
+    all-gather enqueued behind the head kernel on the library's stream every step, barriers, the gathered-block check,
+    and the parity gate in front of it all."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "20", "--warmup", "3", "--no-cpu-baseline",
+                        "--force-collective", "--profile-steps", "1", "--event-steps", "3"], cwd=ROOT, capture_output=True,
+                       text=True, timeout=580)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert d["n_gpus"] == 1 and d["parity"]["checked"] and "all-gather" in d["config"]["workload"]
+    assert d["value"] > 50000          # the collective must not serialise the pass (HBM-resident 150 k img/s without it)
