@@ -37,4 +37,5 @@ int rn_rw_launch(const RwPlan& p, int dtype, hipStream_t s, const rnk::StageArgs
 
 // ---- cross-stage fused pair: conv-pool-BN -> conv-pool-BN + residual of a depth-3 block (rn_stage23.hip)
 bool rn_stage23_supported(int in_side);
+bool rn_stage23_plan(int in_side, int* n_cblocks, int* x0, int* wo);   // column blocks (x0, wo: 4 entries)
 int rn_stage23_launch(int dtype, hipStream_t s, const rnk::Stage23Args& a, int n);

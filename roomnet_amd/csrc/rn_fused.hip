@@ -852,29 +852,34 @@ int rn_fused_forward(rn_handle* h, const uint8_t* d_bgr, const float* d_rgb, int
             fa.rscale = static_cast<float>(s2.skip_side) / static_cast<float>(s2.out_side);
             fa.W = s.in_side;
             fa.Wo = s2.out_side;
-            // whole rows per workgroup, one workgroup per CU: bands only to fill the chip / even out the rounds
-            // (a band costs its rows plus 11 steps of pipeline fill)
+            if (!rn_stage23_plan(s.in_side, &fa.n_cblocks, fa.cb_x0, fa.cb_wo)) {
+                rn_set_error("fused stage pair: no column-block plan for input side %d", s.in_side);
+                return RN_E_STATE;
+            }
+            // one workgroup per CU: workgroup = image x column block x band of rows; bands only to fill the chip / even
+            // out the rounds (a band costs its rows plus 11 steps of pipeline fill)
             const int n_cu = h->n_cu;
+            const long per_band = static_cast<long>(n) * fa.n_cblocks;
             int bands = 1;
             long best_cost = -1;
             const int max_bands = (s2.out_side + 7) / 8;
             for (int b = 1; b <= 8 && b <= max_bands; ++b) {
-                const long rounds = (static_cast<long>(n) * b + n_cu - 1) / n_cu;
+                const long rounds = (per_band * b + n_cu - 1) / n_cu;
                 const long cost = rounds * ((s2.out_side + b - 1) / b + 11);
                 if (best_cost < 0 || cost < best_cost) {
                     best_cost = cost;
                     bands = b;
                 }
             }
-            if (n * bands < n_cu) {
-                bands = (n_cu + n - 1) / n;
+            if (per_band * bands < n_cu) {
+                bands = static_cast<int>((n_cu + per_band - 1) / per_band);
                 if (bands > max_bands) bands = max_bands;
             }
             fa.rows_per_band = (s2.out_side + bands - 1) / bands;
             fa.n_bands = (s2.out_side + fa.rows_per_band - 1) / fa.rows_per_band;
 #ifdef RN_STAMPS
             static unsigned long long* stamp_host23 = nullptr;
-            const size_t nwaves23 = static_cast<size_t>(fa.n_bands) * n * 8;
+            const size_t nwaves23 = static_cast<size_t>(fa.n_bands) * fa.n_cblocks * n * 8;
             if (!stamp_host23) (void)hipHostMalloc(reinterpret_cast<void**>(&stamp_host23), 16u << 20, 0);
             std::memset(stamp_host23, 0, nwaves23 * 96);
             fa.stamp_buf = stamp_host23;

@@ -220,6 +220,10 @@ struct Stage23Args {
     float rscale;                 // float(W) / float(Wo), fp32 as TF computes it
     int W, Wo;                    // side of the input / of the output (= W - 10)
     int rows_per_band, n_bands;
+    // column blocks: a workgroup owns output columns [cb_x0[b], cb_x0[b] + cb_wo[b]) of its band and reads input
+    // columns cb_x0[b] .. cb_x0[b] + cb_wo[b] + 9 (whole rows when n_cblocks == 1: the 224 x 224 network)
+    int n_cblocks;
+    int cb_x0[4], cb_wo[4];
     unsigned long long* stamp_buf; // diagnostic build (-DRN_STAMPS) only: per-wave cycle sums
 };
 

@@ -8,12 +8,13 @@
 // re-reads recent rows, served by L2 / Infinity Cache), B's write and re-read disappear.  Stage-boundary model:
 // 14.25 MB per image for the two stages (bf16, 224 input); this kernel moves 5.65 MB.
 //
-// Geometry: a workgroup owns one image x one band of output rows and ALL columns (W <= 215: whole rows of A and B
-// fit the LDS rings: 4 x A row + 4 x B row + the skip rows = 155 KB).  Per step t one row of A arrives by LDS-DMA,
-// the first stage finishes B row t-5 for all eight 32-column tiles (written to the B ring with ds_write_b64), the
-// second stage finishes output row t-11 from the B rows of earlier steps.  One s_barrier per step.  The residual's
-// skip rows are fetched again (L2) into small wave-private rings: each second-stage wave stages only the 64 skip
-// columns its own two tiles interpolate from, so nothing but the A and B rings is shared between waves.
+// Geometry: a workgroup owns one image x one band of output rows x one column block.  W <= 215 (the 224 x 224 network):
+// the block is the whole row -- 4 x A row + 4 x B row + the skip rows = 155 KB of LDS.  Wider inputs are cut into column
+// blocks of 193..215 input columns (rn_stage23_plan; 600 x 600: three), each re-reading its 10 halo columns.  Per step t
+// one row of A arrives by LDS-DMA, the first stage finishes B row t-5 for all eight 32-column tiles (written to the B
+// ring with ds_write_b64), the second stage finishes output row t-11 from the B rows of earlier steps.  One s_barrier
+// per step.  The residual's skip rows are fetched again (L2) into small wave-private rings: each second-stage wave
+// stages only the 64 skip columns its own two tiles interpolate from, so nothing but the A and B rings is shared.
 //
 // The arithmetic of both stages is instruction-for-instruction that of stage_rw_kernel's POOLM variants
 // (rn_stage_rw.hip): results are bit-identical to the two-launch path
@@ -68,11 +69,11 @@ __device__ __forceinline__ unsigned long long stamp23() {
 // the second stage for two tiles each on the B rows of earlier steps.  Wave w and wave w + 4 share a SIMD, so every
 // SIMD hosts one producer and one consumer: while one of them is in a VALU-heavy epilogue the other one's MFMA chain
 // keeps the matrix pipe busy.  (Measured against a 4-wave form -- one wave per SIMD doing all four jobs with the
-// epilogue micro-ops placed between its own MFMAs, in the history: a single wave pays ~5 cycles per non-MFMA
-// instruction and hides none of them behind its own dependent MFMAs; 5800 cycles per step against 5200 here, where
-// the consumer's serial instruction stream is the critical path and the producer waits ~1500 cycles at the barrier:
-// profiles/r2_b_stamps.txt.)  The consumer runs at s_setprio 1 (it is the wave the step waits for); deferring the
-// epilogue of its second tile to the next step, to put its chains opposite the producer's epilogues, measured the same.
+// epilogue micro-ops placed between its own MFMAs, in the history: 5800 cycles per step against 5200 here.)  The
+// consumers run at s_setprio 1.  Work is balanced between the roles by letting the producer issue the partner
+// consumer's regular skip-row DMA (see the schedule below): barrier wait 130 (producer) / 520 (consumer) cycles per
+// step, profiles/r2_c_stamps.txt.  Both roles use 254 of 256 registers: check tools/spills.sh after ANY edit -- a
+// handful of spilled registers costs 25 % and hipcc says nothing.
 template <int DT>
 __global__ __launch_bounds__(512, 2) void stage23pc_kernel(const Stage23Args a) {
     constexpr int KC = 18, BAHEAD = 4;
@@ -82,10 +83,12 @@ __global__ __launch_bounds__(512, 2) void stage23pc_kernel(const Stage23Args a) 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wq = wave & 3;                             // tile pair of this wave
     const int r = lane & 31, hh = lane >> 5;
-    const int band = blockIdx.x, n = blockIdx.y;
-    const int W = a.W, Wb = W - 5, Wo = a.Wo;
+    const int cblk = blockIdx.x % a.n_cblocks, band = blockIdx.x / a.n_cblocks, n = blockIdx.y;
+    // block-local widths (what the rings hold) and the full sides (row pitches, vertical clamps, residual tables)
+    const int Win = a.W, Hout = a.Wo, x0 = a.cb_x0[cblk];
+    const int Wo = a.cb_wo[cblk], W = Wo + 10, Wb = W - 5;
     const int yo0 = band * a.rows_per_band;
-    const int nrows = min(Wo, yo0 + a.rows_per_band) - yo0;
+    const int nrows = min(Hout, yo0 + a.rows_per_band) - yo0;
     const int nsteps = nrows + F_LAG;
 
     float* const tab = reinterpret_cast<float*>(smem);
@@ -93,7 +96,8 @@ __global__ __launch_bounds__(512, 2) void stage23pc_kernel(const Stage23Args a) 
     char* const ringA = smem + F_RINGA_OFF;
     char* const ringB = smem + F_RINGB_OFF;
     const unsigned ringA_lds = lds_addr(ringA), ringB_lds = lds_addr(ringB);
-    const char* const in_img = reinterpret_cast<const char*>(a.in + static_cast<int64_t>(n) * W * W * 32);
+    const char* const in_img = reinterpret_cast<const char*>(a.in + static_cast<int64_t>(n) * Win * Win * 32);
+    const char* const in_blk = in_img + x0 * 64;          // first input column of this column block
     constexpr int OOB = 0x40000000;
 
     // band matrix of the pool MFMA (see rn_stage_rw.hip, POOLM)
@@ -165,18 +169,18 @@ __global__ __launch_bounds__(512, 2) void stage23pc_kernel(const Stage23Args a) 
     // more; it lands before the producer's end-of-step wait and the barrier publishes it).  When the lo row jumps by 2
     // (1 step in 20) a second new row is needed whose slot is still being read: the CONSUMER fetches that one itself at
     // the start of step t+1 and waits for it before its first epilogue.
-    const int xs0 = a.rlo[min(58 * wq, Wo - 1)];
+    const int xs0 = a.rlo[x0 + min(58 * wq, Wo - 1)];     // first skip column of this wave's tile pair (full-width index)
     unsigned sk_goff[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int q = lane + 64 * i;
         const int p = q >> 2, c = q & 3;
-        sk_goff[i] = static_cast<unsigned>(min(xs0 + p, W - 1) * 64 + ((c ^ swz4(p)) << 4));
+        sk_goff[i] = static_cast<unsigned>(min(xs0 + p, Win - 1) * 64 + ((c ^ swz4(p)) << 4));
     }
     char* const skw = smem + F_SKIP_OFF + wq * (F_NSK * F_SKROW);
     const unsigned skw_lds = lds_addr(skw);
     auto issue_skip_row = [&](int y, int slot) __attribute__((always_inline)) {
-        const char* row = in_img + static_cast<int64_t>(y) * static_cast<int64_t>(W * 64);
+        const char* row = in_img + static_cast<int64_t>(y) * static_cast<int64_t>(Win * 64);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             unsigned off = sk_goff[i];
@@ -237,7 +241,7 @@ __global__ __launch_bounds__(512, 2) void stage23pc_kernel(const Stage23Args a) 
                 }
             }
         };
-        const char* a_next = in_img + static_cast<int64_t>(yo0) * (W * 64);
+        const char* a_next = in_blk + static_cast<int64_t>(yo0) * (Win * 64);
         unsigned baseA[2][3][2], wbB[2];
 #pragma unroll
         for (int T = 0; T < 2; ++T) {
@@ -281,16 +285,16 @@ __global__ __launch_bounds__(512, 2) void stage23pc_kernel(const Stage23Args a) 
 #endif
         auto step = [&](auto PC, int t) __attribute__((always_inline)) {
             constexpr int P = decltype(PC)::value;
-            if (t < nrows + 9) a_next += W * 64;
+            if (t < nrows + 9) a_next += Win * 64;
             issue_A_pieces(IC<0>{}, IC<4>{}, a_next, (P + 1) % F_NA);            // A row t+1
             {
                 // skip rows of the partner consumer (see the schedule above)
-                const int need_cur = min(ylo_step(t) + 1, W - 1);
+                const int need_cur = min(ylo_step(t) + 1, Win - 1);
                 if (sk_f < need_cur) {                      // the consumer fetches this one itself (lo row jumped by 2)
                     ++sk_f;
                     sk_slot = sk_slot == F_NSK - 1 ? 0 : sk_slot + 1;
                 }
-                const int need_next = min(ylo_step(t + 1) + 1, W - 1);
+                const int need_next = min(ylo_step(t + 1) + 1, Win - 1);
                 if (sk_f < need_next) {
                     ++sk_f;
                     sk_slot = sk_slot == F_NSK - 1 ? 0 : sk_slot + 1;
@@ -382,10 +386,10 @@ __global__ __launch_bounds__(512, 2) void stage23pc_kernel(const Stage23Args a) 
                 baseB[T][kx][cc] = ringB_lds + static_cast<unsigned>(cb * 64 + (((cc * 2 + hh) ^ swz4(cb)) << 4));
             }
         const int xo = x_t + r;
-        voff[T] = (r < 29 && xo < Wo) ? (xo * 32 + 8 * hh) * 2 : OOB;
-        const int xo_t0 = min(x_t, Wo - 1);
+        voff[T] = (r < 29 && xo < Wo) ? ((x0 + xo) * 32 + 8 * hh) * 2 : OOB;
+        const int xo_t0 = x0 + min(x_t, Wo - 1);
         const int xs_t = a.rlo[xo_t0] - xs0;
-        const int xq = min(xo, Wo - 1);
+        const int xq = x0 + min(xo, Wo - 1);
         const int plo = a.rlo[xq] - xs0, phi = a.rhi[xq] - xs0;
         const float xlq = res_quant_lerp<DT>(a.rlerp[xq]);
 #pragma unroll
@@ -412,8 +416,8 @@ __global__ __launch_bounds__(512, 2) void stage23pc_kernel(const Stage23Args a) 
         }
     }
     asm volatile("" : "+a"(bw[0][0]), "+a"(bw[0][1]), "+a"(bw[1][0]), "+a"(bw[1][1]));
-    const int out_row_bytes = Wo * 64;
-    const char* out_row = reinterpret_cast<const char*>(a.out + static_cast<int64_t>(n) * Wo * Wo * 32) + static_cast<int64_t>(yo0) * out_row_bytes;
+    const int out_row_bytes = Hout * 64;
+    const char* out_row = reinterpret_cast<const char*>(a.out + static_cast<int64_t>(n) * Hout * Hout * 32) + static_cast<int64_t>(yo0) * out_row_bytes;
     i32x4 hp[2][2], q0[2][2], q1[2][2];
 #pragma unroll
     for (int T = 0; T < 2; ++T) hp[T][0] = hp[T][1] = q0[T][0] = q0[T][1] = q1[T][0] = q1[T][1] = i32x4{0, 0, 0, 0};
@@ -527,7 +531,7 @@ __global__ __launch_bounds__(512, 2) void stage23pc_kernel(const Stage23Args a) 
         const int jo = t - F_LAG;
         cx_cur.yl = vl_cur.yl;
         cx_cur.sk_lo = static_cast<unsigned>(slot_cur * F_SKROW);
-        cx_cur.sk_hi = static_cast<unsigned>((vl_cur.ylo + 1 > W - 1 ? slot_cur : (slot_cur == F_NSK - 1 ? 0 : slot_cur + 1)) * F_SKROW);
+        cx_cur.sk_hi = static_cast<unsigned>((vl_cur.ylo + 1 > Win - 1 ? slot_cur : (slot_cur == F_NSK - 1 ? 0 : slot_cur + 1)) * F_SKROW);
         cx_cur.rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(out_row), 0, out_row_bytes, 0x00020000);
         cx_cur.emit_mask = jo >= 0 ? 0 : OOB;
         if (jo >= 0 && jo < nrows - 1) out_row += out_row_bytes;
@@ -538,13 +542,13 @@ __global__ __launch_bounds__(512, 2) void stage23pc_kernel(const Stage23Args a) 
         // next step is fetched by the partner producer during this step (mirrored in sk_f / sk_slot)
         const VLerp vl_next = vlerp_of(yo0 + min(max(jo + 1, 0), nrows - 1));
         {
-            const int need_cur = min(vl_cur.ylo + 1, W - 1);
+            const int need_cur = min(vl_cur.ylo + 1, Win - 1);
             if (sk_f < need_cur) {
                 ++sk_f;
                 sk_slot = sk_slot == F_NSK - 1 ? 0 : sk_slot + 1;
                 issue_skip_row(sk_f, sk_slot);
             }
-            const int need_next = min(vl_next.ylo + 1, W - 1);
+            const int need_next = min(vl_next.ylo + 1, Win - 1);
             if (sk_f < need_next) {
                 ++sk_f;
                 sk_slot = sk_slot == F_NSK - 1 ? 0 : sk_slot + 1;
@@ -620,7 +624,27 @@ __global__ __launch_bounds__(512, 2) void stage23pc_kernel(const Stage23Args a) 
 
 }  // namespace
 
-bool rn_stage23_supported(int in_side) { return in_side >= F_WMIN && in_side <= F_WMAX; }
+// Column blocks of the output side (= in_side - 10): as few as fit the rings, of equal width +-1.  Every block's input
+// width (its output width + 10) must lie in [F_WMIN, F_WMAX].  224 x 224: one block of 205; 600 x 600: 194 + 194 + 193.
+bool rn_stage23_plan(int in_side, int* n_cblocks, int* x0, int* wo) {
+    const int out = in_side - 10;
+    if (out < F_WMIN - 10) return false;
+    const int nb = (out + (F_WMAX - 10) - 1) / (F_WMAX - 10);
+    if (nb > 4) return false;
+    const int base = out / nb, rem = out % nb;
+    if (base + 10 < F_WMIN) return false;
+    int x = 0;
+    for (int b = 0; b < nb; ++b) {
+        const int w = base + (b < rem ? 1 : 0);
+        if (x0) x0[b] = x;
+        if (wo) wo[b] = w;
+        x += w;
+    }
+    if (n_cblocks) *n_cblocks = nb;
+    return true;
+}
+
+bool rn_stage23_supported(int in_side) { return rn_stage23_plan(in_side, nullptr, nullptr, nullptr); }
 
 int rn_stage23_launch(int dtype, hipStream_t s, const Stage23Args& a, int n) {
     auto launch = [&](auto kern) -> int {
@@ -631,7 +655,7 @@ int rn_stage23_launch(int dtype, hipStream_t s, const Stage23Args& a, int n) {
             RN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             attr_devices.fetch_or(1ull << (dev & 63), std::memory_order_release);
         }
-        hipLaunchKernelGGL(kern, dim3(a.n_bands, n), dim3(512), F_LDS, s, a);
+        hipLaunchKernelGGL(kern, dim3(a.n_bands * a.n_cblocks, n), dim3(512), F_LDS, s, a);
         RN_CHECK_LAUNCH();
         return RN_OK;
     };
