@@ -374,6 +374,34 @@ def test_cross_stage_fusion_at_600_is_bit_identical_to_stage_launches(weights, n
             plain.close()
 
 
+@pytest.mark.parametrize("side,blocks", [(202, 1), (211, 1), (409, 2), (634, 3), (439, 0), (190, 0)])
+def test_cross_stage_fusion_geometry_sweep(weights, side, blocks):
+    """Edges of the fused kernel's column-block plan: the narrowest supported row (stage-2 input 193 + 1: a one-lane tail
+    DMA piece), an odd width, two equal blocks, three blocks of the maximum width 215 (615 output columns), and sides with
+    no plan (0 blocks: two launches).  Fused results must be the stage launches' bit for bit."""
+    from oracle import roomnet_ref as R
+    from roomnet_amd.synth import parity_batch
+    g = build_graph(6, side)
+    w = dict(weights)
+    w["dense/kernel"] = R.synth_dense_kernel_600(g.flat_len)
+    ims = parity_batch(side, seed=1)[[31, 20]]
+    fused = _capi.Engine(g, w, device=0, dtype="bf16", max_batch=2)
+    plain = _capi.Engine(g, w, device=0, dtype="bf16", max_batch=2, stage_launches=True)
+    try:
+        groups = [list(x) for x in fused.launch_groups()]
+        assert ([2, 3] in groups) == (blocks > 0), (side, g.stages[2].in_side, groups)
+        ids_f, probs_f = fused.forward_u8(ims)
+        ids_p, probs_p = plain.forward_u8(ims)
+        a, b = fused.tap("s3.bn2", 2), plain.tap("s3.bn2", 2)
+        bad = np.argwhere(a != b)
+        assert bad.size == 0, (side, len(bad), bad[:8].tolist(), float(np.abs(a - b).max()))
+        np.testing.assert_array_equal(probs_f, probs_p)
+        np.testing.assert_array_equal(ids_f, ids_p)
+    finally:
+        fused.close()
+        plain.close()
+
+
 def test_cross_stage_fusion_two_unequal_column_blocks_at_420(weights):
     """im_side 420: the stage-2 input is 411 wide -> two column blocks of 201 and 200 output columns.  Fused vs stage
     launches bit for bit, and the block output against the C oracle for one image.  (im_side 300 has no block plan --
