@@ -871,7 +871,7 @@ __global__ __launch_bounds__(64 * NPT * ((COUT + 31) / 32) * KS, 1) void stage_r
             } else if constexpr (k >= M_BN && k < M_BN + 2 * NG) {
                 if constexpr (emit_phase) {
                     constexpr int g = (k - M_BN) / 2, h2 = (k - M_BN) % 2;    // channel group, half (channels 2 h2, 2 h2 + 1)
-                    f32x4 sc1, sh1, sc2, sh2;
+                    [[maybe_unused]] f32x4 sc1, sh1, sc2, sh2;
                     if constexpr (C::PTAB_REGS) {
                         sc1 = sc1r[g];
                         sh1 = sh1r[g];
