@@ -960,27 +960,29 @@ int rn_fused_forward(rn_handle* h, const uint8_t* d_bgr, const float* d_rgb, int
             a.n_colblocks = f.rw.n_colblocks;
             a.npt = f.rw.npt;
             a.n_ctg = 1;
-            // one 8-wave workgroup per CU is resident: size the grid to whole rounds of the chip
-            // (every rw variant keeps exactly one workgroup per CU resident -- checked with HW_ID stamps).  A band
-            // costs its rows plus ~10 rows of prologue / pool warm-up; pick the band count whose whole rounds of
-            // the chip give the least time: 1 band at batch 256 x 224^2, 2 when e.g. 64 x 600^2 images x 6 column
-            // blocks = 384 workgroups would otherwise run 1.5 rounds.
+            // Workgroups per CU: one (8-wave variants; checked with HW_ID stamps) or four (the 2-wave workgroups of the
+            // 32->64 stage).  A band costs its rows plus ~10 rows of prologue / pool warm-up; pick the band count that
+            // gives the least time.  One workgroup per CU runs in whole rounds of the chip: 1 band at batch 256 x 224^2,
+            // 2 when e.g. 64 x 600^2 images x 6 column blocks = 384 workgroups would otherwise run 1.5 rounds.  Small
+            // workgroups are back-filled as slots free up, so their cost is the fractional number of rounds (>= 1).
             const int per_band = n * f.rw.n_colblocks;
-            const int n_cu = h->n_cu;
+            const long slots = static_cast<long>(h->n_cu) * f.rw.wgs_per_cu;
             const int max_bands = (s.out_side + 7) / 8;
             int bands = 1;
-            long best_cost = -1;
+            double best_cost = -1;
             for (int b = 1; b <= 8 && b <= max_bands; ++b) {
-                const long rounds = (static_cast<long>(per_band) * b + n_cu - 1) / n_cu;
+                const long wgs = static_cast<long>(per_band) * b;
+                const double rounds = f.rw.wgs_per_cu == 1 ? static_cast<double>((wgs + slots - 1) / slots)
+                                                           : std::max(1.0, static_cast<double>(wgs) / static_cast<double>(slots));
                 const long rows = (s.out_side + b - 1) / b * (s.pool_k ? s.pool_s : 1) + 10;
-                const long cost = rounds * rows;
+                const double cost = rounds * static_cast<double>(rows);
                 if (best_cost < 0 || cost < best_cost) {
                     best_cost = cost;
                     bands = b;
                 }
             }
-            if (per_band * bands < n_cu) {      // small batches: fill the chip first
-                bands = (n_cu + per_band - 1) / per_band;
+            if (static_cast<long>(per_band) * bands < slots) {      // small batches: fill the chip first
+                bands = static_cast<int>((slots + per_band - 1) / per_band);
                 if (bands > max_bands) bands = max_bands;
             }
             a.rows_per_band = (s.out_side + bands - 1) / bands;

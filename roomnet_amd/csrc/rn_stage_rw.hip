@@ -42,8 +42,14 @@ namespace {
 //            tile from two row-local DPP shifts (row_shl:1, row_shl:2) on the vertically summed row.
 //            (Measured on the same box: the MFMA pool is 5 % faster than DPP for the stride-1 residual stage,
 //             7 % slower for the stride-2 stages, which pool only every other row.)
-constexpr int rw_tile_nout(int pk, int ps) { return pk ? (ps == 2 ? 14 : 32 - pk + 1) : 32; }
-constexpr int rw_tile_stride(int pk, int ps) { return pk ? rw_tile_nout(pk, ps) * ps : 32; }
+//  pool 4/2, "wide" (the 32->64 stage, one pixel tile per workgroup): plain lane -> column map, 15 windows per tile
+//            (even columns 0..28); the horizontal sums cross the 16-lane DPP rows, so they use wave shifts
+//            (wave_shl:1, three DPP operations per value instead of two).  203 conv columns = 7 tiles instead of 8.
+constexpr int rw_tile_nout(int pk, int ps, bool wide = false) { return pk ? (ps == 2 ? (wide ? 15 : 14) : 32 - pk + 1) : 32; }
+constexpr int rw_tile_stride(int pk, int ps, bool wide = false) { return pk ? rw_tile_nout(pk, ps, wide) * ps : 32; }
+constexpr bool rw_wide2(int cin, int cout, int pk, int ps, bool res, int npt, int ks) {
+    return cin == 32 && cout == 64 && pk == 4 && ps == 2 && !res && npt == 1 && ks == 1;
+}
 
 #ifndef RN_SPREAD_DMA
 #define RN_SPREAD_DMA 1
@@ -67,8 +73,9 @@ struct RwCfg {
     static constexpr int CT = (COUT + 31) / 32;
     static constexpr int NG = COUT >= 32 ? 4 : COUT / 8;   // 4-channel groups per lane half-row
     static constexpr int CPO = COUT / 8;                       // 16-byte chunks per output/skip pixel
-    static constexpr int TSTRIDE = rw_tile_stride(PK, PS);
-    static constexpr int NOUT_T = rw_tile_nout(PK, PS);
+    static constexpr bool WIDE2 = rw_wide2(CIN, COUT, PK, PS, RES, NPT, KS);
+    static constexpr int TSTRIDE = rw_tile_stride(PK, PS, WIDE2);
+    static constexpr int NOUT_T = rw_tile_nout(PK, PS, WIDE2);
     // POOLM: the 4-wide horizontal window sums run on the matrix cores.  The conv MFMA is issued with its
     // operands swapped (D'[pixel][cout]: pixel rows in the accumulator registers, one cout per lane), so a
     // lane's ReLU6'd values, rounded to fp16 pairs, ARE an A-operand fragment V[cout][x] of a second MFMA
@@ -78,7 +85,8 @@ struct RwCfg {
     // rounding, so a pooled row costs 4 MFMAs (2 pair-sum rows x K = 32) instead of 48 DPP instructions.
     static constexpr bool POOLM = PK == 4 && PS == 1;
     static constexpr bool RES_SPLIT = !POOLM;                  // residual interpolation weights as hi + lo 16-bit operands
-    static constexpr bool GAP = PK == 4 && PS == 2;            // gapped lane -> column map, DPP pooling (see rw_tile_nout)
+    static constexpr bool GAP = PK == 4 && PS == 2 && !WIDE2;  // gapped lane -> column map, DPP pooling (see rw_tile_nout)
+    static constexpr bool DPP2 = PK == 4 && PS == 2;           // stride-2 pooling by DPP (gapped or wide)
     // KS = 3: the K dimension is split by kernel row over three waves per pixel tile (each keeps one
     // kernel row's weight fragments in registers); partial accumulators meet in LDS (K = 1152 stage)
     static constexpr int NTHREADS = 64 * NPT * CT * KS;
@@ -438,8 +446,9 @@ __global__ __launch_bounds__(64 * NPT * ((COUT + 31) / 32) * KS, 1) void stage_r
     }
     // output column of this lane: MFMA-pooled tiles deliver window i of the tile on lane i (see POOLM), gapped
     // tiles the window that starts at the lane's own conv column
-    const int xo = C::GAP ? (x0c + pt * TSTRIDE + pm) / PS : (PK ? (x0c + pt * TSTRIDE) / PS : x0c + pt * TSTRIDE) + r;
-    const bool lane_win = C::GAP ? ((r & 1) == 0 && (r & 15) <= 12) : r < NOUT_T;   // a window of the tile ends up here
+    const int xo = C::DPP2 ? (x0c + pt * TSTRIDE + pm) / PS : (PK ? (x0c + pt * TSTRIDE) / PS : x0c + pt * TSTRIDE) + r;
+    // a window of the tile ends up on this lane (gapped / wide tiles: the window that starts at the lane's own, even, column)
+    const bool lane_win = C::GAP ? ((r & 1) == 0 && (r & 15) <= 12) : (C::WIDE2 ? ((r & 1) == 0 && r <= 28) : r < NOUT_T);
     const bool lane_out = lane_win && xo < a.Wo && (xo - xo_blk0) < NPT * NOUT_T;
     const float* const ptab_lane = ptab + ct * 32 + 4 * hh;                                // + 8*g (+ table*COUT)
     f32x4 sc1r[NG], sh1r[NG], sc2r[NG], sh2r[NG];
@@ -811,14 +820,14 @@ __global__ __launch_bounds__(64 * NPT * ((COUT + 31) / 32) * KS, 1) void stage_r
         const bool epi_wave = KS == 1 || ks == 0;        // K split: only the wave of kernel row 0 owns the epilogue
         // explicit placement where the epilogue has MFMAs of its own; the plain VALU epilogue of the stride-2
         // non-residual stage does better under hipcc's own interleave (sched_group_barrier hints): 0.375 vs 0.39 ms
-        constexpr bool SLICED = KS == 1 && !(C::GAP && !RES);
+        constexpr bool SLICED = KS == 1 && !(C::DPP2 && !RES);
         auto mop = [&](auto KK) __attribute__((always_inline)) {
             constexpr int k = decltype(KK)::value;
             if constexpr (k == M_RES_RD) {
                 if constexpr (KS > 1) part_add((P + 1) & 1, acc_old);
                 if constexpr (RESW) res_issue(sbuf_read, tq);
             } else if constexpr (k >= M_FRONT && k < M_FRONT + NF) {
-                if constexpr (C::GAP) {
+                if constexpr (C::DPP2) {
                     // stride 2, DPP variant: windows start at even conv rows and end at odd rows j = 2e + 3; the odd
                     // rows sum vertically first, then run the horizontal half on the 4-row sums
                     constexpr int i2 = 2 * (k - M_FRONT);
@@ -831,9 +840,9 @@ __global__ __launch_bounds__(64 * NPT * ((COUT + 31) / 32) * KS, 1) void stage_r
                             q0f[i2 + jj] = pq;
                         }
 #pragma unroll
-                        for (int jj = 0; jj < 2; ++jj) u[jj] = t[jj] + row_next<1>(t[jj]);
+                        for (int jj = 0; jj < 2; ++jj) u[jj] = t[jj] + (C::WIDE2 ? lane_next(t[jj]) : row_next<1>(t[jj]));
 #pragma unroll
-                        for (int jj = 0; jj < 2; ++jj) H[i2 + jj] = u[jj] + row_next<2>(u[jj]);
+                        for (int jj = 0; jj < 2; ++jj) H[i2 + jj] = u[jj] + (C::WIDE2 ? lane_next(lane_next(u[jj])) : row_next<2>(u[jj]));
                     } else {
 #pragma unroll
                         for (int i = i2; i < i2 + 2; ++i) hprev[i] = relu6f(acc_old[i]);
@@ -1127,20 +1136,25 @@ bool rn_rw_supported(int cin, int cout, int pool_k, int pool_s, bool res, int ou
     if (pool_k == 4 && pool_s != 1 && pool_s != 2) return false;
     const int ps = pool_k ? pool_s : 1;
     int variant = -1, npt = 0;
-    const int nout_t = rw_tile_nout(pool_k, ps), tstride = rw_tile_stride(pool_k, ps);
+    const bool wide = rw_wide2(cin, cout, pool_k, ps, res, 1, 1);
+    const int nout_t = rw_tile_nout(pool_k, ps, wide), tstride = rw_tile_stride(pool_k, ps, wide);
     const int tiles = (out_side + nout_t - 1) / nout_t;
     // waves per workgroup = npt x cout tiles: 8 waves (two per SIMD, <= 256 registers) where the
     // weights are small, 4 or 2 waves (one per SIMD, whole register file) for K >= 576 / residual
     if (cin == 8 && cout == 32 && pool_k == 4 && ps == 1 && !res) variant = 0, npt = tiles > 4 ? 8 : 4;
     if (cin == 32 && cout == 32 && pool_k == 4 && ps == 1 && !res) variant = 1, npt = tiles > 4 ? 8 : 4;
     if (cin == 32 && cout == 32 && pool_k == 4 && ps == 1 && res) variant = 2, npt = 4;
-    if (cin == 32 && cout == 64 && pool_k == 4 && ps == 2 && !res) variant = 3, npt = 4;
+    // 32->64: one "wide" pixel tile x two cout tiles per workgroup (2 waves; four workgroups per CU): 203 conv columns
+    // are 7 wide tiles instead of 8 gapped ones -- measured 0.375 -> 0.360 ms at batch 256 (the 4-tile workgroups of
+    // gapped tiles measured the same as 1- and 2-tile ones, so the decomposition itself is free)
+    if (cin == 32 && cout == 64 && pool_k == 4 && ps == 2 && !res) variant = 3, npt = 1;
     if (cin == 64 && cout == 64 && pool_k == 4 && ps == 2 && res) variant = 4, npt = 2;
     if (cin == 64 && cout == 128 && pool_k == 0 && !res) variant = 5, npt = 1;
     if (cin == 128 && cout == 16 && pool_k == 4 && ps == 2 && !res) variant = 6, npt = 2;   // K split over 3 waves
     if (variant < 0) return false;
     plan->variant = variant;
     plan->npt = npt;
+    plan->wgs_per_cu = variant == 3 ? 4 : 1;        // 2-wave workgroups at <= 256 registers, 25 KB of LDS each
     plan->n_colblocks = (tiles + npt - 1) / npt;
     const int ringcols = (npt - 1) * tstride + 34;
     plan->skipcols = 0;
@@ -1177,7 +1191,7 @@ int rn_rw_launch(const RwPlan& p, int dtype, hipStream_t s, const StageArgs& a, 
         case 1 * 16 + 4: return launch_rw_dt<32, 32, 4, 1, false, 4>(dtype, s, a, grid);
         case 1 * 16 + 8: return launch_rw_dt<32, 32, 4, 1, false, 8>(dtype, s, a, grid);
         case 2 * 16 + 4: return launch_rw_dt<32, 32, 4, 1, true, 4>(dtype, s, a, grid);
-        case 3 * 16 + 4: return launch_rw_dt<32, 64, 4, 2, false, 4>(dtype, s, a, grid);
+        case 3 * 16 + 1: return launch_rw_dt<32, 64, 4, 2, false, 1>(dtype, s, a, grid);
         case 4 * 16 + 2: return launch_rw_dt<64, 64, 4, 2, true, 2>(dtype, s, a, grid);
         case 5 * 16 + 1: return launch_rw_dt<64, 128, 0, 1, false, 1>(dtype, s, a, grid);
         case 6 * 16 + 2: return launch_rw_dt<128, 16, 4, 2, false, 2, 3>(dtype, s, a, grid);
