@@ -205,6 +205,12 @@ __global__ __launch_bounds__(64 * NPT * ((COUT + 31) / 32) * KS, 1) void stage_r
 
     // ---- folded BN tables -> LDS
     for (int i = tid; i < 4 * COUT; i += NTHREADS) ptab[i] = a.ptab[i];
+    // Private-ring variants: a wave whose whole tile lies right of the image has nothing to do and shares nothing with
+    // the others (no barrier in their row loop; a finished wave is not waited for by the one barrier of the prologue):
+    // it leaves after its share of the table copy.  (600 x 600: 21 tiles in 3 blocks of 8 -- three such waves.)
+    if constexpr (C::PRIV) {
+        if ((PK ? (x0c + pt * TSTRIDE) / PS : x0c + pt * TSTRIDE) >= a.Wo) return;
+    }
 
     // ---- this wave's weight fragments -> registers (lane-linear, coalesced)
     i32x4 wreg[KCW];
