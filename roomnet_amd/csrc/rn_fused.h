@@ -30,6 +30,7 @@ struct RwPlan {
     int n_colblocks = 0;
     int skipcols = 0;
     size_t lds_bytes = 0;
+    bool wide = false;       // stride-2 pooling on wide tiles (15 windows per tile) instead of gapped ones (14)
     int wgs_per_cu = 1;      // workgroups of this variant resident on one CU (register / LDS budget of the instantiation)
 };
 bool rn_rw_supported(int cin, int cout, int pool_k, int pool_s, bool res, int out_side, int skip_side,

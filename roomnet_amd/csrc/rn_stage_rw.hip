@@ -47,16 +47,12 @@ namespace {
 //            (wave_shl:1, three DPP operations per value instead of two).  203 conv columns = 7 tiles instead of 8.
 constexpr int rw_tile_nout(int pk, int ps, bool wide = false) { return pk ? (ps == 2 ? (wide ? 15 : 14) : 32 - pk + 1) : 32; }
 constexpr int rw_tile_stride(int pk, int ps, bool wide = false) { return pk ? rw_tile_nout(pk, ps, wide) * ps : 32; }
-constexpr bool rw_wide2(int cin, int cout, int pk, int ps, bool res, int npt, int ks) {
-    return cin == 32 && cout == 64 && pk == 4 && ps == 2 && !res && npt == 1 && ks == 1;
-}
-
 #ifndef RN_SPREAD_DMA
 #define RN_SPREAD_DMA 1
 #endif
 constexpr int RW_SKIPBUF = 3;   // staged skip-row pairs (residual): 1 being read + 2 in flight
 
-template <int DT, int CIN, int COUT, int PK, int PS, bool RES, int NPT, int KS = 1, bool S0F_ = false>
+template <int DT, int CIN, int COUT, int PK, int PS, bool RES, int NPT, int KS = 1, bool S0F_ = false, bool WIDE_ = false>
 struct RwCfg {
     // S0F: stage 0 (uint8 image -> conv 3->8 -> ReLU6 -> pool 3/1 -> BN) is computed by the SAME wave, row by row,
     // straight into its private ring: the 8-channel tensor between stages 0 and 1 never reaches HBM (see s0_feed)
@@ -73,7 +69,8 @@ struct RwCfg {
     static constexpr int CT = (COUT + 31) / 32;
     static constexpr int NG = COUT >= 32 ? 4 : COUT / 8;   // 4-channel groups per lane half-row
     static constexpr int CPO = COUT / 8;                       // 16-byte chunks per output/skip pixel
-    static constexpr bool WIDE2 = rw_wide2(CIN, COUT, PK, PS, RES, NPT, KS);
+    static constexpr bool WIDE2 = WIDE_;                       // wide stride-2 tiles (see rw_tile_nout)
+    static_assert(!WIDE_ || (PK == 4 && PS == 2 && KS == 1), "wide tiles: the stride-2 DPP pooling variants");
     static constexpr int TSTRIDE = rw_tile_stride(PK, PS, WIDE2);
     static constexpr int NOUT_T = rw_tile_nout(PK, PS, WIDE2);
     // POOLM: the 4-wide horizontal window sums run on the matrix cores.  The conv MFMA is issued with its
@@ -164,9 +161,9 @@ __device__ __forceinline__ unsigned long long stamp() {
 }
 #endif
 
-template <int DT, int CIN, int COUT, int PK, int PS, bool RES, int NPT, int KS, bool S0F>
+template <int DT, int CIN, int COUT, int PK, int PS, bool RES, int NPT, int KS, bool S0F, bool WIDE>
 __global__ __launch_bounds__(64 * NPT * ((COUT + 31) / 32) * KS, 1) void stage_rw_kernel(const StageArgs a) {
-    using C = RwCfg<DT, CIN, COUT, PK, PS, RES, NPT, KS, S0F>;
+    using C = RwCfg<DT, CIN, COUT, PK, PS, RES, NPT, KS, S0F, WIDE>;
     constexpr int CP = C::CP, KC = C::KC, CT = C::CT, CPO = C::CPO, TSTRIDE = C::TSTRIDE, NOUT_T = C::NOUT_T;
     constexpr int RINGCOLS = C::RINGCOLS, ROWB = C::ROWB, NTHREADS = C::NTHREADS, LPT = C::LPT, SLPT = C::SLPT;
     constexpr int PIXB = CIN * 2, NG = C::NG;
@@ -1097,10 +1094,10 @@ __global__ __launch_bounds__(64 * NPT * ((COUT + 31) / 32) * KS, 1) void stage_r
 #endif
 }
 
-template <int DT, int CIN, int COUT, int PK, int PS, bool RES, int NPT, int KS = 1, bool S0F = false>
+template <int DT, int CIN, int COUT, int PK, int PS, bool RES, int NPT, int KS = 1, bool S0F = false, bool WIDE = false>
 int launch_rw(hipStream_t s, const StageArgs& a, dim3 grid) {
-    using C = RwCfg<DT, CIN, COUT, PK, PS, RES, NPT, KS, S0F>;
-    auto kern = stage_rw_kernel<DT, CIN, COUT, PK, PS, RES, NPT, KS, S0F>;
+    using C = RwCfg<DT, CIN, COUT, PK, PS, RES, NPT, KS, S0F, WIDE>;
+    auto kern = stage_rw_kernel<DT, CIN, COUT, PK, PS, RES, NPT, KS, S0F, WIDE>;
     // the attribute is per device: remember which devices of this process have it (one handle per GPU per process
     // is the normal deployment, several handles on several GPUs / threads in one process must work too)
     static std::atomic<unsigned long long> attr_devices{0};
@@ -1126,23 +1123,22 @@ int launch_rw(hipStream_t s, const StageArgs& a, dim3 grid) {
     return RN_OK;
 }
 
-template <int CIN, int COUT, int PK, int PS, bool RES, int NPT, int KS = 1, bool S0F = false>
+template <int CIN, int COUT, int PK, int PS, bool RES, int NPT, int KS = 1, bool S0F = false, bool WIDE = false>
 int launch_rw_dt(int dtype, hipStream_t s, const StageArgs& a, dim3 grid) {
-    if (dtype == RN_DTYPE_BF16) return launch_rw<RN_DTYPE_BF16, CIN, COUT, PK, PS, RES, NPT, KS, S0F>(s, a, grid);
-    return launch_rw<RN_DTYPE_F16, CIN, COUT, PK, PS, RES, NPT, KS, S0F>(s, a, grid);
+    if (dtype == RN_DTYPE_BF16) return launch_rw<RN_DTYPE_BF16, CIN, COUT, PK, PS, RES, NPT, KS, S0F, WIDE>(s, a, grid);
+    return launch_rw<RN_DTYPE_F16, CIN, COUT, PK, PS, RES, NPT, KS, S0F, WIDE>(s, a, grid);
 }
 
 }  // namespace
 
 // Geometry query for the rw kernels.  Returns false when no rw variant covers the stage, so
 // the caller can use the generic kernel.
-bool rn_rw_supported(int cin, int cout, int pool_k, int pool_s, bool res, int out_side, int skip_side,
-                     RwPlan* plan) {
+static bool rw_plan(int cin, int cout, int pool_k, int pool_s, bool res, int out_side, int skip_side, bool wide,
+                    RwPlan* plan) {
     if (pool_k != 4 && pool_k != 0) return false;
     if (pool_k == 4 && pool_s != 1 && pool_s != 2) return false;
     const int ps = pool_k ? pool_s : 1;
     int variant = -1, npt = 0;
-    const bool wide = rw_wide2(cin, cout, pool_k, ps, res, 1, 1);
     const int nout_t = rw_tile_nout(pool_k, ps, wide), tstride = rw_tile_stride(pool_k, ps, wide);
     const int tiles = (out_side + nout_t - 1) / nout_t;
     // waves per workgroup = npt x cout tiles: 8 waves (two per SIMD, <= 256 registers) where the
@@ -1160,6 +1156,7 @@ bool rn_rw_supported(int cin, int cout, int pool_k, int pool_s, bool res, int ou
     if (variant < 0) return false;
     plan->variant = variant;
     plan->npt = npt;
+    plan->wide = wide;
     plan->wgs_per_cu = variant == 3 ? 4 : 1;        // 2-wave workgroups at <= 256 registers, 25 KB of LDS each
     plan->n_colblocks = (tiles + npt - 1) / npt;
     const int ringcols = (npt - 1) * tstride + 34;
@@ -1186,6 +1183,24 @@ bool rn_rw_supported(int cin, int cout, int pool_k, int pool_s, bool res, int ou
     return true;
 }
 
+// Geometry query for the rw kernels (see above).  Stride-2 pooling stages can use gapped (14 windows) or wide (15 windows
+// per tile, one DPP operation more per value) tiles: the 32->64 stage always runs wide, the 64->64 residual stage where
+// that saves a column block and the residual's K = 32 window still covers a tile (600 x 600: 142 output columns = 11
+// gapped tiles = 6 blocks of 2, or 10 wide tiles = 5 blocks; 224 x 224: 4 tiles either way -> gapped).
+bool rn_rw_supported(int cin, int cout, int pool_k, int pool_s, bool res, int out_side, int skip_side,
+                     RwPlan* plan) {
+    const bool s2 = pool_k == 4 && pool_s == 2;
+    if (s2 && !res && cin == 32 && cout == 64) return rw_plan(cin, cout, pool_k, pool_s, res, out_side, skip_side, true, plan);
+    if (s2 && res && cin == 64 && cout == 64 && ((out_side + 14) / 15 + 1) / 2 < ((out_side + 13) / 14 + 1) / 2) {
+        RwPlan w;
+        if (rw_plan(cin, cout, pool_k, pool_s, res, out_side, skip_side, true, &w)) {
+            *plan = w;
+            return true;
+        }
+    }
+    return rw_plan(cin, cout, pool_k, pool_s, res, out_side, skip_side, false, plan);
+}
+
 int rn_rw_launch(const RwPlan& p, int dtype, hipStream_t s, const StageArgs& a, dim3 grid) {
     switch (p.variant * 16 + p.npt) {
         case 0 * 16 + 4:
@@ -1197,8 +1212,10 @@ int rn_rw_launch(const RwPlan& p, int dtype, hipStream_t s, const StageArgs& a, 
         case 1 * 16 + 4: return launch_rw_dt<32, 32, 4, 1, false, 4>(dtype, s, a, grid);
         case 1 * 16 + 8: return launch_rw_dt<32, 32, 4, 1, false, 8>(dtype, s, a, grid);
         case 2 * 16 + 4: return launch_rw_dt<32, 32, 4, 1, true, 4>(dtype, s, a, grid);
-        case 3 * 16 + 1: return launch_rw_dt<32, 64, 4, 2, false, 1>(dtype, s, a, grid);
-        case 4 * 16 + 2: return launch_rw_dt<64, 64, 4, 2, true, 2>(dtype, s, a, grid);
+        case 3 * 16 + 1: return launch_rw_dt<32, 64, 4, 2, false, 1, 1, false, true>(dtype, s, a, grid);
+        case 4 * 16 + 2:
+            if (p.wide) return launch_rw_dt<64, 64, 4, 2, true, 2, 1, false, true>(dtype, s, a, grid);
+            return launch_rw_dt<64, 64, 4, 2, true, 2>(dtype, s, a, grid);
         case 5 * 16 + 1: return launch_rw_dt<64, 128, 0, 1, false, 1>(dtype, s, a, grid);
         case 6 * 16 + 2: return launch_rw_dt<128, 16, 4, 2, false, 2, 3>(dtype, s, a, grid);
         default:
