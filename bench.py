@@ -268,8 +268,15 @@ def main():
     # probs [B,6] fp32 and ids [B] int64 live in ONE byte buffer per rank, so the result exchange is a single
     # all-gather (32 bytes per image) instead of two latency-bound collectives
     from roomnet_amd.parallel import result_buffers, unpack_results
-    combo, probs, ids = result_buffers(B, graph.num_classes, dev)
-    g_combo = torch.empty((world * combo.numel(),), dtype=torch.uint8, device=dev) if multi else None
+    # TWO result buffers (and gathered buffers): the all-gather of step k is asynchronous -- RCCL runs it on its own
+    # stream behind the head kernel of step k -- and overlaps the kernels of step k+1, which write the other buffer; a
+    # buffer is reused only after the gather that read it two steps earlier has finished (stream-ordered wait, no host
+    # sync).  Every step still does one forward pass and one all-gather; all of it is inside the timed bracket.
+    bufs = [result_buffers(B, graph.num_classes, dev) for _ in range(2)]
+    combo, probs, ids = bufs[0]
+    g_bufs = [torch.empty((world * combo.numel(),), dtype=torch.uint8, device=dev) for _ in range(2)] if multi else None
+    works = [None, None]
+    n_steps_done = [0]
 
     # ONE explicit stream for the library's kernels and the collective: torch's default stream is the null stream,
     # which the library's own (non-blocking) stream is not ordered against.
@@ -277,24 +284,35 @@ def main():
         stream = None
 
         def sync():
-            pass
+            drain()
 
-        def forward():
-            eng.forward_into(ims, probs, ids)
+        def forward(k=0):
+            eng.forward_into(ims, bufs[k][1], bufs[k][2])
     else:
         stream = torch.cuda.Stream(dev)
         eng.set_stream(stream.cuda_stream)
 
         def sync():
+            drain()
             torch.cuda.synchronize()
 
-        def forward():
-            eng.forward_u8_device(ims.data_ptr(), B, probs.data_ptr(), ids.data_ptr())
+        def forward(k=0):
+            eng.forward_u8_device(ims.data_ptr(), B, bufs[k][1].data_ptr(), bufs[k][2].data_ptr())
+
+    def drain():
+        for k in range(2):
+            if works[k] is not None:
+                works[k].wait()
+                works[k] = None
 
     def step():
-        forward()
+        k = n_steps_done[0] & 1
+        n_steps_done[0] += 1
+        if multi and works[k] is not None:
+            works[k].wait()                   # the gather that read buffer k two steps ago
+        forward(k)
         if multi:
-            dist.all_gather_into_tensor(g_combo, combo)
+            works[k] = dist.all_gather_into_tensor(g_bufs[k], bufs[k][0], async_op=True)
 
     def on_stream():
         return torch.cuda.stream(stream) if stream is not None else contextlib.nullcontext()
@@ -340,17 +358,19 @@ def main():
 
     # sanity: outputs are a distribution and an argmax of it; every rank's gathered block carries that rank's results
     if not args.no_parity_check:
-        p = probs.cpu().numpy()
-        i = ids.cpu().numpy()
-        assert np.allclose(p.sum(1), 1.0, atol=1e-4) and (p.argmax(1) == i).all()
-        if multi:
-            rows = g_combo.view(world, combo.numel())
-            assert torch.equal(rows[rank], combo), "rank %d: its own block of the all-gather differs from its results" % rank
-            for r in range(world):
-                gi, gp = unpack_results(rows[r], B, graph.num_classes)
-                gp = gp.cpu().numpy()
-                assert np.allclose(gp.sum(1), 1.0, atol=1e-4) and (gp.argmax(1) == gi.cpu().numpy()).all(), \
-                    "rank %d: block %d of the all-gather is not a result" % (rank, r)
+        for k in range(2 if n_steps_done[0] > 1 else 1):
+            combo_k, probs_k, ids_k = bufs[k]
+            p = probs_k.cpu().numpy()
+            i = ids_k.cpu().numpy()
+            assert np.allclose(p.sum(1), 1.0, atol=1e-4) and (p.argmax(1) == i).all()
+            if multi:
+                rows = g_bufs[k].view(world, combo_k.numel())
+                assert torch.equal(rows[rank], combo_k), "rank %d: its own block of the all-gather differs from its results" % rank
+                for r in range(world):
+                    gi, gp = unpack_results(rows[r], B, graph.num_classes)
+                    gp = gp.cpu().numpy()
+                    assert np.allclose(gp.sum(1), 1.0, atol=1e-4) and (gp.argmax(1) == gi.cpu().numpy()).all(), \
+                        "rank %d: block %d of the all-gather is not a result" % (rank, r)
 
     n_st = len(graph.stages)
     stage_ms = np.zeros(n_st)
