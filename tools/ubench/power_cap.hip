@@ -45,6 +45,40 @@ __global__ __launch_bounds__(512, 2) void mfma_k(const int* __restrict__ seed, f
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
+// the same loop on v_mfma_f32_16x16x32_bf16: 8 independent 16x16 accumulators (4 registers each) per wave
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+template <bool LDS>
+__global__ __launch_bounds__(512, 2) void mfma16_k(const int* __restrict__ seed, float* out, int iters) {
+    __shared__ __attribute__((aligned(16))) int smem[16 * 1024];
+    for (int i = threadIdx.x; i < 16 * 1024; i += blockDim.x) smem[i] = seed[i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    i32x4 a[4], b[4];
+    for (int i = 0; i < 4; ++i) {
+        a[i] = *reinterpret_cast<const i32x4*>(&smem[((wave * 4 + i) * 64 + lane) * 4 % (16 * 1024 - 4)]);
+        b[i] = *reinterpret_cast<const i32x4*>(&smem[((wave * 4 + i + 32) * 64 + lane) * 4 % (16 * 1024 - 4)]);
+    }
+    f32x4 acc[8] = {};
+    const unsigned base = static_cast<unsigned>(reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) char*)smem)) + lane * 16 + wave * 4096;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                i32x4 bv = b[i & 3];
+                if constexpr (LDS) {
+                    if ((i & 1) == 0) asm volatile("ds_read_b128 %0, %1 offset:%2\n\ts_waitcnt lgkmcnt(0)" : "=v"(bv) : "v"(base), "n"(0));
+                }
+                acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[i & 3]), __builtin_bit_cast(bf16x8, bv), acc[i], 0, 0, 0);
+            }
+        }
+    }
+    float s = 0;
+    for (int i = 0; i < 8; ++i)
+        for (int j = 0; j < 4; ++j) s += acc[i][j];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
 __global__ void copy_k(const float4* __restrict__ in, float4* __restrict__ out, size_t n) {
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) out[i] = in[i];
 }
@@ -85,6 +119,9 @@ int main(int argc, char** argv) {
     const double flop = double(nb) * 8 * iters * 32 * 2.0 * 32 * 32 * 16;
     sustain("mfma bf16 32x32x16, registers", flop, "TFLOP/s", secs, [&] { hipLaunchKernelGGL((mfma_k<false, false>), dim3(nb), dim3(512), 0, 0, seed, out, iters); });
     sustain("mfma f16  32x32x16, registers", flop, "TFLOP/s", secs, [&] { hipLaunchKernelGGL((mfma_k<true, false>), dim3(nb), dim3(512), 0, 0, seed, out, iters); });
+    const double flop16 = double(nb) * 8 * iters * 64 * 2.0 * 16 * 16 * 32;
+    sustain("mfma bf16 16x16x32, registers", flop16, "TFLOP/s", secs, [&] { hipLaunchKernelGGL((mfma16_k<false>), dim3(nb), dim3(512), 0, 0, seed, out, iters); });
+    sustain("mfma bf16 16x16x32, B from LDS (1 read per 2 MFMAs)", flop16, "TFLOP/s", secs, [&] { hipLaunchKernelGGL((mfma16_k<true>), dim3(nb), dim3(512), 0, 0, seed, out, iters); });
     sustain("mfma bf16 32x32x16, B from LDS", flop, "TFLOP/s", secs, [&] { hipLaunchKernelGGL((mfma_k<false, true>), dim3(nb), dim3(512), 0, 0, seed, out, iters); });
     const size_t n4 = (size_t(1) << 30) / 16;
     float4 *ci, *co;
