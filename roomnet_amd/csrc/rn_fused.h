@@ -1,5 +1,6 @@
 // Fused 16-bit (bf16 / fp16 storage, fp32 accumulate) MFMA execution path.
 #pragma once
+#include <vector>
 #include "rn_internal.h"
 #include "rn_stage.h"
 
@@ -39,5 +40,11 @@ int rn_rw_launch(const RwPlan& p, int dtype, hipStream_t s, const rnk::StageArgs
 
 // ---- cross-stage fused pair: conv-pool-BN -> conv-pool-BN + residual of a depth-3 block (rn_stage23.hip)
 bool rn_stage23_supported(int in_side);
+// rn_conv16.hip: the un-pooled 64 -> 128 stage on 16x16x32 matrix tiles
+bool rn_conv16_supported(int cin, int cout, int pool_k, bool res);
+int rn_conv16_colblocks(int out_side);
+void rn_conv16_pack(const float* w_hwio, int dtype, unsigned short (*cvt_bf16)(float), unsigned short (*cvt_f16)(float),
+                    std::vector<unsigned short>* out);
+int rn_conv16_launch(int dtype, hipStream_t s, const rnk::Conv16Args& a, int n);
 bool rn_stage23_plan(int in_side, int* n_cblocks, int* x0, int* wo);   // column blocks (x0, wo: 4 entries)
 int rn_stage23_launch(int dtype, hipStream_t s, const rnk::Stage23Args& a, int n);

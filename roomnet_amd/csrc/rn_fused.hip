@@ -483,8 +483,24 @@ unsigned short f32_to_f16(float f) {
     return static_cast<unsigned short>(sign | out);
 }
 
+// Cost of running `wgs` equal workgroups of `rows` row steps each with `slots` of them resident at a time, for the
+// variants with several small workgroups per CU (they are back-filled as slots free up, so a launch does not run in
+// whole rounds of the chip).  Fitted to band-count sweeps on the GPU ("Band counts"):
+//   * 2-wave workgroups, four per CU (32->64 stage): the fractional number of rounds plus an eighth of a round for the
+//     ragged end, 1.5 row steps of prologue per workgroup (224: 2 bands; 600: 4);
+//   * 4-wave workgroups, two per CU (64->128 stage): a partial last round costs at least 0.6 of a round (1.125 and 2.25
+//     rounds measured as bad as 2 and 3), 3 row steps of prologue (224: 2 bands; 600: 5).
+static double rn_backfill_cost(long wgs, long slots, int rows, int wgs_per_cu) {
+    const double r = std::max(1.0, static_cast<double>(wgs) / static_cast<double>(slots));
+    if (wgs_per_cu >= 4) return (r + 0.12) * (rows + 1.5);
+    const double whole = std::floor(r), frac = r - whole;
+    return (whole + (frac > 1e-9 ? std::max(frac, 0.6) : 0.0)) * (rows + 3.0);
+}
+
 struct FusedStage {
     bool use_rw = false;         // register-weights kernel (rn_stage_rw.hip) covers this stage
+    bool use_c16 = false;        // 16x16x32-tile kernel (rn_conv16.hip) runs this stage instead
+    i32x4* wfrag16 = nullptr;    // its weight fragments
     RwPlan rw;
     float* ptab = nullptr;       // folded BN tables for the rw kernel
     int variant = -1;            // index into the dispatch table
@@ -709,6 +725,22 @@ int rn_fused_prepare(rn_handle* h, const rn_weights* w) {
         h->allocs.push_back(d);
         RN_HIP(hipMemcpy(d, frag.data(), frag.size() * 2, hipMemcpyHostToDevice));
         f.wfrag = static_cast<i32x4*>(d);
+        // the un-pooled 64 -> 128 stage runs on 16x16x32 tiles (rn_conv16.hip) unless the comparison flags ask for the
+        // one-kernel-family paths
+        if (f.use_rw && f.ptab && rn_conv16_supported(s.cin, s.cout, s.pool_k, s.skip_stage >= 0) &&
+            !(h->flags & RN_FLAG_GENERIC_KERNELS)) {
+            std::vector<unsigned short> f16;
+            rn_conv16_pack(wsrc, h->dtype, f32_to_bf16, f32_to_f16, &f16);
+            void* d16 = nullptr;
+            if (hipMalloc(&d16, f16.size() * 2) != hipSuccess) {
+                rn_set_error("hipMalloc(conv16 weights) failed");
+                return RN_E_NOMEM;
+            }
+            h->allocs.push_back(d16);
+            RN_HIP(hipMemcpy(d16, f16.data(), f16.size() * 2, hipMemcpyHostToDevice));
+            f.wfrag16 = static_cast<i32x4*>(d16);
+            f.use_c16 = true;
+        }
     }
     // ---- cross-stage fusion: the last two steps of a depth-3 block (network.py:183-203 with block_depth = 3):
     // stage i (32->32, pool 4/1) feeds only stage i+1 (32->32, pool 4/1 + residual), whose skip tensor is stage i's
@@ -945,6 +977,40 @@ int rn_fused_forward(rn_handle* h, const uint8_t* d_bgr, const float* d_rgb, int
         }
         a.H = a.W = s.in_side;
         a.Ho = a.Wo = s.out_side;
+        if (f.use_c16) {
+            Conv16Args ca{};
+            ca.in = a.in;
+            ca.out = a.out;
+            ca.wfrag = f.wfrag16;
+            ca.ptab = f.ptab;
+            ca.H = ca.W = s.in_side;
+            ca.Ho = ca.Wo = s.out_side;
+            ca.n_colblocks = rn_conv16_colblocks(s.out_side);
+            // 4-wave workgroups, two per CU; back-filled, so the cost of a band count is the fractional number of rounds
+            const long per_band = static_cast<long>(n) * ca.n_colblocks;
+            const long slots = 2L * h->n_cu;
+            const int max_bands = (s.out_side + 3) / 4;
+            int bands = 1;
+            double best_cost = -1;
+            for (int b = 1; b <= 8 && b <= max_bands; ++b) {
+                if (per_band * b < slots && b < max_bands) continue;          // fill the chip first
+                const double cost = rn_backfill_cost(per_band * b, slots, (s.out_side + b - 1) / b, 2);
+                if (best_cost < 0 || cost < best_cost) {
+                    best_cost = cost;
+                    bands = b;
+                }
+            }
+            if (per_band * bands < slots) {
+                bands = static_cast<int>((slots + per_band - 1) / per_band);
+                if (bands > max_bands) bands = max_bands;
+            }
+            ca.rows_per_band = (s.out_side + bands - 1) / bands;
+            ca.n_bands = (s.out_side + ca.rows_per_band - 1) / ca.rows_per_band;
+            int rc = rn_conv16_launch(h->dtype, h->stream, ca, n);
+            if (rc != RN_OK) return rc;
+            rn_record_event(h, 2 + static_cast<int>(i));
+            continue;
+        }
         if (f.use_rw) {
 #ifdef RN_DIAG
             if (const char* dbg = getenv("RN_DEBUG_FLAGS")) a.dbg_flags = atoi(dbg);   // diagnostic builds only
@@ -972,10 +1038,9 @@ int rn_fused_forward(rn_handle* h, const uint8_t* d_bgr, const float* d_rgb, int
             double best_cost = -1;
             for (int b = 1; b <= 8 && b <= max_bands; ++b) {
                 const long wgs = static_cast<long>(per_band) * b;
-                const double rounds = f.rw.wgs_per_cu == 1 ? static_cast<double>((wgs + slots - 1) / slots)
-                                                           : std::max(1.0, static_cast<double>(wgs) / static_cast<double>(slots));
-                const long rows = (s.out_side + b - 1) / b * (s.pool_k ? s.pool_s : 1) + 10;
-                const double cost = rounds * static_cast<double>(rows);
+                const long rows_b = (s.out_side + b - 1) / b * (s.pool_k ? s.pool_s : 1);     // conv rows of a band
+                const double cost = f.rw.wgs_per_cu == 1 ? static_cast<double>((wgs + slots - 1) / slots) * static_cast<double>(rows_b + 10)
+                                                         : rn_backfill_cost(wgs, slots, static_cast<int>(rows_b) + 2, f.rw.wgs_per_cu);
                 if (best_cost < 0 || cost < best_cost) {
                     best_cost = cost;
                     bands = b;

@@ -227,6 +227,16 @@ struct Stage23Args {
     unsigned long long* stamp_buf; // diagnostic build (-DRN_STAMPS) only: per-wave cycle sums
 };
 
+// 64 -> 128 stage without pooling on 16x16x32 matrix tiles (rn_conv16.hip)
+struct Conv16Args {
+    const unsigned short* in;     // [N, H, W, 64]
+    unsigned short* out;          // [N, Ho, Wo, 128]
+    const i32x4* wfrag;           // [18 chunks][8 cout tiles][64 lanes] A-operand fragments (rn_conv16_pack)
+    const float* ptab;            // folded BN: scale[128], shift[128]
+    int H, W, Ho, Wo;
+    int rows_per_band, n_bands, n_colblocks;
+};
+
 template <int CIN>
 struct StageGeom {
     static constexpr int CP = CIN / 8;                               // 16-byte chunks per pixel
