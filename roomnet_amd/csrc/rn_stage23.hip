@@ -208,11 +208,14 @@ __global__ __launch_bounds__(512, 2) void stage23pc_kernel(const Stage23Args a) 
 
     if (wave < 4) {
         // =============================================================== producer: first stage, A ring -> B ring
+        // weight fragments: loaded by inline asm straight into accumulator registers, all 18 in flight together (a
+        // compiler-visible load pinned with "+a" got an s_waitcnt vmcnt(0) of its own: 18 serial L2 round trips per wave
+        // in front of every band); retired by the wait_vmcnt<0>() below, ordered by the empty asm behind it
         i32x4 w2[KC];
 #pragma unroll
         for (int kc = 0; kc < KC; ++kc) {
-            w2[kc] = a.wfrag2[kc * 64 + lane];
-            asm volatile("" : "+a"(w2[kc]));
+            const i32x4* src = a.wfrag2 + kc * 64 + lane;
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=a"(w2[kc]) : "v"(src) : "memory");
         }
         // ---- A rows: four DMA pieces per producer wave and row (a piece is 64 lanes x 16 B, the fourth is the masked W-192 tail)
         const int ptid = wq * 64 + lane;
@@ -262,6 +265,8 @@ __global__ __launch_bounds__(512, 2) void stage23pc_kernel(const Stage23Args a) 
         for (int T = 0; T < 2; ++T) hp[T][0] = hp[T][1] = q0[T][0] = q0[T][1] = q1[T][0] = q1[T][1] = i32x4{0, 0, 0, 0};
         issue_A_pieces(IC<0>{}, IC<4>{}, a_next, 0);
         wait_vmcnt<0>();
+#pragma unroll
+        for (int kc = 0; kc < KC; ++kc) asm volatile("" : "+a"(w2[kc]));
         lds_barrier();
 
         const float* const tabl = tab + 4 * hh;
@@ -366,11 +371,11 @@ __global__ __launch_bounds__(512, 2) void stage23pc_kernel(const Stage23Args a) 
 
     // =================================================================== consumer: second stage, B ring -> HBM
     __builtin_amdgcn_s_setprio(1);
-    i32x4 w3[KC];
+    i32x4 w3[KC];                                         // (loaded like the producer's: see there)
 #pragma unroll
     for (int kc = 0; kc < KC; ++kc) {
-        w3[kc] = a.wfrag3[kc * 64 + lane];
-        asm volatile("" : "+a"(w3[kc]));
+        const i32x4* src = a.wfrag3 + kc * 64 + lane;
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=a"(w3[kc]) : "v"(src) : "memory");
     }
     unsigned baseB[2][3][2], a_off[2][2];
     int voff[2];
@@ -435,6 +440,9 @@ __global__ __launch_bounds__(512, 2) void stage23pc_kernel(const Stage23Args a) 
     f32x16 acc1;
 #pragma unroll
     for (int g = 0; g < 16; ++g) acc1[g] = 0.f;
+    wait_vmcnt<0>();                                      // the weight fragments have landed
+#pragma unroll
+    for (int kc = 0; kc < KC; ++kc) asm volatile("" : "+a"(w3[kc]));
     lds_barrier();
 
     const unsigned tabl_lds = lds_addr(tab + 64 + 4 * hh);
