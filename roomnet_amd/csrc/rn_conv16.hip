@@ -209,6 +209,172 @@ __global__ __launch_bounds__(256, 2) void conv16_kernel(const Conv16Args a) {
     wait_vmcnt<0>();
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// 128 -> 16 stage with avg-pool 4/2 (reference network.py:232, conv_block(16)) on the same 16x16x32 tiles:
+//
+//   in [N, H, W, 128] -> conv3x3 VALID -> ReLU6 -> avg-pool 4x4 stride 2 -> BN  = out [N, Ho, Wo, 16]
+//
+// The 32x32x16 template spends half of every MFMA on cout rows that do not exist (16 of 32) and splits K = 1152 over
+// three waves that meet in LDS every row.  Here M = 16 is the stage's cout count exactly: one wave = one 16-pixel tile x
+// all 16 couts, its 36 weight fragments (K = 9 taps x 4 channel quarters) in registers, no K split.  A 16-pixel tile is
+// one 16-lane DPP row, so the horizontal pool is the two row-local shifts of the gapped 32-pixel tiles: windows start
+// at the even columns 0 .. 12, 7 outputs per tile, tile stride 14 conv columns -- 44 conv columns (224 x 224) are
+// exactly 3 tiles.  Workgroup = image x band x block of 3 tiles (21 output columns), 3 waves sharing the input ring.
+constexpr int P16_CIN = 128, P16_COUT = 16;
+constexpr int P16_NT = 3;                          // pixel tiles = waves per workgroup
+constexpr int P16_BLKO = 7 * P16_NT;               // output columns per block
+constexpr int P16_RINGW = 14 * (P16_NT - 1) + 18;  // input columns a block reads (46)
+constexpr int P16_PIECES = 4;                      // DMA pieces of 192 lanes x 16 B per row (46 px x 16 chunks = 736 <= 768)
+constexpr int P16_ROWB = P16_PIECES * 64 * P16_NT * 16;
+constexpr int P16_KC = 36;
+constexpr int P16_LDS = C16_NSLOT * P16_ROWB;
+static_assert(P16_RINGW * 16 <= P16_PIECES * 64 * P16_NT, "a ring row fits its DMA pieces");
+
+// 16 chunks per 256-byte pixel = one whole bank row per pixel: chunk ^ ((pixel & 7) << 1) is conflict-free for every tap
+// column and channel quarter under ds_read_b128's lane grouping (enumerated; pixel & 15 and (pixel >> 1) & 15 are not)
+__device__ __forceinline__ int p16_swz(int pix) { return (pix & 7) << 1; }
+
+template <int DT>
+__global__ __launch_bounds__(64 * P16_NT, 2) void conv16p_kernel(const Conv16Args a) {
+    extern __shared__ __attribute__((aligned(64))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i16 = lane & 15, kg = lane >> 4;
+    const int cb = blockIdx.x % a.n_colblocks, band = blockIdx.x / a.n_colblocks, n = blockIdx.y;
+    const int xc0 = 2 * P16_BLKO * cb;                       // first conv / input column of the block
+    const int yo0 = band * a.rows_per_band;
+    const int nout = min(a.Ho, yo0 + a.rows_per_band) - yo0;
+    const int nconv = 2 * nout + 2, nin = nconv + 2;
+
+    // weights: 36 fragments, 32 of them straight into accumulator registers (see conv16_kernel)
+    i32x4 wr[P16_KC];
+#pragma unroll
+    for (int c = 0; c < P16_KC; ++c) {
+        const i32x4* src = a.wfrag + c * 64 + lane;
+        if (c < 32)
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=a"(wr[c]) : "v"(src) : "memory");
+        else
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(wr[c]) : "v"(src) : "memory");
+    }
+
+    const char* const in_img = reinterpret_cast<const char*>(a.in + static_cast<int64_t>(n) * a.H * a.W * P16_CIN);
+    const int64_t in_row_bytes = static_cast<int64_t>(a.W) * P16_CIN * 2;
+    unsigned goff[P16_PIECES];
+#pragma unroll
+    for (int i = 0; i < P16_PIECES; ++i) {
+        const int q = tid + 64 * P16_NT * i;
+        const int p = min(q >> 4, P16_RINGW - 1), c = q & 15;
+        const int pc = min(xc0 + p, a.W - 1);
+        goff[i] = static_cast<unsigned>((pc * P16_CIN + ((c ^ p16_swz(p)) << 3)) * 2);
+    }
+    auto issue_row = [&](int j, int slot) __attribute__((always_inline)) {
+        const char* row = in_img + static_cast<int64_t>(2 * yo0 + min(j, nin - 1)) * in_row_bytes;
+#pragma unroll
+        for (int i = 0; i < P16_PIECES; ++i) {
+            unsigned off = goff[i];
+            asm volatile("" : "+v"(off));
+            dma16(row + off, smem + slot * P16_ROWB + i * (64 * P16_NT * 16) + wave * 1024);
+        }
+    };
+#pragma unroll
+    for (int j = 0; j < C16_AHEAD; ++j) issue_row(j, j);
+
+    const unsigned ring_lds = static_cast<unsigned>(reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) char*)smem));
+    unsigned boff[3][4];
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int p = 14 * wave + i16 + kx;
+            boff[kx][q] = ring_lds + static_cast<unsigned>(p * 256 + (((4 * q + kg) ^ p16_swz(p)) << 4));
+        }
+    const f32x4v sc = *reinterpret_cast<const f32x4v*>(a.ptab + 4 * kg);
+    const f32x4v sh = *reinterpret_cast<const f32x4v*>(a.ptab + P16_COUT + 4 * kg);
+    constexpr int OOB = 0x40000000;
+    const int xo = P16_BLKO * cb + 7 * wave + (i16 >> 1);
+    const int voff_lane = ((i16 & 1) == 0 && i16 <= 12 && xo < a.Wo) ? (xo * P16_COUT + 4 * kg) * 2 : OOB;
+    const int out_row_bytes = a.Wo * P16_COUT * 2;
+    const char* out_row = reinterpret_cast<const char*>(a.out + static_cast<int64_t>(n) * a.Ho * a.Wo * P16_COUT) +
+                          static_cast<int64_t>(yo0) * out_row_bytes;
+    float hprev[4] = {0.f, 0.f, 0.f, 0.f}, q0[4] = {0.f, 0.f, 0.f, 0.f};
+
+    wait_vmcnt<0>();
+#pragma unroll
+    for (int c = 0; c < P16_KC; ++c) {
+        if (c < 32)
+            asm volatile("" : "+a"(wr[c]));
+        else
+            asm volatile("" : "+v"(wr[c]));
+    }
+    // One step = one conv row s.  vmcnt: behind the 4 pieces of input row s + 2 (issued in step s - 3) come 1 store +
+    // 4 pieces + 1 store + 4 pieces + 1 store = 11 operations (a store is issued every row, out of range on rows that
+    // emit nothing, so the count is constant).
+    auto step = [&](auto PC, int s) __attribute__((always_inline)) {
+        constexpr int P = decltype(PC)::value;
+        wait_vmcnt<2 * P16_PIECES + 3>();
+        raw_barrier();
+        issue_row(s + C16_AHEAD, (P + C16_AHEAD) % C16_NSLOT);
+        f32x4v acc[2];
+        i32x4 bq[2];
+        auto rd = [&](auto CC, i32x4& b) __attribute__((always_inline)) {
+            constexpr int C = decltype(CC)::value;
+            constexpr int tap = C / 4, q = C % 4, ky = tap / 3, kx = tap % 3;
+            constexpr int slot_off = ((P + ky) % C16_NSLOT) * P16_ROWB;
+            const unsigned ad = boff[kx][q];                 // (named outside the asm: implicit capture of an asm operand)
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(b) : "v"(ad), "n"(slot_off));
+        };
+        rd(IC<0>{}, bq[0]);
+        [&]<int... C>(std::integer_sequence<int, C...>) {
+            (([&] {
+                 const f32x4v zero = {0.f, 0.f, 0.f, 0.f};
+                 if constexpr (C + 1 < P16_KC) {
+                     rd(IC<(C + 1 < P16_KC ? C + 1 : 0)>{}, bq[(C + 1) & 1]);
+                     asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(bq[C & 1]));
+                 } else {
+                     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bq[C & 1]));
+                 }
+                 acc[C & 1] = mfma16<DT>(wr[C], bq[C & 1], C < 2 ? zero : acc[C & 1]);     // two chains: even / odd chunks
+             }()),
+             ...);
+        }(std::make_integer_sequence<int, P16_KC>{});
+        // ReLU6 -> vertical 4-row sums on the odd rows -> horizontal 4-column sums inside the 16-lane DPP row -> BN
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = relu6f(acc[0][j] + acc[1][j]);
+        int vo = OOB;
+        float y[4] = {0.f, 0.f, 0.f, 0.f};
+        if constexpr ((P & 1) == 1) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float pq = hprev[j] + v[j];
+                const float t = q0[j] + pq;
+                q0[j] = pq;
+                const float u = t + row_next<1>(t);
+                const float H = u + row_next<2>(u);
+                y[j] = fmaf(H, sc[j], sh[j]);
+            }
+            if (s >= 3) vo = voff_lane;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) hprev[j] = v[j];
+        }
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(out_row), 0, out_row_bytes, 0x00020000);
+        const i32x2v d = {static_cast<int>(pack2<DT>(y[0], y[1])), static_cast<int>(pack2<DT>(y[2], y[3]))};
+        __builtin_amdgcn_raw_buffer_store_b64(d, rs, vo, 0, 0);
+        if ((P & 1) == 1 && s >= 3) out_row += out_row_bytes;
+    };
+    int s = 0;
+    for (; s + C16_NSLOT - 1 < nconv; s += C16_NSLOT) {
+        [&]<int... I>(std::integer_sequence<int, I...>) { (step(IC<I>{}, s + I), ...); }(std::make_integer_sequence<int, C16_NSLOT>{});
+    }
+    [&]<int... I>(std::integer_sequence<int, I...>) {
+        ((s + I < nconv ? (step(IC<I>{}, s + I), 0) : 0), ...);
+    }(std::make_integer_sequence<int, C16_NSLOT - 1>{});
+    wait_vmcnt<0>();
+}
+
 }  // namespace
 
 bool rn_conv16_supported(int cin, int cout, int pool_k, bool res) { return cin == C16_CIN && cout == C16_COUT && pool_k == 0 && !res; }
@@ -238,4 +404,40 @@ int rn_conv16_launch(int dtype, hipStream_t s, const Conv16Args& a, int n) {
     };
     if (dtype == RN_DTYPE_BF16) return launch(conv16_kernel<RN_DTYPE_BF16>);
     return launch(conv16_kernel<RN_DTYPE_F16>);
+}
+
+bool rn_conv16p_supported(int cin, int cout, int pool_k, int pool_s, bool res) {
+    return cin == P16_CIN && cout == P16_COUT && pool_k == 4 && pool_s == 2 && !res;
+}
+
+int rn_conv16p_colblocks(int out_side) { return (out_side + P16_BLKO - 1) / P16_BLKO; }
+
+// A-operand fragments: frag[chunk c][lane][j] = W[k = 32 c + 8 (lane / 16) + j][cout = lane % 16]
+void rn_conv16p_pack(const float* w_hwio, int dtype, unsigned short (*cvt_bf16)(float), unsigned short (*cvt_f16)(float),
+                     std::vector<unsigned short>* out) {
+    out->assign(static_cast<size_t>(P16_KC) * 64 * 8, 0);
+    for (int c = 0; c < P16_KC; ++c)
+        for (int l = 0; l < 64; ++l)
+            for (int j = 0; j < 8; ++j) {
+                const int k = 32 * c + 8 * (l >> 4) + j, co = l & 15;
+                const float v = w_hwio[static_cast<size_t>(k) * P16_COUT + co];
+                (*out)[(static_cast<size_t>(c) * 64 + l) * 8 + j] = dtype == RN_DTYPE_BF16 ? cvt_bf16(v) : cvt_f16(v);
+            }
+}
+
+int rn_conv16p_launch(int dtype, hipStream_t s, const Conv16Args& a, int n) {
+    auto launch = [&](auto kern) -> int {
+        static std::atomic<unsigned long long> attr_devices{0};     // 72 KB of dynamic LDS: per device and instantiation
+        int dev = 0;
+        RN_HIP(hipGetDevice(&dev));
+        if (!(attr_devices.load(std::memory_order_acquire) >> (dev & 63) & 1ull)) {
+            RN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            attr_devices.fetch_or(1ull << (dev & 63), std::memory_order_release);
+        }
+        hipLaunchKernelGGL(kern, dim3(a.n_bands * a.n_colblocks, n), dim3(64 * P16_NT), P16_LDS, s, a);
+        RN_CHECK_LAUNCH();
+        return RN_OK;
+    };
+    if (dtype == RN_DTYPE_BF16) return launch(conv16p_kernel<RN_DTYPE_BF16>);
+    return launch(conv16p_kernel<RN_DTYPE_F16>);
 }

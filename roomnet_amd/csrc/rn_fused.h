@@ -46,5 +46,11 @@ int rn_conv16_colblocks(int out_side);
 void rn_conv16_pack(const float* w_hwio, int dtype, unsigned short (*cvt_bf16)(float), unsigned short (*cvt_f16)(float),
                     std::vector<unsigned short>* out);
 int rn_conv16_launch(int dtype, hipStream_t s, const rnk::Conv16Args& a, int n);
+// ... and the 128 -> 16 stage with avg-pool 4/2 (one wave = one 16-pixel tile x all 16 couts, no K split)
+bool rn_conv16p_supported(int cin, int cout, int pool_k, int pool_s, bool res);
+int rn_conv16p_colblocks(int out_side);
+void rn_conv16p_pack(const float* w_hwio, int dtype, unsigned short (*cvt_bf16)(float), unsigned short (*cvt_f16)(float),
+                     std::vector<unsigned short>* out);
+int rn_conv16p_launch(int dtype, hipStream_t s, const rnk::Conv16Args& a, int n);
 bool rn_stage23_plan(int in_side, int* n_cblocks, int* x0, int* wo);   // column blocks (x0, wo: 4 entries)
 int rn_stage23_launch(int dtype, hipStream_t s, const rnk::Stage23Args& a, int n);

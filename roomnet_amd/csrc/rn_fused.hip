@@ -500,6 +500,7 @@ static double rn_backfill_cost(long wgs, long slots, int rows, int wgs_per_cu) {
 struct FusedStage {
     bool use_rw = false;         // register-weights kernel (rn_stage_rw.hip) covers this stage
     bool use_c16 = false;        // 16x16x32-tile kernel (rn_conv16.hip) runs this stage instead
+    bool use_c16p = false;       // ... its pooled 128 -> 16 sibling
     i32x4* wfrag16 = nullptr;    // its weight fragments
     RwPlan rw;
     float* ptab = nullptr;       // folded BN tables for the rw kernel
@@ -740,6 +741,20 @@ int rn_fused_prepare(rn_handle* h, const rn_weights* w) {
             RN_HIP(hipMemcpy(d16, f16.data(), f16.size() * 2, hipMemcpyHostToDevice));
             f.wfrag16 = static_cast<i32x4*>(d16);
             f.use_c16 = true;
+        }
+        if (f.use_rw && f.ptab && rn_conv16p_supported(s.cin, s.cout, s.pool_k, s.pool_s, s.skip_stage >= 0) &&
+            !(h->flags & RN_FLAG_GENERIC_KERNELS)) {
+            std::vector<unsigned short> f16;
+            rn_conv16p_pack(wsrc, h->dtype, f32_to_bf16, f32_to_f16, &f16);
+            void* d16 = nullptr;
+            if (hipMalloc(&d16, f16.size() * 2) != hipSuccess) {
+                rn_set_error("hipMalloc(conv16p weights) failed");
+                return RN_E_NOMEM;
+            }
+            h->allocs.push_back(d16);
+            RN_HIP(hipMemcpy(d16, f16.data(), f16.size() * 2, hipMemcpyHostToDevice));
+            f.wfrag16 = static_cast<i32x4*>(d16);
+            f.use_c16p = true;
         }
     }
     // ---- cross-stage fusion: the last two steps of a depth-3 block (network.py:183-203 with block_depth = 3):
@@ -1007,6 +1022,39 @@ int rn_fused_forward(rn_handle* h, const uint8_t* d_bgr, const float* d_rgb, int
             ca.rows_per_band = (s.out_side + bands - 1) / bands;
             ca.n_bands = (s.out_side + ca.rows_per_band - 1) / ca.rows_per_band;
             int rc = rn_conv16_launch(h->dtype, h->stream, ca, n);
+            if (rc != RN_OK) return rc;
+            rn_record_event(h, 2 + static_cast<int>(i));
+            continue;
+        }
+        if (f.use_c16p) {
+            Conv16Args ca{};
+            ca.in = a.in;
+            ca.out = a.out;
+            ca.wfrag = f.wfrag16;
+            ca.ptab = f.ptab;
+            ca.H = ca.W = s.in_side;
+            ca.Ho = ca.Wo = s.out_side;
+            ca.n_colblocks = rn_conv16p_colblocks(s.out_side);
+            const long per_band = static_cast<long>(n) * ca.n_colblocks;
+            const long slots = 2L * h->n_cu;                 // 3-wave workgroups with 72 KB of LDS: two per CU
+            const int max_bands = (s.out_side + 3) / 4;
+            int bands = 1;
+            double best_cost = -1;
+            for (int b = 1; b <= 8 && b <= max_bands; ++b) {
+                if (per_band * b < slots && b < max_bands) continue;          // fill the chip first
+                const double cost = rn_backfill_cost(per_band * b, slots, 2 * ((s.out_side + b - 1) / b) + 2, 2);
+                if (best_cost < 0 || cost < best_cost) {
+                    best_cost = cost;
+                    bands = b;
+                }
+            }
+            if (per_band * bands < slots) {
+                bands = static_cast<int>((slots + per_band - 1) / per_band);
+                if (bands > max_bands) bands = max_bands;
+            }
+            ca.rows_per_band = (s.out_side + bands - 1) / bands;
+            ca.n_bands = (s.out_side + ca.rows_per_band - 1) / ca.rows_per_band;
+            int rc = rn_conv16p_launch(h->dtype, h->stream, ca, n);
             if (rc != RN_OK) return rc;
             rn_record_event(h, 2 + static_cast<int>(i));
             continue;
