@@ -24,7 +24,7 @@ def model_bytes(i):
     alg = s.in_side * s.in_side * s.cin * (1 if i == 0 else elem) + s.out_side * s.out_side * s.cout * elem
     if s.residual: alg += s.skip_side * s.skip_side * s.cout * elem
     return alg * B
-stage_kernels = [k for k in fetch if 'stage' in k or 'tail_kernel' in k or 'conv16_kernel' in k]
+stage_kernels = [k for k in fetch if 'stage' in k or 'tail_kernel' in k or 'conv16' in k]
 out = {"note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) of `python3 bench.py --steps 3 --warmup 1` (batch %d, "
                "%dx%d, %s). KiB per dispatch, mean over dispatches. gfx950 correction: FETCH_SIZE doubled (wide streaming reads are "
                "tallied at half size), WRITE_SIZE exact. traffic_bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024; algorithmic_bytes = "
