@@ -34,7 +34,6 @@ constexpr int C16_ROWB = 2 * 256 * 16;            // bytes per ring row: two DMA
 constexpr int C16_KC = 18;                        // K chunks of 32: (tap, channel half)
 constexpr int C16_TAB_OFF = C16_NSLOT * C16_ROWB;     // folded BN tables behind the ring: scale[128], shift[128]
 constexpr int C16_LDS = C16_TAB_OFF + 2 * C16_COUT * 4;
-constexpr int C16_STORES = 6;                     // output store instructions per lane and row (3 pixel tiles x 2 cout tiles)
 
 using f32x4v = __attribute__((ext_vector_type(4))) float;
 using i32x2v = __attribute__((ext_vector_type(2))) int;
@@ -145,11 +144,12 @@ __global__ __launch_bounds__(256, 2) void conv16_kernel(const Conv16Args a) {
         }
     // One step = one output row s (ring phase P = s mod NSLOT, compile time).  Order: counted wait for row s + 2 ->
     // barrier (every wave's pieces of it have landed, and every wave is done reading row s - 1) -> DMA of row s + AHEAD
-    // into the slot of row s - 1 -> 108 MFMAs -> epilogue + 6 stores.  vmcnt counts DMA pieces and stores in issue
-    // order: behind the pieces of row s + 2 (issued in step s - 3) come 6 stores + 2 pieces + 6 + 2 + 6 stores = 22.
+    // into the slot of row s - 1 -> 108 MFMAs -> epilogue + 6 stores.  The wait counts only the LOADS issued behind the
+    // pieces of row s + 2 (rows s + 3, s + 4: four pieces), like the row-streaming template: loads return in order among
+    // themselves, a count that included the stores in between would lean on load / store ordering as well.
     auto step = [&](auto PC, int s) __attribute__((always_inline)) {
         constexpr int P = decltype(PC)::value;
-        wait_vmcnt<3 * C16_STORES + 4>();
+        wait_vmcnt<4>();
         raw_barrier();
         issue_row(s + C16_AHEAD, (P + C16_AHEAD) % C16_NSLOT);
         f32x4v acc[3][2];
@@ -308,12 +308,11 @@ __global__ __launch_bounds__(64 * P16_NT, 2) void conv16p_kernel(const Conv16Arg
         else
             asm volatile("" : "+v"(wr[c]));
     }
-    // One step = one conv row s.  vmcnt: behind the 4 pieces of input row s + 2 (issued in step s - 3) come 1 store +
-    // 4 pieces + 1 store + 4 pieces + 1 store = 11 operations (a store is issued every row, out of range on rows that
-    // emit nothing, so the count is constant).
+    // One step = one conv row s.  vmcnt: the loads behind the 4 pieces of input row s + 2 are the 8 pieces of rows s + 3
+    // and s + 4 (stores are not counted: see conv16_kernel).
     auto step = [&](auto PC, int s) __attribute__((always_inline)) {
         constexpr int P = decltype(PC)::value;
-        wait_vmcnt<2 * P16_PIECES + 3>();
+        wait_vmcnt<2 * P16_PIECES>();
         raw_barrier();
         issue_row(s + C16_AHEAD, (P + C16_AHEAD) % C16_NSLOT);
         f32x4v acc[2];
