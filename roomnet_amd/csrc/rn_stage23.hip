@@ -269,16 +269,30 @@ __global__ __launch_bounds__(512, 2) void stage23pc_kernel(const Stage23Args a) 
         for (int kc = 0; kc < KC; ++kc) asm volatile("" : "+a"(w2[kc]));
         lds_barrier();
 
-        const float* const tabl = tab + 4 * hh;
+        const unsigned tabl_lds = lds_addr(tab + 4 * hh);
         auto epi = [&](auto TC, auto PC, const f32x16& acce) __attribute__((always_inline)) {
             constexpr int T = decltype(TC)::value, P = decltype(PC)::value;
+            // folded-BN table entries of the lane's 16 channels: all eight reads go out in front of the pooling (32 VALU + 4
+            // dependent MFMAs cover their latency); compiler-visible loads sat behind the pooling, two per channel group, each
+            // pair waited for with lgkmcnt(0) right before its use: four exposed LDS round trips per epilogue
+            f32x4 tsc[4], tsh[4];
+            {
+                const unsigned ta = tabl_lds;                    // (named outside the asm: implicit capture)
+                auto& t1 = tsc;
+                auto& t2 = tsh;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(t1[g]) : "v"(ta), "n"(32 * g));
+                    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(t2[g]) : "v"(ta), "n"(128 + 32 * g));
+                }
+            }
             const f32x16 H = pool(IC<(P & 1)>{}, acce, hp[T], q0[T], q1[T]);
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(tsc[0]), "+v"(tsc[1]), "+v"(tsc[2]), "+v"(tsc[3]), "+v"(tsh[0]), "+v"(tsh[1]), "+v"(tsh[2]), "+v"(tsh[3]));
             constexpr int off = ((P + 3) % F_NB) * F_ROWB;       // B row t-5
             auto& wb = wbB;                                      // (named here: implicit capture of an asm operand)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const f32x4 sc = *reinterpret_cast<const f32x4*>(tabl + 8 * g);
-                const f32x4 sh = *reinterpret_cast<const f32x4*>(tabl + 32 + 8 * g);
+                const f32x4 sc = tsc[g], sh = tsh[g];
                 const f32x2 y0 = pk_fma(f32x2{H[4 * g], H[4 * g + 1]}, f32x2{sc[0], sc[1]}, f32x2{sh[0], sh[1]});
                 const f32x2 y1 = pk_fma(f32x2{H[4 * g + 2], H[4 * g + 3]}, f32x2{sc[2], sc[3]}, f32x2{sh[2], sh[3]});
                 const i32x2 d = {static_cast<int>(pack2<DT>(y0[0], y0[1])), static_cast<int>(pack2<DT>(y1[0], y1[1]))};
@@ -459,19 +473,6 @@ __global__ __launch_bounds__(512, 2) void stage23pc_kernel(const Stage23Args a) 
             asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(tq[4 + t2]) : "v"(ahi));
             asm volatile("ds_read_b64_tr_b16 %0, %1 offset:1024" : "=v"(tq[6 + t2]) : "v"(ahi));
         }
-        const f32x16 H = pool(PRC, acce, hp[T], q0[T], q1[T]);
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(tq[0]), "+v"(tq[1]), "+v"(tq[2]), "+v"(tq[3]), "+v"(tq[4]), "+v"(tq[5]), "+v"(tq[6]), "+v"(tq[7]));
-        const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        const i32x4 al0 = {tq[0][0], tq[0][1], tq[1][0], tq[1][1]}, al1 = {tq[2][0], tq[2][1], tq[3][0], tq[3][1]};
-        const i32x4 ah0 = {tq[4][0], tq[4][1], tq[5][0], tq[5][1]}, ah1 = {tq[6][0], tq[6][1], tq[7][0], tq[7][1]};
-        f32x16 r_lo = mfma32<DT>(al0, bw[T][0], zero);
-        f32x16 r_hi = mfma32<DT>(ah0, bw[T][0], zero);
-        r_lo = mfma32<DT>(al1, bw[T][1], r_lo);
-        r_hi = mfma32<DT>(ah1, bw[T][1], r_hi);
-        uint2 pk[4];
-        // folded-BN table entries of channel group g: read by inline asm one group ahead of their use and retired by a
-        // counted wait (compiler-visible LDS loads are waited for with lgkmcnt(0) right before use: four exposed LDS
-        // round trips per epilogue on the wave the whole step waits for)
         f32x4 tsc1[4], tsh1[4], tsc2[4];
         auto tab_issue = [&](auto GC) __attribute__((always_inline)) {
             constexpr int g = decltype(GC)::value;
@@ -483,7 +484,20 @@ __global__ __launch_bounds__(512, 2) void stage23pc_kernel(const Stage23Args a) 
             asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(t2[g]) : "v"(ta), "n"(128 + 32 * g));
             asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(t3[g]) : "v"(ta), "n"(256 + 32 * g));
         };
+        const f32x16 H = pool(PRC, acce, hp[T], q0[T], q1[T]);
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(tq[0]), "+v"(tq[1]), "+v"(tq[2]), "+v"(tq[3]), "+v"(tq[4]), "+v"(tq[5]), "+v"(tq[6]), "+v"(tq[7]));
+        const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        const i32x4 al0 = {tq[0][0], tq[0][1], tq[1][0], tq[1][1]}, al1 = {tq[2][0], tq[2][1], tq[3][0], tq[3][1]};
+        const i32x4 ah0 = {tq[4][0], tq[4][1], tq[5][0], tq[5][1]}, ah1 = {tq[6][0], tq[6][1], tq[7][0], tq[7][1]};
+        f32x16 r_lo = mfma32<DT>(al0, bw[T][0], zero);
+        f32x16 r_hi = mfma32<DT>(ah0, bw[T][0], zero);
+        r_lo = mfma32<DT>(al1, bw[T][1], r_lo);
+        r_hi = mfma32<DT>(ah1, bw[T][1], r_hi);
+        uint2 pk[4];
         tab_issue(IC<0>{});
+        // folded-BN table entries of channel group g: read by inline asm one group ahead of their use and retired by a
+        // counted wait (compiler-visible LDS loads are waited for with lgkmcnt(0) right before use: four exposed LDS
+        // round trips per epilogue on the wave the whole step waits for)
         [&]<int... G>(std::integer_sequence<int, G...>) {
             (([&] {
                  constexpr int g = G;
