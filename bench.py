@@ -472,11 +472,20 @@ def main():
                 else:
                     kname = "stage_rw_kernel, stage %d (%d->%d ch%s)" % (dom_stages[0], s0.cin, s0.cout,
                                                                          " + residual" if s0.residual else "")
+                traffic = measured_traffic(dom_stages, B, args.side, args.dtype)
+                dom_flops = sum(sflops[k] for k in dom_stages) * B
                 out["roofline"] = {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                                    "frac": achieved / HBM_PEAK,
-                                   "traffic": measured_traffic(dom_stages, B, args.side, args.dtype),
+                                   "traffic": traffic,
                                    "kernel": kname, "stages": dom_stages, "kernel_ms": group_ms[dom],
-                                   "algorithmic_bytes_per_launch": int(dom_bytes)}
+                                   "algorithmic_bytes_per_launch": int(dom_bytes),
+                                   # `achieved` / `frac` are EFFECTIVE figures under the contract's stage-boundary byte model
+                                   # (SURVEY 8d): a launch that fuses stages is credited with the bytes those stages would
+                                   # move as separate launches.  What the launch physically moves is `traffic` (PMC):
+                                   "achieved_kind": "effective: algorithmic stage-boundary bytes of every stage the launch computes / launch time",
+                                   "measured_gbps": None if traffic is None else traffic / dom_s / 1e9,
+                                   "measured_frac": None if traffic is None else traffic / dom_s / HBM_PEAK,
+                                   "mfma_frac": dom_flops / dom_s / MFMA_PEAK_16}
             med = float(np.median(event_ms))
             out["path"] = {"algorithmic_bytes_per_image": int(bytes_per_img),
                            "hbm_frac": value * bytes_per_img / (world * HBM_PEAK),

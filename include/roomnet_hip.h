@@ -217,8 +217,19 @@ RN_API int rn_stage_launch(const rn_handle* h, int stage);
  * first n % N devices one more) and the ONLY exchange on the data path is one RCCL
  * all-gather of every device's packed results over xGMI: per device `slot_bytes` =
  * max_batch_per_device * (num_classes * 4 + 8) bytes = probs [cap, C] float32 followed by
- * ids [cap] int64 (32 bytes per image).  librccl is loaded on the first rn_group_create.
- * One host thread drives all devices; calls on one group must be serialised by the caller. */
+ * ids [cap] int64 (32 bytes per image).  librccl is loaded on the first rn_group_create
+ * (environment ROOMNET_RCCL_LIB, read at that call only: another file to dlopen instead);
+ * without it rn_group_create returns RN_E_STATE and says which dlopen failed.
+ * One host thread drives all devices; calls on one group must be serialised by the caller;
+ * every rn_group_* call leaves the caller's current HIP device as it found it.
+ * SCALING: rn_group_forward_u8_device is the entry that scales -- the shards are already in
+ * each device's HBM (as in BASELINE's measurement contract) and nothing but 32 B per image
+ * crosses a link.  rn_group_forward_u8 takes one pageable host buffer: it uploads the
+ * shards with one short-lived host thread per device (a pageable copy blocks its caller)
+ * and is bound by the host's memory and PCIe bandwidth (38.5 MB per device and call at
+ * 256 x 224 x 224), not by the GPUs.
+ * VALIDATION: groups of more than one device have not run on hardware yet (the
+ * development pool has one MI355X per box); the one-device group is tested on the GPU. */
 typedef struct rn_group rn_group;
 /* devices == NULL: devices 0 .. ndev-1.  Weights are replicated (0.7 MB). */
 RN_API int rn_group_create(const rn_weights* w, int ndev, const int* devices, int dtype, int max_batch_per_device,

@@ -21,7 +21,7 @@ done
 "$HIPCC" "${CFLAGS[@]}" ${RN_RW_FLAGS:--mllvm -amdgpu-mfma-vgpr-form} -c "$HERE/rn_stage_rw.hip" -o "$OBJ/rn_stage_rw.o" &
 "$HIPCC" "${CFLAGS[@]}" ${RN_RW_FLAGS:--mllvm -amdgpu-mfma-vgpr-form} -c "$HERE/rn_stage23.hip" -o "$OBJ/rn_stage23.o" &
 wait
-"$HIPCC" --offload-arch=gfx950 -shared -fPIC "$OBJ"/rn_api.o "$OBJ"/rn_kernels_f32.o "$OBJ"/rn_fused.o "$OBJ"/rn_imageops.o "$OBJ"/rn_group.o "$OBJ"/rn_tail.o "$OBJ"/rn_conv16.o "$OBJ"/rn_stage_rw.o "$OBJ"/rn_stage23.o -ldl \
+"$HIPCC" --offload-arch=gfx950 -shared -fPIC "$OBJ"/rn_api.o "$OBJ"/rn_kernels_f32.o "$OBJ"/rn_fused.o "$OBJ"/rn_imageops.o "$OBJ"/rn_group.o "$OBJ"/rn_tail.o "$OBJ"/rn_conv16.o "$OBJ"/rn_stage_rw.o "$OBJ"/rn_stage23.o -ldl -lpthread \
     ${RN_EXTRA_FLAGS:-} -o "$OUT/libroomnet_hip.so"
 echo "built $OUT/libroomnet_hip.so"
 # register report of the hot kernels: a spill in one of them costs ~25 % of its time (seen on the fused stage pair) and

@@ -142,6 +142,7 @@ __global__ __launch_bounds__(256, 2) void conv16_kernel(const Conv16Args a) {
             else
                 asm volatile("" : "+v"(wr[c][ct]));
         }
+    lds_barrier();                                                     // the BN table written above is visible to every wave
     // One step = one output row s (ring phase P = s mod NSLOT, compile time).  Order: counted wait for row s + 2 ->
     // barrier (every wave's pieces of it have landed, and every wave is done reading row s - 1) -> DMA of row s + AHEAD
     // into the slot of row s - 1 -> 108 MFMAs -> epilogue + 6 stores.  The wait counts only the LOADS issued behind the

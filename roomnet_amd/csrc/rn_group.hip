@@ -6,17 +6,26 @@
 // several MI355X from one process.  (The Python benchmark keeps one process per GPU with torch.distributed.)
 //
 // librccl is resolved with dlopen at the first rn_group_create: a process that never asks for a group does not
-// load it.  One host thread drives all devices: per device one stream (the handle's own), the forward pass is
+// load it (ROOMNET_RCCL_LIB names another file to load instead; read once, at that first call, never on the launch
+// path).  One host thread drives all devices: per device one stream (the handle's own), the forward pass is
 // enqueued device by device, the all-gather is one ncclGroupStart/End bracket over all communicators, so the
 // collective is stream-ordered behind each device's head kernel without a host synchronisation in between.
+// The host-buffer entry rn_group_forward_u8 additionally starts one short-lived upload thread per device: a copy out
+// of pageable memory blocks the thread that issues it, and one thread issuing eight of them would run them one
+// after the other.  Every entry point leaves the caller's current HIP device as it found it.
+//
+// Groups of more than one device have NOT run on hardware yet (the development pool has one MI355X per box): the
+// one-device group is what tests/test_group.py validates.
 #include "rn_internal.h"
 
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <new>
+#include <thread>
 
 namespace {
 
@@ -36,12 +45,18 @@ std::string g_rccl_error;
 
 bool load_rccl() {
     std::call_once(g_rccl_once, [] {
+        std::string last_error = "?";
+        const char* forced = std::getenv("ROOMNET_RCCL_LIB");
         for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            if (forced && *forced) name = forced;
             g_rccl.dl = dlopen(name, RTLD_NOW | RTLD_LOCAL);
             if (g_rccl.dl) break;
+            const char* e = dlerror();           // (one call: dlerror() clears the error state it returns)
+            if (e) last_error = e;
+            if (forced && *forced) break;
         }
         if (!g_rccl.dl) {
-            g_rccl_error = std::string("dlopen(librccl) failed: ") + (dlerror() ? dlerror() : "?");
+            g_rccl_error = "dlopen(librccl) failed: " + last_error;
             return;
         }
         auto sym = [&](const char* n) -> void* {
@@ -68,6 +83,17 @@ bool load_rccl() {
         }                                                                                                  \
     } while (0)
 
+// the caller's current HIP device, put back when an entry point returns (the per-handle entry points do the same)
+struct CurrentDeviceRestore {
+    int prev = -1;
+    CurrentDeviceRestore() {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    }
+    ~CurrentDeviceRestore() {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+};
+
 }  // namespace
 
 struct rn_group {
@@ -88,6 +114,7 @@ struct rn_group {
 
 extern "C" void rn_group_destroy(rn_group* g) {
     if (!g) return;
+    CurrentDeviceRestore restore;
     for (int d = 0; d < static_cast<int>(g->handles.size()); ++d) {
         if (hipSetDevice(g->devices[d]) != hipSuccess) continue;
         (void)hipDeviceSynchronize();
@@ -121,6 +148,7 @@ extern "C" int rn_group_create(const rn_weights* w, int ndev, const int* devices
         rn_set_error("rn_group_create: %s", g_rccl_error.c_str());
         return RN_E_STATE;
     }
+    CurrentDeviceRestore restore;
     rn_group* g = new (std::nothrow) rn_group();
     if (!g) {
         rn_set_error("rn_group_create: out of host memory");
@@ -195,9 +223,19 @@ static int group_run(rn_group* g, const uint8_t* const* d_shards, const int* cou
         if (rc != RN_OK) return rc;
     }
     RN_NCCL(g_rccl.GroupStart());
+    // (an error inside the bracket still closes it: RCCL keeps a group call open per thread until GroupEnd)
     for (int d = 0; d < g->ndev; ++d) {
-        RN_HIP(hipSetDevice(g->devices[d]));
-        RN_NCCL(g_rccl.AllGather(g->d_send[d], g->d_recv[d], g->slot_bytes, ncclUint8, g->comms[d], g->handles[d]->stream));
+        if (hipSetDevice(g->devices[d]) != hipSuccess) {
+            (void)g_rccl.GroupEnd();
+            rn_set_error("rn_group: hipSetDevice(%d) failed", g->devices[d]);
+            return RN_E_HIP;
+        }
+        const ncclResult_t r = g_rccl.AllGather(g->d_send[d], g->d_recv[d], g->slot_bytes, ncclUint8, g->comms[d], g->handles[d]->stream);
+        if (r != ncclSuccess) {
+            (void)g_rccl.GroupEnd();
+            rn_set_error("ncclAllGather on device %d failed: %s", g->devices[d], g_rccl.GetErrorString(r));
+            return RN_E_HIP;
+        }
     }
     RN_NCCL(g_rccl.GroupEnd());
     return RN_OK;
@@ -213,6 +251,7 @@ extern "C" int rn_group_forward_u8_device(rn_group* g, const uint8_t* const* d_s
             rn_set_error("rn_group_forward_u8_device: device %d: %d images out of range (max_batch_per_device %d)", d, counts[d], g->cap);
             return RN_E_RANGE;
         }
+    CurrentDeviceRestore restore;
     return group_run(g, d_shards, counts);
 }
 
@@ -231,6 +270,7 @@ extern "C" int rn_group_sync(rn_group* g) {
         rn_set_error("null group");
         return RN_E_INVALID;
     }
+    CurrentDeviceRestore restore;
     for (int d = 0; d < g->ndev; ++d) {
         RN_HIP(hipSetDevice(g->devices[d]));
         RN_HIP(hipStreamSynchronize(g->handles[d]->stream));
@@ -247,19 +287,35 @@ extern "C" int rn_group_forward_u8(rn_group* g, const uint8_t* bgr_nhwc, int n, 
         rn_set_error("rn_group_forward_u8: n = %d out of range (1..%d)", n, g->cap * g->ndev);
         return RN_E_RANGE;
     }
+    CurrentDeviceRestore restore;
     const size_t img_bytes = static_cast<size_t>(g->im_side) * g->im_side * 3;
     std::vector<const uint8_t*> shards(g->ndev, nullptr);
     std::vector<int> counts(g->ndev, 0);
+    // one upload thread per device: hipMemcpyAsync out of pageable memory stages through the runtime's pinned buffers
+    // on the CALLING thread and returns when the source has been read -- issued from one thread the devices' uploads
+    // (38.5 MB each at 256 images of 224 x 224) would follow one another (~1.5 ms each) in front of 1.6 ms of compute
+    std::vector<std::thread> uploads;
+    std::vector<hipError_t> up_rc(g->ndev, hipSuccess);
     for (int d = 0; d < g->ndev; ++d) {
         int lo, cnt;
         shard(n, g->ndev, d, &lo, &cnt);
         counts[d] = cnt;
         shards[d] = g->d_in[d];
         if (cnt == 0) continue;
-        RN_HIP(hipSetDevice(g->devices[d]));
-        RN_HIP(hipMemcpyAsync(g->d_in[d], bgr_nhwc + static_cast<size_t>(lo) * img_bytes, static_cast<size_t>(cnt) * img_bytes,
-                              hipMemcpyHostToDevice, g->handles[d]->stream));
+        const uint8_t* src = bgr_nhwc + static_cast<size_t>(lo) * img_bytes;
+        const size_t bytes = static_cast<size_t>(cnt) * img_bytes;
+        uploads.emplace_back([g, d, src, bytes, &up_rc] {
+            hipError_t e = hipSetDevice(g->devices[d]);
+            if (e == hipSuccess) e = hipMemcpyAsync(g->d_in[d], src, bytes, hipMemcpyHostToDevice, g->handles[d]->stream);
+            up_rc[d] = e;
+        });
     }
+    for (auto& t : uploads) t.join();
+    for (int d = 0; d < g->ndev; ++d)
+        if (up_rc[d] != hipSuccess) {
+            rn_set_error("rn_group_forward_u8: upload to device %d failed: %s", g->devices[d], hipGetErrorString(up_rc[d]));
+            return RN_E_HIP;
+        }
     int rc = group_run(g, shards.data(), counts.data());
     if (rc != RN_OK) return rc;
     // every device holds every device's results; read them back from the first one

@@ -117,6 +117,10 @@ class DataParallelRoomNet:
         ncls = getattr(self.model, "num_classes", 6)
         if self._engine is not None:
             return self._infer_device(im_batch, n, lo, hi, ncls)
+        return self._infer_host(im_batch, n, lo, hi, ncls)
+
+    def _infer_host(self, im_batch, n, lo, hi, ncls):
+        import torch
         if hi > lo:
             ids, probs = self._forward(im_batch[lo:hi])
         else:
@@ -133,7 +137,16 @@ class DataParallelRoomNet:
         cmax = max(counts) if counts else 0
         if cmax > eng.max_batch:
             raise ValueError("shard of %d images exceeds the engine's max_batch %d" % (cmax, eng.max_batch))
-        shard = np.ascontiguousarray(np.asarray(im_batch[lo:hi], dtype=np.uint8))
+        # same feed rule as RoomNet.infer: uint8 (or integral values in [0, 255]) goes to the device path; a float feed
+        # is refused by the 16-bit models with the reason, and takes the model's own infer() on a float32 model
+        # (decided on the whole batch, so that every rank takes the same branch and the same collective)
+        feed = np.asarray(im_batch)
+        if feed.size and hasattr(self.model, "_as_feed"):
+            feed = self.model._as_feed(feed)
+        if feed.size and feed.dtype != np.uint8:
+            return self._infer_host(im_batch, n, lo, hi, ncls)
+        shard = feed[lo:hi].astype(np.uint8, copy=False)
+        shard = np.ascontiguousarray(shard)
         with torch.cuda.stream(self._stream):
             combo, probs, ids = result_buffers(cmax, ncls, self.device)
             combo.zero_()
