@@ -46,7 +46,8 @@ def read_fpaths(list_fpath):
 
 
 def _prepare(nn, im):
-    """The host half of ``RoomNet.infer_optimized`` (network.py:149-152)."""
+    """The host half of ``RoomNet.infer_optimized`` (network.py:149-152); used for images the device pipeline does
+    not take (anything but 3-channel uint8) and for model objects without ``infer_images``."""
     im = nn.center_crop(im)
     h, w, _ = im.shape
     if h != nn.im_side or w != nn.im_side:
@@ -54,16 +55,32 @@ def _prepare(nn, im):
     return np.ascontiguousarray(im)
 
 
-def _infer_files(nn, fpaths, batch_size):
-    """Yield ``(index, image_bgr, idx, conf)`` per readable file, running the GPU in batches."""
+def _classify(nn, ims):
+    """``(ids, probs-or-None)`` for a list of decoded BGR images of any size.  ``RoomNet.infer_images`` hands the raw
+    images to the GPU, which crops and resizes them (``rn_classify_images_u8``: byte for byte the host restatement of
+    ``cv2.resize``); other model objects get the host-prepared batch through ``infer`` like the reference's caller."""
+    if hasattr(nn, 'infer_images'):
+        outs = nn.infer_images(ims)
+    else:
+        outs = nn.infer(np.stack([_prepare(nn, im) for im in ims], 0))
+    return outs if isinstance(outs, tuple) else (outs, None)
+
+
+DECODE_THREADS = min(8, os.cpu_count() or 1)
+
+
+def _infer_files(nn, fpaths, batch_size, decode_threads=None):
+    """Yield ``(index, image_bgr, idx, conf)`` per readable file, in list order.  Files are decoded on a small thread
+    pool (Pillow releases the GIL while it decodes) that runs up to two batches ahead of the GPU; the GPU gets the
+    decoded images in batches of ``batch_size``."""
+    from collections import deque
+    from concurrent.futures import ThreadPoolExecutor
     pending = []
 
     def flush():
         if not pending:
             return []
-        batch = np.stack([p[2] for p in pending], 0)
-        outs = nn.infer(batch)
-        ids, probs = outs if isinstance(outs, tuple) else (outs, None)
+        ids, probs = _classify(nn, [p[1] for p in pending])
         # the confidence stays an np.float32 scalar like infer_outs[1][0][idx] of the reference (infer.py:84): its
         # printed form, round(conf * 100, 2) and str(conf) are float32 results
         res = [(p[0], p[1], int(ids[k]), (probs[k][ids[k]] if probs is not None else np.float32('nan')))
@@ -71,18 +88,32 @@ def _infer_files(nn, fpaths, batch_size):
         pending.clear()
         return res
 
-    for i, fpath in enumerate(fpaths):
-        im = imread(fpath)
-        if im is None:
-            # the reference crashes here (cv2.imread returns None, infer.py:81-82); report and go on
-            print(fpath, '---> unreadable image, skipped')
-            continue
-        pending.append((i, im, _prepare(nn, im)))
-        if len(pending) >= batch_size:
-            for r in flush():
-                yield r
-    for r in flush():
-        yield r
+    nthreads = max(1, int(decode_threads or DECODE_THREADS))
+    window = max(2 * batch_size, nthreads)
+    todo = iter(enumerate(fpaths))
+    inflight = deque()
+    with ThreadPoolExecutor(max_workers=nthreads) as pool:
+        def top_up():
+            while len(inflight) < window:
+                nxt = next(todo, None)
+                if nxt is None:
+                    return
+                inflight.append((nxt[0], nxt[1], pool.submit(imread, nxt[1])))
+        top_up()
+        while inflight:
+            i, fpath, fut = inflight.popleft()
+            im = fut.result()
+            top_up()
+            if im is None:
+                # the reference crashes here (cv2.imread returns None, infer.py:81-82); report and go on
+                print(fpath, '---> unreadable image, skipped')
+                continue
+            pending.append((i, im))
+            if len(pending) >= batch_size:
+                for r in flush():
+                    yield r
+        for r in flush():
+            yield r
 
 
 def groundtruth_validation(nn, list_fpath=None, batch_size=64):

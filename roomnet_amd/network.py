@@ -238,5 +238,26 @@ class RoomNet:
             out_label_idx, out_label_conf = eng.forward_f32(x[None])
         return out_label_idx, out_label_conf
 
+    def infer_images(self, images):
+        """Batched ``infer_optimized``: a list of BGR HWC images of ANY size -> what ``infer`` returns for the batch of
+        their centre-cropped, resized versions (network.py:149-152 per image, then network.py:128-135).  3-channel
+        uint8 images -- what ``cv2.imread`` yields -- go to the GPU as they are: crop + INTER_LINEAR resize run there
+        (``rn_classify_images_u8``, byte for byte the host restatement); anything else is prepared on the host.  Not
+        in the reference (its caller loops over ``infer_optimized``, infer.py:79-82); the directory drivers use it."""
+        images = list(images)
+        if not images:
+            empty = np.zeros((0,), np.int64), np.zeros((0, self.num_classes), np.float32)
+            return empty if self.optimized_inference else empty[0]
+        if all(isinstance(im, np.ndarray) and im.dtype == np.uint8 and im.ndim == 3 and im.shape[2] == 3 for im in images):
+            ids, probs = self._engine().classify_images(images)
+            return (ids, probs) if self.optimized_inference else ids
+        prepared = []
+        for im in images:
+            im = self.center_crop(np.asarray(im))
+            if im.shape[0] != self.im_side or im.shape[1] != self.im_side:
+                im = resize_linear_u8(np.ascontiguousarray(im), self.im_side, self.im_side)
+            prepared.append(np.ascontiguousarray(im))
+        return self.infer(np.stack(prepared, 0))
+
     def train_step(self, x_in, y):
         raise NotImplementedError("training (network.py:158-170) is out of scope of the MI355X inference path")

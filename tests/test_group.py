@@ -41,3 +41,23 @@ def test_group_argument_checks(weights):
         assert rc < 0 and b"out of range" in grp.lib.rn_last_error()
     finally:
         grp.close()
+
+
+def test_group_bench_tool_prints_the_bench_line_for_one_device():
+    """tools/group_bench.py (ctypes only, no torch): the same JSON line as bench.py from the single-process group; on
+    this pool's boxes that is the one-device group -- an 8-GPU node runs the same file with --gpus 8."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "group_bench.py"), "--gpus", "1", "--steps", "3",
+                          "--warmup", "1", "--batch", "16"], capture_output=True, text=True, timeout=600, cwd=root)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config"):
+        assert key in line, key
+    assert line["n_gpus"] == 1 and line["steps"] == 3 and line["unit"] == "images/sec" and line["value"] > 0
+    assert line["parity"]["checked"] and line["parity"]["ids_wrong"] == 0
+    assert "torch" not in out.stderr.lower() or "import" not in out.stderr.lower()

@@ -45,7 +45,7 @@ def _stage_out_names(g):
 FUSED_AWAY = {"s0.bn", "s2.bn"}
 
 
-def _check_stage_outputs(engine, weights, parity_images, skip=()):
+def _check_stage_outputs(engine, weights, parity_images, skip=(), record=None, label=""):
     idx = [14, 30, 2]
     ims = parity_images[idx]
     ref = c_oracle.infer(weights, ims, taps=True)
@@ -62,16 +62,18 @@ def _check_stage_outputs(engine, weights, parity_images, skip=()):
         rel = float(np.abs(got - want).max() / max(np.abs(want).max(), 1e-6))
         report.append((name, rel))
     print(engine.dtype_name, " ".join("%s=%.2e" % r for r in report))
+    if record:
+        record("stage_rel_err_224_%s" % label, engine.dtype_name, {name: rel for name, rel in report})
     for name, rel in report:
         assert rel <= STAGE_TOL[engine.dtype_name], (name, rel, report)
 
 
-def test_stage_outputs_vs_oracle(engine, weights, parity_images):
-    _check_stage_outputs(engine, weights, parity_images, skip=FUSED_AWAY)
+def test_stage_outputs_vs_oracle(engine, weights, parity_images, record):
+    _check_stage_outputs(engine, weights, parity_images, skip=FUSED_AWAY, record=record, label="fused_launches")
 
 
-def test_stage_outputs_vs_oracle_stagewise(engine_stagewise, weights, parity_images):
-    _check_stage_outputs(engine_stagewise, weights, parity_images)
+def test_stage_outputs_vs_oracle_stagewise(engine_stagewise, weights, parity_images, record):
+    _check_stage_outputs(engine_stagewise, weights, parity_images, record=record, label="one_launch_per_stage")
 
 
 @pytest.mark.parametrize("nb", [1, 5, 8, 33, 70])
@@ -103,10 +105,19 @@ def test_cross_stage_fusion_is_bit_identical_to_stage_launches(weights, parity_i
             plain.close()
 
 
-def test_logits_probs_ids_vs_golden(engine, parity_images, golden_parity):
+def test_logits_probs_ids_vs_golden(engine, parity_images, golden_parity, record):
+    errs = []
+    for i in range(0, 40, 8):                  # logits of all 40 images, in chunks of the engine's capacity
+        engine.forward_u8(parity_images[i:i + 8])
+        errs.append(np.abs(engine.tap("d3.relu", 8) - golden_parity["logits_f64"][i:i + 8]).max(1))
+    errs = np.concatenate(errs)
     ids, probs = engine.forward_u8(parity_images)
-    logits = engine.tap("d3.relu", 8)          # last chunk of 8
-    err = np.abs(logits - golden_parity["logits_f64"][32:40]).max()
+    err = errs.max()
+    record("parity_set_40_images_224", engine.dtype_name, {
+        "max_abs_dlogit_vs_fp64": float(err), "mean_abs_dlogit_per_image_max": float(errs.mean()),
+        "max_abs_dprob_vs_fp64": float(np.abs(probs - golden_parity["probs_f64"]).max()),
+        "ids_differing_from_fp64": int((ids != golden_parity["ids"]).sum()),
+        "smallest_top2_margin_fp64": float(golden_parity["top2_margin"].min())})
     assert err <= TOL_LOGITS, err
     safe = golden_parity["top2_margin"] > MARGIN
     assert safe.sum() >= 25
@@ -261,7 +272,7 @@ def test_randomized_batch_256_against_the_f32_hip_path(weights):
         f32.close()
 
 
-def test_random_4096_images_id_agreement_with_the_f32_hip_path(weights):
+def test_random_4096_images_id_agreement_with_the_f32_hip_path(weights, record):
     """4096 random images (uniform noise and block noise of random scale, which reaches several classes) through the
     fused bf16 path against the per-node float32 HIP path: count the disagreeing class ids; every disagreement must be
     a near-tie in float32 (top-2 logit margin below the 16-bit tolerance)."""
@@ -290,6 +301,10 @@ def test_random_4096_images_id_agreement_with_the_f32_hip_path(weights):
         f32.close()
     print("bf16 vs float32 HIP path: %d of %d class ids differ; classes seen %s; margins of the differing ones: %s" % (
         len(disagree), n, seen.tolist(), ["%.3f" % m for _, m in disagree][:20]))
+    record("random_4096_images_224", "bf16_vs_float32_hip_path", {
+        "images": n, "ids_differing": len(disagree), "classes_seen_float32": seen.tolist(),
+        "float32_top2_margins_of_the_differing": [round(m, 4) for _, m in disagree],
+        "largest_margin_of_a_differing_id": max([m for _, m in disagree], default=0.0)})
     assert (seen > 0).sum() >= 2                               # the set is not degenerate
     assert all(m <= MARGIN for _, m in disagree), disagree
     assert len(disagree) <= n // 100
@@ -313,7 +328,7 @@ def test_batch_limits(engine):
 
 # ------------------------------------------------------------------ 600x600 variant (BASELINE config 5)
 @pytest.mark.parametrize("dtype,tol", [("f16", 0.1), ("bf16", 0.1), ("f32", 1e-4)])
-def test_600_variant_vs_golden(weights, dtype, tol):
+def test_600_variant_vs_golden(weights, dtype, tol, record):
     """Large-activation variant: conv/BN weights from the checkpoint, seeded synthetic dense/kernel
     (the shipped one only fits 224).  Exercises column blocks and multi-band launches."""
     import os
@@ -328,6 +343,8 @@ def test_600_variant_vs_golden(weights, dtype, tol):
     try:
         ids, probs = e.forward_u8(ims)
         logits = e.tap("d3.relu", 4)
+        rec = {"max_abs_dlogit_vs_fp64": float(np.abs(logits - g["logits_f64"]).max()),
+               "ids_differing_from_fp64": int((ids != g["ids"]).sum()), "images": int(len(ids))}
         assert np.abs(logits - g["logits_f64"]).max() <= tol
         safe = g["top2_margin"] > (1e-3 if dtype == "f32" else MARGIN)
         np.testing.assert_array_equal(ids[safe], g["ids"][safe])
@@ -335,13 +352,19 @@ def test_600_variant_vs_golden(weights, dtype, tol):
             # stage outputs against the C oracle for one image
             ref = c_oracle.infer(w, ims[1:2], taps=True)
             e.forward_u8(ims[1:2])
+            rels = {}
             for s in e.graph.stages:
                 name = "s%d.%s" % (s.index, "bn2" if s.residual else "bn")
                 if name in FUSED_AWAY:       # computed inside the next stage's kernel: never in HBM
                     continue
                 got, want = e.tap(name, 1), np.asarray(ref["taps"][name])
-                rel = float(np.abs(got - want).max() / max(np.abs(want).max(), 1e-6))
+                rels[name] = float(np.abs(got - want).max() / max(np.abs(want).max(), 1e-6))
+            rec["stage_rel_err"] = rels
+            record("parity_600", dtype, rec)
+            for name, rel in rels.items():
                 assert rel <= STAGE_TOL[dtype] * 1.5, (name, rel)
+        else:
+            record("parity_600", dtype, rec)
     finally:
         e.close()
 

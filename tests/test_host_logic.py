@@ -295,3 +295,50 @@ def test_overlay_text_is_hershey_simplex_strokes_at_the_cv2_anchor():
     np.testing.assert_array_equal(a, b)
     put_text(a, "Kitchen", (50, 500), 1.0, (1, 2, 3))
     assert len(hershey.GLYPHS) >= 76 and all(len(s) >= 2 for _, strokes in hershey.GLYPHS.values() for s in strokes)
+
+
+def test_infer_files_decodes_on_a_pool_and_keeps_list_order(tmp_path, capsys):
+    """The driver loop without a GPU: files are decoded on the thread pool, unreadable ones are reported and skipped,
+    results come back in list order whatever the batch size, and a model object without ``infer_images`` (the
+    reference's own class) gets host-prepared batches through ``infer``."""
+    from roomnet_amd import imageio
+    from roomnet_amd.infer import _infer_files
+    from roomnet_amd.imageops import resize_linear_u8
+
+    class Stub:
+        im_side = 8
+        batches = []
+
+        def center_crop(self, x):
+            h, w, _ = x.shape
+            o = abs((w - h) // 2)
+            return x[:, o:o + h, :] if h < w else (x[o:o + w, :, :] if w < h else x.copy())
+
+        def infer(self, batch):
+            assert batch.dtype == np.uint8 and batch.shape[1:] == (8, 8, 3)
+            Stub.batches.append(len(batch))
+            ids = batch[:, 0, 0, 0].astype(np.int64) % 6                  # "class" = a pixel of the prepared image
+            probs = np.zeros((len(batch), 6), np.float32)
+            probs[np.arange(len(batch)), ids] = 0.5
+            return ids, probs
+
+    rng = np.random.default_rng(3)
+    paths, want = [], []
+    for k in range(11):
+        p = tmp_path / ("f_%02d.png" % k)
+        if k in (4, 9):
+            p.write_bytes(b"junk")
+        else:
+            h, w = int(rng.integers(8, 40)), int(rng.integers(8, 40))
+            im = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+            assert imageio.imwrite(str(p), im)
+            c = Stub().center_crop(im)
+            prep = c if c.shape[0] == 8 else resize_linear_u8(np.ascontiguousarray(c), 8, 8)
+            want.append((k, int(prep[0, 0, 0]) % 6))
+        paths.append(str(p))
+    for bs, threads in ((3, 4), (64, 1)):
+        Stub.batches = []
+        got = [(i, idx) for i, _im, idx, _conf in _infer_files(Stub(), paths, bs, decode_threads=threads)]
+        assert got == want
+        assert Stub.batches == ([3, 3, 3] if bs == 3 else [9])
+    assert capsys.readouterr().out.count("unreadable image, skipped") == 4

@@ -168,3 +168,63 @@ def test_groundtruth_validation_from_a_list_file(nn, weights, parity_images, tmp
     np.testing.assert_allclose(stats["precisions"], prec)
     np.testing.assert_allclose(stats["recalls"], rec)
     np.testing.assert_allclose(stats["f-scores"], fsc)
+
+
+def _mixed_size_set(parity_images):
+    """Images of the sizes a real directory holds, made from the parity set by Pillow resampling (content only: what the
+    drivers must reproduce is the crop + resize of THESE pixels): landscape, portrait, 1080p, the exact-2x case, an
+    up-scale, and one that needs neither crop nor resize."""
+    from PIL import Image
+    sizes = [(300, 400), (500, 375), (1080, 1920), (448, 448), (100, 150), (224, 224)]       # (h, w)
+    pick = [1, 9, 14, 22, 30, 38]
+    out = []
+    for (h, w), i in zip(sizes, pick):
+        im = Image.fromarray(parity_images[i]).resize((w, h), Image.BICUBIC)
+        out.append(np.ascontiguousarray(np.asarray(im, dtype=np.uint8)))
+    return out
+
+
+def _expected_prepared(im):
+    """centre crop + cv2.resize of one image by the scalar oracle (the exact-2x case is OpenCV's 2x2 box average)."""
+    from oracle import cv_resize_ref
+    c = np.ascontiguousarray(cv_resize_ref.center_crop(im))
+    if c.shape[0] == 224:
+        return c
+    if c.shape[0] == 448:
+        v = c.astype(np.int32)
+        return ((v[0::2, 0::2] + v[0::2, 1::2] + v[1::2, 0::2] + v[1::2, 1::2] + 2) >> 2).astype(np.uint8)
+    return cv_resize_ref.resize_linear_u8_scalar(c, 224, 224)
+
+
+def test_directory_drivers_feed_mixed_size_images_through_the_gpu_pipeline(nn, weights, parity_images, tmp_path, capsys):
+    """classify_im_dir and groundtruth_validation hand the decoded images to the GPU as they are (crop + resize there,
+    decode on a thread pool): ids and confidences equal those of the scalar cv2.resize restatement + the C oracle."""
+    from roomnet_amd.infer import CLASS_LABELS, classify_im_dir, groundtruth_validation
+    ims = _mixed_size_set(parity_images)
+    prepared = np.stack([_expected_prepared(im) for im in ims], 0)
+    ref = c_oracle.infer(weights, prepared)
+    # the model's own batched entry for images of any size
+    ids, probs = nn.infer_images(ims)
+    np.testing.assert_array_equal(ids, ref["ids"])
+    np.testing.assert_allclose(probs, ref["probs"], atol=1e-5, rtol=0)
+    d = tmp_path / "mixed"
+    d.mkdir()
+    for k, im in enumerate(ims):
+        assert imageio.imwrite(str(d / ("m_%d.png" % k)), im)
+    (d / "broken.jpg").write_bytes(b"\xff\xd8 not a jpeg")
+    xl = classify_im_dir(nn, str(d), overlay=False, batch_size=4)
+    out = capsys.readouterr().out
+    assert "unreadable image" in out
+    cells = read_xls(xl)["classification_results"]
+    rows = {cells[(r, 0)]: (cells[(r, 1)], float(cells[(r, 2)])) for r in {r for r, _ in cells} if r > 0}
+    assert len(rows) == len(ims)
+    for k in range(len(ims)):
+        label, conf = rows["m_%d.png" % k]
+        assert label == CLASS_LABELS[ref["ids"][k]]
+        assert abs(conf - ref["probs"][k, ref["ids"][k]]) <= 1e-5
+        assert os.path.isfile(str(d) + "_classified" + os.sep + label + os.sep + "m_%d.png" % k)
+    lst = tmp_path / "mixed_list.txt"
+    lst.write_text("".join("%s %d\n" % (d / ("m_%d.png" % k), int(ref["ids"][k]) if k % 2 else 5) for k in range(len(ims))))
+    stats = groundtruth_validation(nn, str(lst), batch_size=4)
+    truth = [int(ref["ids"][k]) if k % 2 else 5 for k in range(len(ims))]
+    assert stats["accuracy"] == pytest.approx(float(np.mean(np.array(truth) == ref["ids"])))
