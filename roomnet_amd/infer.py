@@ -66,7 +66,7 @@ def _classify(nn, ims):
     return outs if isinstance(outs, tuple) else (outs, None)
 
 
-DECODE_THREADS = min(8, os.cpu_count() or 1)
+DECODE_THREADS = min(16, os.cpu_count() or 1)
 
 
 def _infer_files(nn, fpaths, batch_size, decode_threads=None):

@@ -16,7 +16,9 @@ pytestmark = pytest.mark.gpu
 
 TOL_LOGITS = 0.1
 MARGIN = 0.2
-STAGE_TOL = {"bf16": 0.04, "f16": 0.006}    # max |err| / absmax of the stage output
+# max |err| / absmax of the stage output.  Observed (profiles/r3_parity.json): bf16 <= 0.0067 at 224 and <= 0.0059 at 600,
+# f16 <= 0.0048 / 0.0024: the bounds sit at about twice that (round 2 carried 0.04 for bf16)
+STAGE_TOL = {"bf16": 0.0125, "f16": 0.006}
 
 
 @pytest.fixture(scope="module", params=["bf16", "f16"])
@@ -235,7 +237,7 @@ def test_full_batch_256_properties(weights, parity_images, golden_parity, dtype)
         small.close()
 
 
-def test_randomized_batch_256_against_the_f32_hip_path(weights):
+def test_randomized_batch_256_against_the_f32_hip_path(weights, record):
     """256 random images (uniform noise, blurred noise, extremes) through the fused bf16 path at bench size vs the
     per-node float32 HIP path: every image's logits within the 16-bit tolerance and the late stage outputs finite and
     close everywhere -- a localized corruption (one tile-row of one workgroup) cannot hide in a maximum over 40 images."""
@@ -255,7 +257,7 @@ def test_randomized_batch_256_against_the_f32_hip_path(weights):
         s7 = big.tap("s7.bn", 256)
         s3 = big.tap("s3.bn2", 256)
         assert np.isfinite(logits).all() and np.isfinite(s7).all() and np.isfinite(s3).all()
-        worst = 0.0
+        worst = worst_stage = 0.0
         for i in range(0, 256, 32):
             f32.forward_u8(ims[i:i + 32])
             ref_logits = f32.tap("d3.relu", 32)
@@ -264,7 +266,9 @@ def test_randomized_batch_256_against_the_f32_hip_path(weights):
             worst = max(worst, float(np.abs(logits[i:i + 32] - ref_logits).max()))
             for got, want in ((s7[i:i + 32], ref_s7), (s3[i:i + 32], ref_s3)):
                 per_image = np.abs(got - want).reshape(32, -1).max(1) / max(float(np.abs(want).max()), 1e-6)
-                assert per_image.max() <= STAGE_TOL["bf16"], (i, per_image.argmax(), per_image.max())
+                worst_stage = max(worst_stage, float(per_image.max()))
+                assert per_image.max() <= 2 * STAGE_TOL["bf16"], (i, per_image.argmax(), per_image.max())
+        record("random_256_images_224", "bf16_vs_float32_hip_path", {"max_abs_dlogit": worst, "max_stage_rel_err_s3_s7": worst_stage})
         assert worst <= TOL_LOGITS, worst
         np.testing.assert_allclose(probs.sum(1), 1.0, atol=1e-5)
     finally:

@@ -51,6 +51,7 @@ def main():
     graph = build_graph(6, args.side)
     grp = _capi.Group(graph, weights, devices=list(range(N)), dtype=dtype, max_batch_per_device=B)
     lib = grp.lib
+    C.CDLL(None).fflush(None)      # librccl prints a banner through C stdio: out now, so the JSON line stays the last line of stdout
     parity = check_parity(grp.forward_u8, args.side, dtype, B * N)
     # resident shards: device d holds its own seeded batch
     shards = (C.c_void_p * N)()
@@ -106,8 +107,9 @@ def main():
            "parity": parity,
            "path": {"algorithmic_bytes_per_image": int(bytes_per_img), "hbm_frac": value * bytes_per_img / (N * HBM_PEAK),
                     "mfma_frac": value * graph.flops_per_image() / (N * MFMA_PEAK_16)}}
-    print(json.dumps(out), flush=True)
     grp.close()
+    C.CDLL(None).fflush(None)
+    print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

@@ -14,7 +14,7 @@ import sys
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 out = os.path.abspath(sys.argv[1] if len(sys.argv) > 1 else os.path.join(root, "gpurun_out", "r3", "parity.json"))
 os.makedirs(os.path.dirname(out), exist_ok=True)
-select = ("test_stage_outputs_vs_oracle or test_logits_probs_ids_vs_golden or test_random_4096_images_id_agreement "
+select = ("test_stage_outputs_vs_oracle or test_logits_probs_ids_vs_golden or test_random_4096_images_id_agreement or test_randomized_batch_256 "
           "or test_600_variant_vs_golden")
 rc = subprocess.call([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_hip_fused.py"), "-q", "-m", "gpu",
                       "-k", select], env=dict(os.environ, RN_PARITY_REPORT=out), cwd=root)
