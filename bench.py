@@ -160,7 +160,9 @@ def cpu_baseline(weights, side):
             "sample": "uniform-noise %dx%d images; mode A = batch-1 loop (infer.py:79-82), mode B = one batch of 8; %d threads "
                       "(of %d usable cores) and 1 thread; median of 3 repetitions within ~3 s per mode; torch-CPU restatement "
                       "(oracle/torch_ref.py, MKL-DNN conv) and plain-C restatement (oracle/tf_ops.c, OpenMP, %d threads) of "
-                      "the reference graph, fp32; %.1f s in all. `value` = the fastest mode. CPU restatement of the "
+                      "the reference graph, fp32; %.1f s in all. `value` = the fastest mode. c_batch8_allthreads is the "
+                      "oracle's NAIVE direct loops (written to be read against the reference, not tuned: no blocking, no "
+                      "im2col/GEMM) -- a checker's rate, not what these cores can do. CPU restatement of the "
                       "reference, not TensorFlow, and not the optimisation target"
                       % (side, side, many, avail, c_threads, el)}
 
