@@ -278,7 +278,7 @@ int alloc_buffers(rn_handle* h) {
             if (fused) {
                 if (id == out_node) {
                     n.dtype = h->dtype;
-                    if ((rc = dev_alloc(h, nb * node_elems(n) * dtype_size(h->dtype) + 256, &p)) != RN_OK) return rc;
+                    if ((rc = dev_alloc(h, nb * node_elems(n) * dtype_size(h->dtype) + 8192, &p)) != RN_OK) return rc;
                     n.ptr = p;
                 }
                 continue;

@@ -27,6 +27,19 @@
 
 using namespace rnk;
 
+// Register class of the lane-constant MFMA operands (weight fragments, pooling band matrix, interpolation weights).
+// With NO "a" constraint anywhere in the kernel LLVM's attributor marks it amdgpu-no-agpr and the allocator gets one flat
+// file of 256 VGPRs per wave; with any "a" constraint it splits the wave's 256 registers 128 + 128 between architectural
+// and accumulator registers, and everything the VALU touches has to fit the 128 (spilled to AGPRs and copied back:
+// 300-500 v_accvgpr moves in this kernel).  -DRN_X_AGPR_PIN restores the pinned form for A/B timing.
+#ifdef RN_X_AGPR_PIN
+#define RN_WREG_OUT(x) "=a"(x)
+#define RN_WREG_IO(x) "+a"(x)
+#else
+#define RN_WREG_OUT(x) "=v"(x)
+#define RN_WREG_IO(x) "+v"(x)
+#endif
+
 namespace {
 
 constexpr int F_NA = 4, F_NB = 4, F_NSK = 3;     // ring depths: A rows, B rows, private skip rows
@@ -76,7 +89,10 @@ __device__ __forceinline__ unsigned long long stamp23() {
 // handful of spilled registers costs 25 % and hipcc says nothing.
 template <int DT>
 __global__ __launch_bounds__(512, 2) void stage23pc_kernel(const Stage23Args a) {
-    constexpr int KC = 18, BAHEAD = 4;
+    #ifndef RN_X_BAHEAD
+#define RN_X_BAHEAD 4
+#endif
+    constexpr int KC = 18, BAHEAD = RN_X_BAHEAD;
     extern __shared__ __attribute__((aligned(64))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -115,10 +131,12 @@ __global__ __launch_bounds__(512, 2) void stage23pc_kernel(const Stage23Args a) 
             }
             pmw[c][d] = static_cast<int>(w);
         }
-    asm volatile("" : "+a"(pmw[0]), "+a"(pmw[1]));
+    asm volatile("" : RN_WREG_IO(pmw[0]), RN_WREG_IO(pmw[1]));
 
     // fragment read of K-chunk kc, conv row whose first input row sits in ring slot S0 (inline asm, counted lgkmcnt)
-    auto chain = [&](auto S0C, auto ROWBC, const unsigned (&base)[3][2], const i32x4 (&wr)[KC], f32x16& accn) __attribute__((always_inline)) {
+    // `hook(IC<I>)` runs right behind chain MFMA I: DMA issue and scalar bookkeeping ride in the MFMAs' shadow there instead
+    // of standing in front of the chain (an LDS-DMA piece costs ~60-180 cycles to issue, a float -> readfirstlane round trip ~40)
+    auto chain = [&](auto S0C, auto ROWBC, const unsigned (&base)[3][2], const i32x4 (&wr)[KC], f32x16& accn, auto&& hook) __attribute__((always_inline)) {
         constexpr int S0 = decltype(S0C)::value, ROWB_ = decltype(ROWBC)::value;
         const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         i32x4 bq[KC];
@@ -137,6 +155,7 @@ __global__ __launch_bounds__(512, 2) void stage23pc_kernel(const Stage23Args a) 
                  constexpr int newer = (KC - 1 - I) < BAHEAD ? (KC - 1 - I) : BAHEAD;
                  asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(bq[I]) : "n"(newer));
                  accn = mfma32<DT>(bq[I], wr[I], I == 0 ? zero : accn);      // D'[pixel][cout]
+                 hook(IC<I>{});
              }()),
              ...);
         }(std::make_integer_sequence<int, KC>{});
@@ -170,24 +189,27 @@ __global__ __launch_bounds__(512, 2) void stage23pc_kernel(const Stage23Args a) 
     // (1 step in 20) a second new row is needed whose slot is still being read: the CONSUMER fetches that one itself at
     // the start of step t+1 and waits for it before its first epilogue.
     const int xs0 = a.rlo[x0 + min(58 * wq, Wo - 1)];     // first skip column of this wave's tile pair (full-width index)
-    unsigned sk_goff[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int q = lane + 64 * i;
-        const int p = q >> 2, c = q & 3;
-        sk_goff[i] = static_cast<unsigned>(min(xs0 + p, Win - 1) * 64 + ((c ^ swz4(p)) << 4));
-    }
+    // piece i of a skip row = pixels xs0 + lane / 4 + 16 i (the chunk swizzle has period 16 pixels): one lane offset, the
+    // 1024 bytes per piece go into the scalar row base.  Pixels right of the image are NOT clamped: they read on into the
+    // next row (the last row of the last image: into the 8 KB of slack behind every activation tensor, rn_api.hip) and
+    // feed only output columns right of the image, which are never stored.
+    const unsigned sk_goff0 = static_cast<unsigned>((xs0 + (lane >> 2)) * 64 + (((lane & 3) ^ swz4(lane >> 2)) << 4));
     char* const skw = smem + F_SKIP_OFF + wq * (F_NSK * F_SKROW);
     const unsigned skw_lds = lds_addr(skw);
-    auto issue_skip_row = [&](int y, int slot) __attribute__((always_inline)) {
+    auto issue_skip_piece = [&](auto IC_, int y, int slot) __attribute__((always_inline)) {
+        constexpr int i = decltype(IC_)::value;
         const char* row = in_img + static_cast<int64_t>(y) * static_cast<int64_t>(Win * 64);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            unsigned off = sk_goff[i];
-            asm volatile("" : "+v"(off));
-            dma16(row + off, skw + slot * F_SKROW + i * 1024);
-        }
+        unsigned off = sk_goff0;
+        asm volatile("" : "+v"(off));
+        dma16(row + i * 1024 + off, skw + slot * F_SKROW + i * 1024);
     };
+    auto issue_skip_row = [&](int y, int slot) __attribute__((always_inline)) {
+        issue_skip_piece(IC<0>{}, y, slot);
+        issue_skip_piece(IC<1>{}, y, slot);
+        issue_skip_piece(IC<2>{}, y, slot);
+        issue_skip_piece(IC<3>{}, y, slot);
+    };
+    auto no_hook = [](auto) __attribute__((always_inline)) {};
     struct VLerp {
         int ylo;
         float yl;
@@ -215,7 +237,7 @@ __global__ __launch_bounds__(512, 2) void stage23pc_kernel(const Stage23Args a) 
 #pragma unroll
         for (int kc = 0; kc < KC; ++kc) {
             const i32x4* src = a.wfrag2 + kc * 64 + lane;
-            asm volatile("global_load_dwordx4 %0, %1, off" : "=a"(w2[kc]) : "v"(src) : "memory");
+            asm volatile("global_load_dwordx4 %0, %1, off" : RN_WREG_OUT(w2[kc]) : "v"(src) : "memory");
         }
         // ---- A rows: four DMA pieces per producer wave and row (a piece is 64 lanes x 16 B, the fourth is the masked W-192 tail)
         const int ptid = wq * 64 + lane;
@@ -264,9 +286,10 @@ __global__ __launch_bounds__(512, 2) void stage23pc_kernel(const Stage23Args a) 
 #pragma unroll
         for (int T = 0; T < 2; ++T) hp[T][0] = hp[T][1] = q0[T][0] = q0[T][1] = q1[T][0] = q1[T][1] = i32x4{0, 0, 0, 0};
         issue_A_pieces(IC<0>{}, IC<4>{}, a_next, 0);
+        int ylo_nxt = ylo_step(0);                       // lo skip row of the output row the coming step finishes
         wait_vmcnt<0>();
 #pragma unroll
-        for (int kc = 0; kc < KC; ++kc) asm volatile("" : "+a"(w2[kc]));
+        for (int kc = 0; kc < KC; ++kc) asm volatile("" : RN_WREG_IO(w2[kc]));
         lds_barrier();
 
         const unsigned tabl_lds = lds_addr(tab + 4 * hh);
@@ -293,9 +316,16 @@ __global__ __launch_bounds__(512, 2) void stage23pc_kernel(const Stage23Args a) 
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const f32x4 sc = tsc[g], sh = tsh[g];
+#ifdef RN_X_SCALAR_FMA
+                float yv[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) yv[j] = __builtin_fmaf(H[4 * g + j], sc[j], sh[j]);
+                const i32x2 d = {static_cast<int>(pack2<DT>(yv[0], yv[1])), static_cast<int>(pack2<DT>(yv[2], yv[3]))};
+#else
                 const f32x2 y0 = pk_fma(f32x2{H[4 * g], H[4 * g + 1]}, f32x2{sc[0], sc[1]}, f32x2{sh[0], sh[1]});
                 const f32x2 y1 = pk_fma(f32x2{H[4 * g + 2], H[4 * g + 3]}, f32x2{sc[2], sc[3]}, f32x2{sh[2], sh[3]});
                 const i32x2 d = {static_cast<int>(pack2<DT>(y0[0], y0[1])), static_cast<int>(pack2<DT>(y1[0], y1[1]))};
+#endif
                 asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(wb[T] ^ static_cast<unsigned>(g << 4)), "v"(d), "n"(off) : "memory");
             }
         };
@@ -305,26 +335,43 @@ __global__ __launch_bounds__(512, 2) void stage23pc_kernel(const Stage23Args a) 
         auto step = [&](auto PC, int t) __attribute__((always_inline)) {
             constexpr int P = decltype(PC)::value;
             if (t < nrows + 9) a_next += Win * 64;
-            issue_A_pieces(IC<0>{}, IC<4>{}, a_next, (P + 1) % F_NA);            // A row t+1
-            {
-                // skip rows of the partner consumer (see the schedule above)
-                const int need_cur = min(ylo_step(t) + 1, Win - 1);
-                if (sk_f < need_cur) {                      // the consumer fetches this one itself (lo row jumped by 2)
-                    ++sk_f;
-                    sk_slot = sk_slot == F_NSK - 1 ? 0 : sk_slot + 1;
+            // A row t+1: one DMA piece behind every fourth MFMA of the first chain.  Skip rows of the partner consumer (see the
+            // schedule above): decided behind the first MFMAs, fetched behind those of the second chain; when no new row is
+            // due the newest one is fetched again into its own slot (same bytes), so the step has no branch around a DMA
+            auto hook0 = [&](auto IC_) __attribute__((always_inline)) {
+                constexpr int i = decltype(IC_)::value;
+                if constexpr (i == 0) issue_A_pieces(IC<0>{}, IC<1>{}, a_next, (P + 1) % F_NA);
+                if constexpr (i == 4) issue_A_pieces(IC<1>{}, IC<2>{}, a_next, (P + 1) % F_NA);
+                if constexpr (i == 8) issue_A_pieces(IC<2>{}, IC<3>{}, a_next, (P + 1) % F_NA);
+                if constexpr (i == 12) issue_A_pieces(IC<3>{}, IC<4>{}, a_next, (P + 1) % F_NA);
+                if constexpr (i == 2) {
+                    const int need_cur = min(ylo_nxt + 1, Win - 1);              // ylo_nxt: lo row of this step's output row
+                    if (sk_f < need_cur) {                  // the consumer fetches this one itself (lo row jumped by 2)
+                        ++sk_f;
+                        sk_slot = sk_slot == F_NSK - 1 ? 0 : sk_slot + 1;
+                    }
                 }
-                const int need_next = min(ylo_step(t + 1) + 1, Win - 1);
-                if (sk_f < need_next) {
-                    ++sk_f;
-                    sk_slot = sk_slot == F_NSK - 1 ? 0 : sk_slot + 1;
-                    issue_skip_row(sk_f, sk_slot);
+                if constexpr (i == 6) {
+                    ylo_nxt = ylo_step(t + 1);
+                    const int need_next = min(ylo_nxt + 1, Win - 1);
+                    if (sk_f < need_next) {
+                        ++sk_f;
+                        sk_slot = sk_slot == F_NSK - 1 ? 0 : sk_slot + 1;
+                    }
                 }
-            }
+            };
+            auto hook1 = [&](auto IC_) __attribute__((always_inline)) {
+                constexpr int i = decltype(IC_)::value;
+                if constexpr (i == 1) issue_skip_piece(IC<0>{}, sk_f, sk_slot);
+                if constexpr (i == 5) issue_skip_piece(IC<1>{}, sk_f, sk_slot);
+                if constexpr (i == 9) issue_skip_piece(IC<2>{}, sk_f, sk_slot);
+                if constexpr (i == 13) issue_skip_piece(IC<3>{}, sk_f, sk_slot);
+            };
             f32x16 acc;
 #ifdef RN_STAMPS
             const unsigned long long tp0 = stamp23();
 #endif
-            chain(IC<(P + 2) % 4>{}, IC<F_ROWA>{}, baseA[0], w2, acc);     // conv row t-2: A rows t-2 .. t
+            chain(IC<(P + 2) % 4>{}, IC<F_ROWA>{}, baseA[0], w2, acc, hook0);     // conv row t-2: A rows t-2 .. t
 #ifdef RN_STAMPS
             const unsigned long long tp1 = stamp23();
 #endif
@@ -332,7 +379,7 @@ __global__ __launch_bounds__(512, 2) void stage23pc_kernel(const Stage23Args a) 
 #ifdef RN_STAMPS
             const unsigned long long tp2 = stamp23();
 #endif
-            chain(IC<(P + 2) % 4>{}, IC<F_ROWA>{}, baseA[1], w2, acc);
+            chain(IC<(P + 2) % 4>{}, IC<F_ROWA>{}, baseA[1], w2, acc, hook1);
 #ifdef RN_STAMPS
             const unsigned long long tp3 = stamp23();
 #endif
@@ -389,7 +436,7 @@ __global__ __launch_bounds__(512, 2) void stage23pc_kernel(const Stage23Args a) 
 #pragma unroll
     for (int kc = 0; kc < KC; ++kc) {
         const i32x4* src = a.wfrag3 + kc * 64 + lane;
-        asm volatile("global_load_dwordx4 %0, %1, off" : "=a"(w3[kc]) : "v"(src) : "memory");
+        asm volatile("global_load_dwordx4 %0, %1, off" : RN_WREG_OUT(w3[kc]) : "v"(src) : "memory");
     }
     unsigned baseB[2][3][2], a_off[2][2];
     int voff[2];
@@ -434,7 +481,7 @@ __global__ __launch_bounds__(512, 2) void stage23pc_kernel(const Stage23Args a) 
             a_off[T][t2] = skw_lds + static_cast<unsigned>((pix * 4 + (ch ^ swz4(pix))) * 16 + (pp & 1) * 8);
         }
     }
-    asm volatile("" : "+a"(bw[0][0]), "+a"(bw[0][1]), "+a"(bw[1][0]), "+a"(bw[1][1]));
+    asm volatile("" : RN_WREG_IO(bw[0][0]), RN_WREG_IO(bw[0][1]), RN_WREG_IO(bw[1][0]), RN_WREG_IO(bw[1][1]));
     const int out_row_bytes = Hout * 64;
     const char* out_row = reinterpret_cast<const char*>(a.out + static_cast<int64_t>(n) * Hout * Hout * 32) + static_cast<int64_t>(yo0) * out_row_bytes;
     i32x4 hp[2][2], q0[2][2], q1[2][2];
@@ -447,6 +494,7 @@ __global__ __launch_bounds__(512, 2) void stage23pc_kernel(const Stage23Args a) 
         int emit_mask;
     };
     VLerp vl_cur = vlerp_of(yo0);
+    VLerp vl_pre = vl_cur;                                // interpolation of the NEXT step's output row, one step ahead
     int slot_cur = 0;
     RowCtx cx_cur{};
     cx_cur.emit_mask = OOB;
@@ -456,7 +504,7 @@ __global__ __launch_bounds__(512, 2) void stage23pc_kernel(const Stage23Args a) 
     for (int g = 0; g < 16; ++g) acc1[g] = 0.f;
     wait_vmcnt<0>();                                      // the weight fragments have landed
 #pragma unroll
-    for (int kc = 0; kc < KC; ++kc) asm volatile("" : "+a"(w3[kc]));
+    for (int kc = 0; kc < KC; ++kc) asm volatile("" : RN_WREG_IO(w3[kc]));
     lds_barrier();
 
     const unsigned tabl_lds = lds_addr(tab + 64 + 4 * hh);
@@ -484,15 +532,39 @@ __global__ __launch_bounds__(512, 2) void stage23pc_kernel(const Stage23Args a) 
             asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(t2[g]) : "v"(ta), "n"(128 + 32 * g));
             asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(t3[g]) : "v"(ta), "n"(256 + 32 * g));
         };
-        const f32x16 H = pool(PRC, acce, hp[T], q0[T], q1[T]);
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(tq[0]), "+v"(tq[1]), "+v"(tq[2]), "+v"(tq[3]), "+v"(tq[4]), "+v"(tq[5]), "+v"(tq[6]), "+v"(tq[7]));
+        // Pooling and residual MFMAs in the order their operands become available, so that the matrix pipe works while the
+        // VALU packs: the two pooling MFMAs that only take the history (q of two rows ago) go first, the four residual MFMAs
+        // follow as soon as the transposed reads are back, the two pooling MFMAs of the new row close the sequence.  (Same
+        // accumulation order of H as pool(): bit-identical.)
+        constexpr int PR = decltype(PRC)::value;
         const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        i32x4(&qold)[2] = PR == 0 ? q0[T] : q1[T];
+        f32x16 H = mfma32<RN_DTYPE_F16>(qold[0], pmw[0], zero);
+        H = mfma32<RN_DTYPE_F16>(qold[1], pmw[1], H);
+        i32x4 qp[2];
+        auto pack_half = [&](auto HC) __attribute__((always_inline)) {
+            constexpr int hf = decltype(HC)::value;
+            auto& hpT = hp[T];
+#pragma unroll
+            for (int i2 = 8 * hf; i2 < 8 * hf + 8; i2 += 2) {
+                const int vp = static_cast<int>(pack2<RN_DTYPE_F16>(relu6f(acce[i2]), relu6f(acce[i2 + 1])));
+                qp[hf][(i2 % 8) / 2] = pk_add_f16(hpT[hf][(i2 % 8) / 2], vp);
+                hpT[hf][(i2 % 8) / 2] = vp;
+            }
+        };
+        pack_half(IC<0>{});
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(tq[0]), "+v"(tq[1]), "+v"(tq[2]), "+v"(tq[3]), "+v"(tq[4]), "+v"(tq[5]), "+v"(tq[6]), "+v"(tq[7]));
         const i32x4 al0 = {tq[0][0], tq[0][1], tq[1][0], tq[1][1]}, al1 = {tq[2][0], tq[2][1], tq[3][0], tq[3][1]};
         const i32x4 ah0 = {tq[4][0], tq[4][1], tq[5][0], tq[5][1]}, ah1 = {tq[6][0], tq[6][1], tq[7][0], tq[7][1]};
         f32x16 r_lo = mfma32<DT>(al0, bw[T][0], zero);
         f32x16 r_hi = mfma32<DT>(ah0, bw[T][0], zero);
         r_lo = mfma32<DT>(al1, bw[T][1], r_lo);
         r_hi = mfma32<DT>(ah1, bw[T][1], r_hi);
+        pack_half(IC<1>{});
+        H = mfma32<RN_DTYPE_F16>(qp[0], pmw[0], H);
+        H = mfma32<RN_DTYPE_F16>(qp[1], pmw[1], H);
+        qold[0] = qp[0];
+        qold[1] = qp[1];
         uint2 pk[4];
         tab_issue(IC<0>{});
         // folded-BN table entries of channel group g: read by inline asm one group ahead of their use and retired by a
@@ -514,6 +586,18 @@ __global__ __launch_bounds__(512, 2) void stage23pc_kernel(const Stage23Args a) 
              [&] {
             constexpr int g = G;
             const f32x4 sc1 = tsc1[g], sh1 = tsh1[g], sc2 = tsc2[g];
+#ifdef RN_X_SCALAR_FMA
+            float yv[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float y1 = __builtin_fmaf(H[4 * g + j], sc1[j], sh1[j]);
+                const float lo = r_lo[4 * g + j];
+                const float rs = __builtin_fmaf(r_hi[4 * g + j] - lo, cx.yl, lo);
+                yv[j] = __builtin_fmaf(rs, sc2[j], y1);
+            }
+            pk[g].x = pack2<DT>(yv[0], yv[1]);
+            pk[g].y = pack2<DT>(yv[2], yv[3]);
+#else
             f32x2 y[2];
             const f32x2 ylv = pk_splat(cx.yl);
 #pragma unroll
@@ -527,6 +611,7 @@ __global__ __launch_bounds__(512, 2) void stage23pc_kernel(const Stage23Args a) 
             }
             pk[g].x = pack2<DT>(y[0][0], y[0][1]);
             pk[g].y = pack2<DT>(y[1][0], y[1][1]);
+#endif
              }()),
              ...);
         }(std::make_integer_sequence<int, 4>{});
@@ -562,7 +647,7 @@ __global__ __launch_bounds__(512, 2) void stage23pc_kernel(const Stage23Args a) 
 #endif
         // skip rows: the rare second new row of a step whose lo row jumped by 2 is fetched here; the regular one for the
         // next step is fetched by the partner producer during this step (mirrored in sk_f / sk_slot)
-        const VLerp vl_next = vlerp_of(yo0 + min(max(jo + 1, 0), nrows - 1));
+        const VLerp vl_next = vl_pre;                  // (computed behind the previous step's second chain)
         {
             const int need_cur = min(vl_cur.ylo + 1, Win - 1);
             if (sk_f < need_cur) {
@@ -582,7 +667,7 @@ __global__ __launch_bounds__(512, 2) void stage23pc_kernel(const Stage23Args a) 
         const unsigned long long tc2 = tc1;
 #endif
         f32x16 acc0;
-        chain(IC<P>{}, IC<F_ROWB>{}, baseB[0], w3, acc0);       // conv row t-8: B rows t-8 .. t-6
+        chain(IC<P>{}, IC<F_ROWB>{}, baseB[0], w3, acc0, no_hook);       // conv row t-8: B rows t-8 .. t-6
 #ifdef RN_STAMPS
         const unsigned long long tc3 = stamp23();
         st_seg[2] += tc3 - tc2;
@@ -597,7 +682,11 @@ __global__ __launch_bounds__(512, 2) void stage23pc_kernel(const Stage23Args a) 
         const unsigned long long tc5 = stamp23();
         st_seg[4] += tc5 - tc4;
 #endif
-        chain(IC<P>{}, IC<F_ROWB>{}, baseB[1], w3, acc1);
+        // the next step's vertical interpolation (float multiply -> floor -> two readfirstlanes) rides behind this chain's MFMAs
+        auto hook_c1 = [&](auto IC_) __attribute__((always_inline)) {
+            if constexpr (decltype(IC_)::value == 2) vl_pre = vlerp_of(yo0 + min(max(jo + 2, 0), nrows - 1));
+        };
+        chain(IC<P>{}, IC<F_ROWB>{}, baseB[1], w3, acc1, hook_c1);
         epi(IC<1>{}, IC<PR>{}, acc1, cx_cur);
 #ifdef RN_STAMPS
         st_seg[5] += stamp23() - tc5;
