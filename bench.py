@@ -211,6 +211,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-steps", type=int, default=5)
     ap.add_argument("--event-steps", type=int, default=30, help="iterations of the per-step hipEvent timing pass (median reported)")
+    ap.add_argument("--pair32", action="store_true", help="fused stage pair on the round-2 32x32x16 kernel (RN_FLAG_PAIR_32X32: comparison arm)")
     ap.add_argument("--no-parity-check", action="store_true", help="skip the golden check (timing experiments with garbage results)")
     ap.add_argument("--stage-launches", action="store_true",
                     help="one launch per conv stage (RN_FLAG_STAGE_LAUNCHES): the unfused comparison arm")
@@ -264,7 +265,7 @@ def main():
             weights["dense/kernel"] = np.random.default_rng(600).uniform(
                 -0.04, 0.04, (graph.flat_len, 32)).astype(np.float32)
         eng = _capi.Engine(graph, weights, device=local_rank, dtype=args.dtype, max_batch=B,
-                           stage_launches=args.stage_launches)
+                           stage_launches=args.stage_launches, pair32=args.pair32)
 
     ims = torch.from_numpy(perf_batch(B, args.side, seed=rank)).to(dev)
     # probs [B,6] fp32 and ids [B] int64 live in ONE byte buffer per rank, so the result exchange is a single

@@ -69,6 +69,10 @@ extern "C" {
                                that only feeds its fused successor is then never written) */
 #define RN_FLAG_GENERIC_KERNELS 4u /* 16-bit handles: every stage on the generic
                                stage_mfma_kernel (diagnostic cross-check of the tuned kernels) */
+#define RN_FLAG_PAIR_32X32 8u /* 16-bit handles: the cross-stage fused pair (last two steps of a
+                               depth-3 conv_block, network.py:183-203) on the round-2 32x32x16 kernel
+                               (rn_stage23.hip) instead of the 16x16x32 one (rn_stage23x.hip):
+                               comparison arm; results differ in the last 16-bit place at most */
 
 #define RN_MAX_STAGES 16
 #define RN_MAX_DENSE 8

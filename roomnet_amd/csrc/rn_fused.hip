@@ -566,6 +566,9 @@ struct FusedState {
     // cross-stage fused pair (rn_stage23.hip): stages pair_first, pair_first + 1 run as one launch
     int pair_first = -1;
     float* pair_ptab = nullptr;  // [5][32]: the first stage's scale, shift | the second stage's scale', shift', scale2
+    bool pair_x16 = false;       // the pair runs on 16x16x32 tiles (rn_stage23x.hip) with the fragments below
+    i32x4* pair_wfrag_a = nullptr;
+    i32x4* pair_wfrag_b = nullptr;
     // stage 0
     unsigned short* s0_lut16 = nullptr;
     int s0_lut_arith = 0;
@@ -784,6 +787,21 @@ int rn_fused_prepare(rn_handle* h, const rn_weights* w) {
             RN_HIP(hipMemcpy(dt, tab.data(), tab.size() * 4, hipMemcpyHostToDevice));
             fs->pair_ptab = static_cast<float*>(dt);
             fs->pair_first = static_cast<int>(i);
+            if (!(h->flags & RN_FLAG_PAIR_32X32)) {
+                for (int which = 0; which < 2; ++which) {
+                    std::vector<unsigned short> f16;
+                    rn_stage23x_pack(w->stages[i + which].kernel, h->dtype, f32_to_bf16, f32_to_f16, &f16);
+                    void* d16 = nullptr;
+                    if (hipMalloc(&d16, f16.size() * 2) != hipSuccess) {
+                        rn_set_error("hipMalloc(fused pair weights) failed");
+                        return RN_E_NOMEM;
+                    }
+                    h->allocs.push_back(d16);
+                    RN_HIP(hipMemcpy(d16, f16.data(), f16.size() * 2, hipMemcpyHostToDevice));
+                    (which ? fs->pair_wfrag_b : fs->pair_wfrag_a) = static_cast<i32x4*>(d16);
+                }
+                fs->pair_x16 = true;
+            }
             break;
         }
     // stage 0 inside stage 1's kernel: the 8-channel register-weights variant computes stage 0 for its own ring columns
@@ -890,8 +908,8 @@ int rn_fused_forward(rn_handle* h, const uint8_t* d_bgr, const float* d_rgb, int
             Stage23Args fa{};
             fa.in = static_cast<const unsigned short*>(h->nodes[prev.node_bn2 >= 0 ? prev.node_bn2 : prev.node_bn].ptr);
             fa.out = static_cast<unsigned short*>(h->nodes[s2.node_bn2].ptr);
-            fa.wfrag2 = f.wfrag;
-            fa.wfrag3 = fs->st[i + 1].wfrag;
+            fa.wfrag2 = fs->pair_x16 ? fs->pair_wfrag_a : f.wfrag;
+            fa.wfrag3 = fs->pair_x16 ? fs->pair_wfrag_b : fs->st[i + 1].wfrag;
             fa.ptab = fs->pair_ptab;
             fa.rlo = s2.rt.lo;
             fa.rhi = s2.rt.hi;
@@ -931,7 +949,7 @@ int rn_fused_forward(rn_handle* h, const uint8_t* d_bgr, const float* d_rgb, int
             std::memset(stamp_host23, 0, nwaves23 * 96);
             fa.stamp_buf = stamp_host23;
 #endif
-            int rc = rn_stage23_launch(h->dtype, h->stream, fa, n);
+            int rc = fs->pair_x16 ? rn_stage23x_launch(h->dtype, h->stream, fa, n) : rn_stage23_launch(h->dtype, h->stream, fa, n);
             if (rc != RN_OK) return rc;
 #ifdef RN_STAMPS
             (void)hipStreamSynchronize(h->stream);

@@ -1,0 +1,572 @@
+// Cross-stage fused kernel for a depth-3 conv_block's last two steps (reference network.py:183-203) on 16x16x32 matrix
+// tiles -- the round-3 successor of stage23pc_kernel (rn_stage23.hip, 32x32x16 tiles), same data flow:
+//
+//   A (block's first BN output = the residual's skip tensor, [N, W, W, 32])
+//     -> conv3x3 32->32 -> ReLU6 -> avg-pool 4/1 -> BN            = B   (never leaves the CU: LDS ring)
+//     -> conv3x3 32->32 -> ReLU6 -> avg-pool 4/1 -> BN -> + legacy-bilinear(A) -> BN   = out [N, W-10, W-10, 32]
+//
+// Same workgroup geometry (image x band of rows x column block, 8 waves: 4 producers run the first stage, 4 consumers the
+// second, wave w and w + 4 share a SIMD), same rings (A 4 rows, B 4 rows, wave-private 3-row skip rings), same step
+// schedule (one A row in, B row t-5 finished, output row t-11 finished, one s_barrier) as rn_stage23.hip.  What changes:
+//
+//  * Pixels are tiled in 16s (v_mfma_f32_16x16x32_{bf16,f16}: one MFMA = 16 pixels x 16 couts x all 32 channels of one
+//    tap).  A wave owns 3 or 4 ADJACENT tiles; the pooling window that crosses a tile border takes its right-hand columns
+//    from the next tile's registers through a second band-matrix MFMA, so tiles inside a wave sit at stride 16 and only
+//    the border between two waves costs the 3 overlap columns of the old stride-29 tiles.  Stage 2's 213 conv columns are
+//    14 tiles (4 + 4 + 3 + 3 over the producers), stage 3's 208 are 14 (3 + 3 + 4 + 4 over the consumers): every SIMD hosts
+//    7 tiles = 112 pixel columns per step where the 32-pixel form hosted 128.
+//  * The two 16-cout halves of a tile are independent accumulators (two MFMA chains interleaved: no dependent-issue
+//    stall), every epilogue object is half the size (a pooled tile is 8 registers, a residual pair 16), and their MFMA
+//    latencies are half as long: the per-wave serial time of a step, which bounds the old kernel (each wave ~95 % busy
+//    at 55 % matrix-pipe duty), shrinks with them.
+//  * Cout order inside a tile is permuted on the host (fragment column n of half h = cout 8 (n / 4) + 4 h + n % 4), so a
+//    lane ends up with 8 CONSECUTIVE couts of one pixel: one 16-byte ds_write / buffer_store per lane and tile, 1 KB
+//    contiguous per wave instruction, no permlane swaps.
+//  * LDS chunk swizzle (pixel >> 1) & 3: conflict-free for the 16x16x32 operand read at every tile alignment
+//    (enumerated over ds_read_b128's lane groups; the 32-pixel form's (pixel >> 2) & 3 is 2-way conflicted here).
+//
+// Arithmetic: the same operations in the same order per output element as the 32x32x16 kernels; the matrix cores add the
+// 288 products of one convolution output tap by tap, 32 channels at a time, where the 32x32x16 form adds them 16 at a
+// time.  On gfx950 the two orders give the SAME bits: every test that compares the fused pair with one launch per stage
+// bit for bit (224, 420 and 600 inputs, 1-4 column blocks, 1-73 bands) passes unchanged with this kernel.
+#include "rn_fused.h"
+#include "rn_stage.h"
+
+#include <atomic>
+#include <utility>
+
+using namespace rnk;
+
+namespace {
+
+constexpr int X_NA = 4, X_NB = 4, X_NSK = 3;     // ring depths: A rows, B rows, private skip rows
+constexpr int X_WMAX = 215;                      // widest A row (column blocks: 193..215, rn_stage23_plan; the tail DMA piece needs W > 192)
+constexpr int X_ROWA = X_WMAX * 64;              // bytes per A ring row (32 channels x 16 bit per pixel)
+constexpr int X_BDUMMY = X_WMAX - 5;             // B ring column that invalid lanes write to (never read for a valid output)
+constexpr int X_ROWB = (X_BDUMMY + 1) * 64;
+constexpr int X_SKROW = 64 * 64;                 // one private skip row: 64 columns
+constexpr int X_NTAB = 5 * 32;                   // folded BN tables: sc2, sh2 | sc3', sh3', sc4
+constexpr int X_RINGA_OFF = 1024;
+constexpr int X_RINGB_OFF = X_RINGA_OFF + X_NA * X_ROWA;
+constexpr int X_SKIP_OFF = X_RINGB_OFF + X_NB * X_ROWB;
+constexpr int X_LDS = X_SKIP_OFF + 4 * X_NSK * X_SKROW;
+constexpr int X_LAG = 11;                        // step t finishes output row t - X_LAG
+constexpr int X_KT = 9;                          // taps = K chunks of 32 (all channels of one tap)
+static_assert(X_LDS <= 160 * 1024, "LDS budget");
+
+// first conv column of each wave's tile run and its length in tiles; consecutive waves overlap by 3 columns (the last
+// tile of a wave has no right neighbour in registers and yields 13 pooled columns)
+__device__ __forceinline__ int xp_start(int w) { return w == 0 ? 0 : w == 1 ? 61 : w == 2 ? 122 : 167; }   // producers: 4 4 3 3 tiles
+__device__ __forceinline__ int xc_start(int w) { return w == 0 ? 0 : w == 1 ? 45 : w == 2 ? 90 : 148; }    // consumers: 3 3 4 4 tiles
+// (consumer 2 ends at column 147, not 150: a consumer interpolates from a 64-column private skip ring, enough for 58
+//  output columns at the block's 215 -> 205 scale)
+
+__device__ __forceinline__ unsigned lds_addr(const void* p) {
+    return static_cast<unsigned>(reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) const char*)p));
+}
+
+__device__ __forceinline__ int swzx(int pix) { return (pix >> 1) & 3; }   // A and B rings (16x16x32 operand reads)
+
+using i32x2 = __attribute__((ext_vector_type(2))) int;
+
+template <int DT>
+__device__ __forceinline__ f32x4 mfma16(i32x4 a, i32x4 b, f32x4 c) {
+    if constexpr (DT == RN_DTYPE_BF16)
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    else
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+
+template <int DT>
+__global__ __launch_bounds__(512, 2) void stage23x_kernel(const Stage23Args a) {
+    constexpr int AHEAD = 3;
+    extern __shared__ __attribute__((aligned(64))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wq = wave & 3;
+    const int px16 = lane & 15, g = lane >> 4;           // tile column / K group (conv operand), pixel / cout group (pooled tiles)
+    const int cblk = blockIdx.x % a.n_cblocks, band = blockIdx.x / a.n_cblocks, n = blockIdx.y;
+    const int Win = a.W, Hout = a.Wo, x0 = a.cb_x0[cblk];
+    const int Wo = a.cb_wo[cblk], W = Wo + 10, Wb = W - 5;
+    const int yo0 = band * a.rows_per_band;
+    const int nrows = min(Hout, yo0 + a.rows_per_band) - yo0;
+    const int nsteps = nrows + X_LAG;
+
+    float* const tab = reinterpret_cast<float*>(smem);
+    for (int i = tid; i < X_NTAB; i += 512) tab[i] = a.ptab[i];
+    char* const ringA = smem + X_RINGA_OFF;
+    char* const ringB = smem + X_RINGB_OFF;
+    const unsigned ringA_lds = lds_addr(ringA), ringB_lds = lds_addr(ringB);
+    const char* const in_img = reinterpret_cast<const char*>(a.in + static_cast<int64_t>(n) * Win * Win * 32);
+    const char* const in_blk = in_img + x0 * 64;
+    constexpr int OOB = 0x40000000;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+
+    // band matrices of the pooling MFMA.  H[cout][xo] = sum_k V[cout][k] * Pm[k][xo]: the A operand of lane (cout, g) is the
+    // lane's own packed history -- K elements 8 g + e are pixel 4 g + (e & 3) of the vertical pair sums two rows back
+    // (e < 4) and of the current row (e >= 4) -- and Pm[k][xo] = 1 where xo <= pixel < xo + 4.  pmx is the same for the
+    // NEXT tile's registers (pixel 16 + 4 g + (e & 3)): the windows of columns 13..15 end there.
+    i32x4 pm, pmx;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        unsigned w0 = 0, w1 = 0;
+#pragma unroll
+        for (int e2 = 0; e2 < 2; ++e2) {
+            const int e = 2 * d + e2;
+            const int p = 4 * g + (e & 3);
+            w0 |= ((p >= px16 && p < px16 + 4) ? 0x3C00u : 0u) << (16 * e2);
+            w1 |= ((16 + p >= px16 && 16 + p < px16 + 4) ? 0x3C00u : 0u) << (16 * e2);
+        }
+        pm[d] = static_cast<int>(w0);
+        pmx[d] = static_cast<int>(w1);
+    }
+    asm volatile("" : "+v"(pm), "+v"(pmx));
+
+    // two interleaved accumulation chains (the tile's two 16-cout halves) over the nine taps; the tap's operand is ONE
+    // ds_read_b128 (16 pixels x 32 channels), issued AHEAD taps early and retired by a counted wait
+    auto chain = [&](auto S0C, auto ROWC, auto KC, const unsigned (&base)[3], const i32x4 (&wr)[2 * X_KT], f32x4 (&acc)[2]) __attribute__((always_inline)) {
+        constexpr int S0 = decltype(S0C)::value, ROW = decltype(ROWC)::value, k = decltype(KC)::value;
+        i32x4 fq[X_KT];
+        auto rd = [&](auto TC, float dep) __attribute__((always_inline)) -> i32x4 {
+            constexpr int tap = decltype(TC)::value, ky = tap / 3, kx = tap % 3;
+            constexpr int off = ((S0 + ky) % 4) * ROW + k * 1024;
+            i32x4 v;
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(base[kx]), "n"(off), "v"(dep));
+            return v;
+        };
+        [&]<int... I>(std::integer_sequence<int, I...>) { ((fq[I] = rd(IC<I>{}, 0.f)), ...); }(std::make_integer_sequence<int, AHEAD>{});
+        [&]<int... I>(std::integer_sequence<int, I...>) {
+            (([&] {
+                 if constexpr (I + AHEAD < X_KT) fq[I + AHEAD] = rd(IC<(I + AHEAD < X_KT ? I + AHEAD : 0)>{}, I == 0 ? 0.f : acc[0][0]);
+                 constexpr int newer = (X_KT - 1 - I) < AHEAD ? (X_KT - 1 - I) : AHEAD;
+                 asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(fq[I]) : "n"(newer));
+                 acc[0] = mfma16<DT>(fq[I], wr[2 * I], I == 0 ? zero4 : acc[0]);          // D'[pixel][cout], couts of half 0
+                 acc[1] = mfma16<DT>(fq[I], wr[2 * I + 1], I == 0 ? zero4 : acc[1]);
+             }()),
+             ...);
+        }(std::make_integer_sequence<int, X_KT>{});
+    };
+    // ReLU6 -> fp16 pairs -> vertical pair sums; the pooling operand of the tile half = [pair sums two rows back | current]
+    auto finish = [&](auto PRC, const f32x4 (&acc)[2], int (&hp)[2][2], int (&q0)[2][2], int (&q1)[2][2], i32x4 (&op)[2]) __attribute__((always_inline)) {
+        constexpr int PR = decltype(PRC)::value;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            int(&qold)[2] = PR == 0 ? q0[h] : q1[h];
+            const int v0 = static_cast<int>(pack2<RN_DTYPE_F16>(relu6f(acc[h][0]), relu6f(acc[h][1])));
+            const int v1 = static_cast<int>(pack2<RN_DTYPE_F16>(relu6f(acc[h][2]), relu6f(acc[h][3])));
+            const int n0 = pk_add_f16(hp[h][0], v0), n1 = pk_add_f16(hp[h][1], v1);
+            hp[h][0] = v0;
+            hp[h][1] = v1;
+            op[h] = i32x4{qold[0], qold[1], n0, n1};
+            qold[0] = n0;
+            qold[1] = n1;
+        }
+    };
+
+    // ---- residual skip rows: schedule as in rn_stage23.hip (the partner producer fetches the regular new row during the
+    // step before it is needed, the consumer itself the rare second one after the lo row jumped by 2)
+    const int xs0 = a.rlo[x0 + min(xc_start(wq), Wo - 1)];     // first skip column of consumer wq's ring (full-width index)
+    // piece i of a skip row = pixels xs0 + lane / 4 + 16 i: one lane offset, 1024 bytes per piece in the scalar base; pixels
+    // right of the image read on into the next row / the slack behind the tensor and only feed columns that are not stored
+    // (no chunk swizzle in the skip rings: a transposed read takes one 8-byte half of every 16-byte chunk it touches, the
+    //  two 16-lane groups of a half-wave are 2-way conflicted whatever the chunk order -- 8 LDS cycles per tile)
+    const unsigned sk_goff0 = static_cast<unsigned>((xs0 + (lane >> 2)) * 64 + ((lane & 3) << 4));
+    char* const skw = smem + X_SKIP_OFF + wq * (X_NSK * X_SKROW);
+    const unsigned skw_lds = lds_addr(skw);
+    auto issue_skip_row = [&](int y, int slot) __attribute__((always_inline)) {
+        const char* row = in_img + static_cast<int64_t>(y) * static_cast<int64_t>(Win * 64);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            unsigned off = sk_goff0;
+            asm volatile("" : "+v"(off));
+            dma16(row + i * 1024 + off, skw + slot * X_SKROW + i * 1024);
+        }
+    };
+    struct VLerp {
+        int ylo;
+        float yl;
+    };
+    auto vlerp_of = [&](int yo) __attribute__((always_inline)) -> VLerp {
+        const float src = mul_rounded(static_cast<float>(yo), a.rscale);
+        const int ylo = static_cast<int>(src);
+        VLerp v;
+        v.ylo = __builtin_amdgcn_readfirstlane(ylo);
+        v.yl = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(src - static_cast<float>(ylo))));
+        return v;
+    };
+    int sk_f = vlerp_of(yo0).ylo - 1;                 // highest skip row fetched so far (by either role)
+    int sk_slot = X_NSK - 1;                          // its ring slot (row y lives in slot (y - ylo(yo0)) mod 3)
+    auto ylo_step = [&](int t) __attribute__((always_inline)) {
+        return vlerp_of(yo0 + min(max(t - X_LAG, 0), nrows - 1)).ylo;
+    };
+
+    if (wave < 4) {
+        // =============================================================== producer: first stage, A ring -> B ring
+        const bool has4 = wq < 2;                                   // tiles of this wave: 4 4 3 3
+        const int xw = xp_start(wq);
+        i32x4 w2[2 * X_KT];
+#pragma unroll
+        for (int f = 0; f < 2 * X_KT; ++f) {
+            const i32x4* src = a.wfrag2 + f * 64 + lane;
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(w2[f]) : "v"(src) : "memory");
+        }
+        // ---- A rows: four DMA pieces per producer wave and row (the fourth is the masked W - 192 tail)
+        const int ptid = wq * 64 + lane;
+        const int tailn = W - 192;
+        const unsigned long long tail_mask = (1ull << tailn) - 1ull;
+        const unsigned ld_goff = static_cast<unsigned>((ptid >> 2) * 64 + (((ptid & 3) ^ swzx(ptid >> 2)) << 4));
+        unsigned ld_goff_tail;
+        {
+            const int q = 768 + tailn * wq + min(lane, tailn - 1);
+            const int p = q >> 2, c = q & 3;
+            ld_goff_tail = static_cast<unsigned>(min(p, W - 1) * 64 + ((c ^ swzx(p)) << 4));
+        }
+        auto issue_A_pieces = [&](const char* row, int slot) __attribute__((always_inline)) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                unsigned off = ld_goff;
+                asm volatile("" : "+v"(off));
+                dma16(row + i * 4096 + off, ringA + slot * X_ROWA + (i * 256 + wq * 64) * 16);
+            }
+            unsigned off = ld_goff_tail;
+            asm volatile("" : "+v"(off));
+            dma16_masked(row + off, ringA + slot * X_ROWA + (768 + tailn * wq) * 16, tail_mask);
+        };
+        const char* a_next = in_blk + static_cast<int64_t>(yo0) * (Win * 64);
+        unsigned baseA[3], wbB[4];
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const int p = xw + px16 + kx;                 // (tile k adds 16 pixels = 1024 bytes: same swizzle; no clamp: columns right
+            baseA[kx] = ringA_lds + static_cast<unsigned>(p * 64 + ((g ^ swzx(p)) << 4));   //  of the row only feed columns that are dropped)
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int xo = xw + 16 * k + px16;
+            const bool last = k == (has4 ? 3 : 2);
+            const int col = (xo < Wb && !(last && px16 >= 13) && (k < 3 || has4)) ? xo : X_BDUMMY;
+            wbB[k] = ringB_lds + static_cast<unsigned>(col * 64 + ((g ^ swzx(col)) << 4));
+        }
+        // folded BN of the lane's 8 couts (8 g .. 8 g + 7)
+        f32x4 scv[2], shv[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            scv[h] = *reinterpret_cast<const f32x4*>(a.ptab + 8 * g + 4 * h);
+            shv[h] = *reinterpret_cast<const f32x4*>(a.ptab + 32 + 8 * g + 4 * h);
+        }
+        int hp[4][2][2], q0[4][2][2], q1[4][2][2];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) hp[k][h][j] = q0[k][h][j] = q1[k][h][j] = 0;
+        issue_A_pieces(a_next, 0);
+        wait_vmcnt<0>();
+#pragma unroll
+        for (int f = 0; f < 2 * X_KT; ++f) asm volatile("" : "+v"(w2[f]));
+        lds_barrier();
+
+        auto out = [&](auto KC, auto PC, const i32x4 (&opk)[2], const i32x4 (&opn)[2], bool cross) __attribute__((always_inline)) {
+            constexpr int k = decltype(KC)::value, P = decltype(PC)::value;
+            constexpr int off = ((P + 3) % X_NB) * X_ROWB;       // B row t-5
+            f32x4 H[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) H[h] = mfma16<RN_DTYPE_F16>(opk[h], pm, zero4);
+            if (cross) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h) H[h] = mfma16<RN_DTYPE_F16>(opn[h], pmx, H[h]);
+            }
+            float y[8];
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) y[4 * h + i] = __builtin_fmaf(H[h][i], scv[h][i], shv[h][i]);
+            const i32x4 d = {static_cast<int>(pack2<DT>(y[0], y[1])), static_cast<int>(pack2<DT>(y[2], y[3])),
+                             static_cast<int>(pack2<DT>(y[4], y[5])), static_cast<int>(pack2<DT>(y[6], y[7]))};
+            auto& wb = wbB;
+            asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(wb[k]), "v"(d), "n"(off) : "memory");
+        };
+        auto step = [&](auto PC, int t) __attribute__((always_inline)) {
+            constexpr int P = decltype(PC)::value;
+            constexpr int PR = P & 1;
+            if (t < nrows + 9) a_next += Win * 64;
+            issue_A_pieces(a_next, (P + 1) % X_NA);                  // A row t+1
+            {
+                const int need_cur = min(ylo_step(t) + 1, Win - 1);
+                if (sk_f < need_cur) {                      // the consumer fetches this one itself (lo row jumped by 2)
+                    ++sk_f;
+                    sk_slot = sk_slot == X_NSK - 1 ? 0 : sk_slot + 1;
+                }
+                const int need_next = min(ylo_step(t + 1) + 1, Win - 1);
+                if (sk_f < need_next) {
+                    ++sk_f;
+                    sk_slot = sk_slot == X_NSK - 1 ? 0 : sk_slot + 1;
+                    issue_skip_row(sk_f, sk_slot);
+                }
+            }
+            f32x4 acc[2];
+            i32x4 op[4][2];
+            op[3][0] = op[3][1] = i32x4{0, 0, 0, 0};
+            chain(IC<(P + 2) % 4>{}, IC<X_ROWA>{}, IC<0>{}, baseA, w2, acc);      // conv row t-2: A rows t-2 .. t
+            finish(IC<PR>{}, acc, hp[0], q0[0], q1[0], op[0]);
+            chain(IC<(P + 2) % 4>{}, IC<X_ROWA>{}, IC<1>{}, baseA, w2, acc);
+            finish(IC<PR>{}, acc, hp[1], q0[1], q1[1], op[1]);
+            out(IC<0>{}, PC, op[0], op[1], true);
+            chain(IC<(P + 2) % 4>{}, IC<X_ROWA>{}, IC<2>{}, baseA, w2, acc);
+            finish(IC<PR>{}, acc, hp[2], q0[2], q1[2], op[2]);
+            out(IC<1>{}, PC, op[1], op[2], true);
+            if (has4) {
+                chain(IC<(P + 2) % 4>{}, IC<X_ROWA>{}, IC<3>{}, baseA, w2, acc);
+                finish(IC<PR>{}, acc, hp[3], q0[3], q1[3], op[3]);
+            }
+            out(IC<2>{}, PC, op[2], op[3], true);             // (3-tile waves: op[3] = 0, and columns 13..15 go to the dummy column)
+            if (has4) out(IC<3>{}, PC, op[3], op[3], false);
+            wait_vmcnt<0>();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            raw_barrier();
+        };
+        int t = 0;
+        for (; t + 3 < nsteps; t += 4) {
+            step(IC<0>{}, t);
+            step(IC<1>{}, t + 1);
+            step(IC<2>{}, t + 2);
+            step(IC<3>{}, t + 3);
+        }
+        const int rem = nsteps - t;
+        if (rem > 0) step(IC<0>{}, t);
+        if (rem > 1) step(IC<1>{}, t + 1);
+        if (rem > 2) step(IC<2>{}, t + 2);
+        wait_vmcnt<0>();
+        return;
+    }
+
+    // =================================================================== consumer: second stage, B ring -> HBM
+    __builtin_amdgcn_s_setprio(1);
+    const bool has4 = wq >= 2;                                      // tiles of this wave: 3 3 4 4
+    const int xw = xc_start(wq);
+    const int xend = wq == 3 ? Wo : min(xc_start(wq + 1), Wo);      // this wave stores output columns [xw, xend)
+    i32x4 w3[2 * X_KT];
+#pragma unroll
+    for (int f = 0; f < 2 * X_KT; ++f) {
+        const i32x4* src = a.wfrag3 + f * 64 + lane;
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(w3[f]) : "v"(src) : "memory");
+    }
+    unsigned baseB[3], a_off[4];
+    i32x4 wx[4];
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+        const int p = xw + px16 + kx;
+        baseB[kx] = ringB_lds + static_cast<unsigned>(p * 64 + ((g ^ swzx(p)) << 4));
+    }
+    // output stores: tile k = 1024 bytes further (immediate); a lane stores while its column lies left of the wave's limit
+    // for that tile: lim(k) = columns of tile k this wave owns (13 in its last tile, cut at the next wave's start / the row end)
+    const int voff0 = ((x0 + xw + px16) * 32 + 8 * g) * 2;
+    const int ntile = has4 ? 4 : 3;
+    auto lim = [&](int k) __attribute__((always_inline)) { return min(xend - xw - 16 * k, k == ntile - 1 ? 13 : 16); };
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int xo = xw + 16 * k + px16;
+        // interpolation window of the tile: 32 source columns starting at xs_k (ring-relative, kept inside the 64-column ring)
+        const int xs_k = min(a.rlo[x0 + min(xw + 16 * k, Wo - 1)] - xs0, 32);
+        const int xq = x0 + min(xo, Wo - 1);
+        const int plo = a.rlo[xq] - xs0, phi = a.rhi[xq] - xs0;
+        const float xlq = res_quant_lerp<DT>(a.rlerp[xq]);
+        unsigned short wh[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int xin = xs_k + 8 * g + j;
+            float w = 0.f;
+            if (xin == plo) w += 1.0f - xlq;
+            if (xin == phi) w += xlq;
+            wh[j] = to16<DT>(w);
+        }
+#pragma unroll
+        for (int d = 0; d < 4; ++d) wx[k][d] = static_cast<int>(static_cast<unsigned>(wh[2 * d]) | (static_cast<unsigned>(wh[2 * d + 1]) << 16));
+        // transposed reads of the skip rows: lane 4 q + p of a 16-lane group supplies the address of pixel row q, couts
+        // 8 p + 4 h .. + 3 (chunk p, byte 8 h: the permuted cout order of fragment column 4 p + j); the second block of 4
+        // pixels lies 256 bytes further
+        const int q = px16 >> 2, p = px16 & 3;
+        a_off[k] = skw_lds + static_cast<unsigned>((xs_k + 8 * g + q) * 64 + (p << 4));
+    }
+    asm volatile("" : "+v"(wx[0]), "+v"(wx[1]), "+v"(wx[2]), "+v"(wx[3]));
+    // folded BN of the lane's 8 couts (sc3', sh3', sc4): read from the LDS table per tile (24 registers otherwise)
+    const unsigned tabl_lds = lds_addr(tab + 64 + 8 * g);
+    const int out_row_bytes = Hout * 64;
+    const char* out_row = reinterpret_cast<const char*>(a.out + static_cast<int64_t>(n) * Hout * Hout * 32) + static_cast<int64_t>(yo0) * out_row_bytes;
+    int hp[4][2][2], q0[4][2][2], q1[4][2][2];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) hp[k][h][j] = q0[k][h][j] = q1[k][h][j] = 0;
+    struct RowCtx {
+        float yl;
+        unsigned sk_lo, sk_hi;
+        const char* row;          // (the buffer resource is built at the store: four more scalars held across the step spilled)
+        int emit_mask;
+    };
+    VLerp vl_cur = vlerp_of(yo0);
+    int slot_cur = 0;
+    RowCtx cx{};
+    wait_vmcnt<0>();                                      // the weight fragments have landed
+#pragma unroll
+    for (int f = 0; f < 2 * X_KT; ++f) asm volatile("" : "+v"(w3[f]));
+    lds_barrier();
+
+    auto out = [&](auto KC, const i32x4 (&opk)[2], const i32x4 (&opn)[2], bool cross) __attribute__((always_inline)) {
+        constexpr int k = decltype(KC)::value;
+        // residual: R_lo / R_hi [cout][xo] = Skip^T [cout][32 source columns] * Wx on the matrix cores
+        i32x2 tq[2][2][2];                      // [lo / hi][half][block]
+        const unsigned alo = a_off[k] + cx.sk_lo, ahi = a_off[k] + cx.sk_hi;
+        asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(tq[0][0][0]) : "v"(alo));
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:256" : "=v"(tq[0][0][1]) : "v"(alo));
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:8" : "=v"(tq[0][1][0]) : "v"(alo));
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:264" : "=v"(tq[0][1][1]) : "v"(alo));
+        asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(tq[1][0][0]) : "v"(ahi));
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:256" : "=v"(tq[1][0][1]) : "v"(ahi));
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:8" : "=v"(tq[1][1][0]) : "v"(ahi));
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:264" : "=v"(tq[1][1][1]) : "v"(ahi));
+        f32x4 tsc1[2], tsh1[2], tsc2[2];
+        {
+            const unsigned ta = tabl_lds;
+            auto& t1 = tsc1;
+            auto& t2 = tsh1;
+            auto& t3 = tsc2;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(t1[h]) : "v"(ta), "n"(16 * h));
+                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(t2[h]) : "v"(ta), "n"(128 + 16 * h));
+                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(t3[h]) : "v"(ta), "n"(256 + 16 * h));
+            }
+        }
+        f32x4 H[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) H[h] = mfma16<RN_DTYPE_F16>(opk[h], pm, zero4);
+        if (cross) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) H[h] = mfma16<RN_DTYPE_F16>(opn[h], pmx, H[h]);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(tq[0][0][0]), "+v"(tq[0][0][1]), "+v"(tq[0][1][0]), "+v"(tq[0][1][1]), "+v"(tq[1][0][0]), "+v"(tq[1][0][1]),
+                       "+v"(tq[1][1][0]), "+v"(tq[1][1][1]), "+v"(tsc1[0]), "+v"(tsc1[1]), "+v"(tsh1[0]), "+v"(tsh1[1]), "+v"(tsc2[0]), "+v"(tsc2[1]));
+        float y[8];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const i32x4 al = {tq[0][h][0][0], tq[0][h][0][1], tq[0][h][1][0], tq[0][h][1][1]};
+            const i32x4 ah = {tq[1][h][0][0], tq[1][h][0][1], tq[1][h][1][0], tq[1][h][1][1]};
+            const f32x4 r_lo = mfma16<DT>(al, wx[k], zero4);
+            const f32x4 r_hi = mfma16<DT>(ah, wx[k], zero4);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float y1 = __builtin_fmaf(H[h][i], tsc1[h][i], tsh1[h][i]);
+                const float lo = r_lo[i];
+                const float rs = __builtin_fmaf(r_hi[i] - lo, cx.yl, lo);
+                y[4 * h + i] = __builtin_fmaf(rs, tsc2[h][i], y1);
+            }
+        }
+        const i32x4 d = {static_cast<int>(pack2<DT>(y[0], y[1])), static_cast<int>(pack2<DT>(y[2], y[3])),
+                         static_cast<int>(pack2<DT>(y[4], y[5])), static_cast<int>(pack2<DT>(y[6], y[7]))};
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(cx.row), 0, out_row_bytes, 0x00020000);
+        const int vo = (px16 < lim(k) ? voff0 + 1024 * k : OOB) | cx.emit_mask;
+        __builtin_amdgcn_raw_buffer_store_b128(d, rs, vo, 0, 0);
+    };
+    auto step = [&](auto PC, int t) __attribute__((always_inline)) {
+        constexpr int P = decltype(PC)::value;
+        constexpr int PR = P & 1;
+        const int jo = t - X_LAG;
+        cx.yl = vl_cur.yl;
+        cx.sk_lo = static_cast<unsigned>(slot_cur * X_SKROW);
+        cx.sk_hi = static_cast<unsigned>((vl_cur.ylo + 1 > Win - 1 ? slot_cur : (slot_cur == X_NSK - 1 ? 0 : slot_cur + 1)) * X_SKROW);
+        cx.row = out_row;
+        cx.emit_mask = jo >= 0 ? 0 : OOB;
+        if (jo >= 0 && jo < nrows - 1) out_row += out_row_bytes;
+        const VLerp vl_next = vlerp_of(yo0 + min(max(jo + 1, 0), nrows - 1));
+        {
+            const int need_cur = min(vl_cur.ylo + 1, Win - 1);
+            if (sk_f < need_cur) {
+                ++sk_f;
+                sk_slot = sk_slot == X_NSK - 1 ? 0 : sk_slot + 1;
+                issue_skip_row(sk_f, sk_slot);
+            }
+            const int need_next = min(vl_next.ylo + 1, Win - 1);
+            if (sk_f < need_next) {
+                ++sk_f;
+                sk_slot = sk_slot == X_NSK - 1 ? 0 : sk_slot + 1;
+            }
+        }
+        f32x4 acc[2];
+        i32x4 op[4][2];
+        op[3][0] = op[3][1] = i32x4{0, 0, 0, 0};
+        chain(IC<P>{}, IC<X_ROWB>{}, IC<0>{}, baseB, w3, acc);           // conv row t-8: B rows t-8 .. t-6
+        finish(IC<PR>{}, acc, hp[0], q0[0], q1[0], op[0]);
+        chain(IC<P>{}, IC<X_ROWB>{}, IC<1>{}, baseB, w3, acc);
+        finish(IC<PR>{}, acc, hp[1], q0[1], q1[1], op[1]);
+        wait_vmcnt<0>();                                       // a skip row fetched at the top of this step has landed
+        out(IC<0>{}, op[0], op[1], true);
+        chain(IC<P>{}, IC<X_ROWB>{}, IC<2>{}, baseB, w3, acc);
+        finish(IC<PR>{}, acc, hp[2], q0[2], q1[2], op[2]);
+        out(IC<1>{}, op[1], op[2], true);
+        if (has4) {
+            chain(IC<P>{}, IC<X_ROWB>{}, IC<3>{}, baseB, w3, acc);
+            finish(IC<PR>{}, acc, hp[3], q0[3], q1[3], op[3]);
+        }
+        out(IC<2>{}, op[2], op[3], true);
+        if (has4) out(IC<3>{}, op[3], op[3], false);
+        {
+            int sl = slot_cur + (vl_next.ylo - vl_cur.ylo);
+            slot_cur = sl >= X_NSK ? sl - X_NSK : sl;
+            vl_cur = vl_next;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        raw_barrier();
+    };
+    int t = 0;
+    for (; t + 3 < nsteps; t += 4) {
+        step(IC<0>{}, t);
+        step(IC<1>{}, t + 1);
+        step(IC<2>{}, t + 2);
+        step(IC<3>{}, t + 3);
+    }
+    const int rem = nsteps - t;
+    if (rem > 0) step(IC<0>{}, t);
+    if (rem > 1) step(IC<1>{}, t + 1);
+    if (rem > 2) step(IC<2>{}, t + 2);
+    wait_vmcnt<0>();
+}
+
+}  // namespace
+
+// B-operand fragments of the 16x16x32 form: frag[tap][half][lane][j] = W[k = 32 tap + 8 (lane / 16) + j][cout(half, lane % 16)]
+// with cout(h, n) = 8 (n / 4) + 4 h + n % 4 (so that a lane's pooled rows 4 g + i of the two halves are couts 8 g .. 8 g + 7)
+void rn_stage23x_pack(const float* w_hwio, int dtype, unsigned short (*cvt_bf16)(float), unsigned short (*cvt_f16)(float),
+                      std::vector<unsigned short>* out) {
+    out->assign(static_cast<size_t>(2 * X_KT) * 64 * 8, 0);
+    for (int tap = 0; tap < X_KT; ++tap)
+        for (int h = 0; h < 2; ++h)
+            for (int l = 0; l < 64; ++l)
+                for (int j = 0; j < 8; ++j) {
+                    const int k = 32 * tap + 8 * (l >> 4) + j, nn = l & 15;
+                    const int co = 8 * (nn >> 2) + 4 * h + (nn & 3);
+                    const float v = w_hwio[static_cast<size_t>(k) * 32 + co];
+                    (*out)[((static_cast<size_t>(tap) * 2 + h) * 64 + l) * 8 + j] = dtype == RN_DTYPE_BF16 ? cvt_bf16(v) : cvt_f16(v);
+                }
+}
+
+int rn_stage23x_launch(int dtype, hipStream_t s, const Stage23Args& a, int n) {
+    auto launch = [&](auto kern) -> int {
+        static std::atomic<unsigned long long> attr_devices{0};     // per device and instantiation
+        int dev = 0;
+        RN_HIP(hipGetDevice(&dev));
+        if (!(attr_devices.load(std::memory_order_acquire) >> (dev & 63) & 1ull)) {
+            RN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            attr_devices.fetch_or(1ull << (dev & 63), std::memory_order_release);
+        }
+        hipLaunchKernelGGL(kern, dim3(a.n_bands * a.n_cblocks, n), dim3(512), X_LDS, s, a);
+        RN_CHECK_LAUNCH();
+        return RN_OK;
+    };
+    if (dtype == RN_DTYPE_BF16) return launch(stage23x_kernel<RN_DTYPE_BF16>);
+    return launch(stage23x_kernel<RN_DTYPE_F16>);
+}
