@@ -125,8 +125,15 @@ __global__ __launch_bounds__(512, 2) void stage23x_kernel(const Stage23Args a) {
 
     // two interleaved accumulation chains (the tile's two 16-cout halves) over the nine taps; the tap's operand is ONE
     // ds_read_b128 (16 pixels x 32 channels), issued AHEAD taps early and retired by a counted wait
-    auto chain = [&](auto S0C, auto ROWC, auto KC, const unsigned (&base)[3], const i32x4 (&wr)[2 * X_KT], f32x4 (&acc)[2]) __attribute__((always_inline)) {
+    // `hook(IC<tap>)` runs behind the tap's MFMA pair: DMA issue and scalar bookkeeping ride in the MFMAs' shadow
+    auto chain = [&](auto S0C, auto ROWC, auto KC, const unsigned (&base)[3], const i32x4 (&wr)[2 * X_KT], f32x4 (&acc)[2], auto&& hook) __attribute__((always_inline)) {
         constexpr int S0 = decltype(S0C)::value, ROW = decltype(ROWC)::value, k = decltype(KC)::value;
+#ifdef RN_X_NOCHAIN      // (timing experiments only, tools/build_variant.sh: wrong results)
+        acc[0] = acc[1] = zero4;
+        asm volatile("" : "+v"(acc[0]), "+v"(acc[1]));
+        [&]<int... I>(std::integer_sequence<int, I...>) { (hook(IC<I>{}), ...); }(std::make_integer_sequence<int, X_KT>{});
+        return;
+#endif
         i32x4 fq[X_KT];
         auto rd = [&](auto TC, float dep) __attribute__((always_inline)) -> i32x4 {
             constexpr int tap = decltype(TC)::value, ky = tap / 3, kx = tap % 3;
@@ -143,25 +150,42 @@ __global__ __launch_bounds__(512, 2) void stage23x_kernel(const Stage23Args a) {
                  asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(fq[I]) : "n"(newer));
                  acc[0] = mfma16<DT>(fq[I], wr[2 * I], I == 0 ? zero4 : acc[0]);          // D'[pixel][cout], couts of half 0
                  acc[1] = mfma16<DT>(fq[I], wr[2 * I + 1], I == 0 ? zero4 : acc[1]);
+                 hook(IC<I>{});
              }()),
              ...);
         }(std::make_integer_sequence<int, X_KT>{});
     };
     // ReLU6 -> fp16 pairs -> vertical pair sums; the pooling operand of the tile half = [pair sums two rows back | current]
-    auto finish = [&](auto PRC, const f32x4 (&acc)[2], int (&hp)[2][2], int (&q0)[2][2], int (&q1)[2][2], i32x4 (&op)[2]) __attribute__((always_inline)) {
-        constexpr int PR = decltype(PRC)::value;
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
+    // Cut into six slices (per 16-cout half: pack rows 0-1, pack rows 2-3, pair sums + operand), so that the slices of tile k
+    // can ride behind the MFMA pairs of tile k + 1's chain (the wave's other accumulator pair): with_finish() below.
+    auto finish_part = [&](auto PARTC, auto PRC, const f32x4 (&acc)[2], int (&hp)[2][2], int (&q0)[2][2], int (&q1)[2][2], i32x4 (&op)[2],
+                           int (&vt)[2][2]) __attribute__((always_inline)) {
+        constexpr int part = decltype(PARTC)::value, PR = decltype(PRC)::value;
+        constexpr int h = part / 3, sub = part % 3;
+        if constexpr (sub == 0) vt[h][0] = static_cast<int>(pack2<RN_DTYPE_F16>(relu6f(acc[h][0]), relu6f(acc[h][1])));
+        if constexpr (sub == 1) vt[h][1] = static_cast<int>(pack2<RN_DTYPE_F16>(relu6f(acc[h][2]), relu6f(acc[h][3])));
+        if constexpr (sub == 2) {
             int(&qold)[2] = PR == 0 ? q0[h] : q1[h];
-            const int v0 = static_cast<int>(pack2<RN_DTYPE_F16>(relu6f(acc[h][0]), relu6f(acc[h][1])));
-            const int v1 = static_cast<int>(pack2<RN_DTYPE_F16>(relu6f(acc[h][2]), relu6f(acc[h][3])));
-            const int n0 = pk_add_f16(hp[h][0], v0), n1 = pk_add_f16(hp[h][1], v1);
-            hp[h][0] = v0;
-            hp[h][1] = v1;
+            const int n0 = pk_add_f16(hp[h][0], vt[h][0]), n1 = pk_add_f16(hp[h][1], vt[h][1]);
+            hp[h][0] = vt[h][0];
+            hp[h][1] = vt[h][1];
             op[h] = i32x4{qold[0], qold[1], n0, n1};
             qold[0] = n0;
             qold[1] = n1;
         }
+    };
+    auto finish = [&](auto PRC, const f32x4 (&acc)[2], int (&hp)[2][2], int (&q0)[2][2], int (&q1)[2][2], i32x4 (&op)[2]) __attribute__((always_inline)) {
+        int vt[2][2];
+        [&]<int... I>(std::integer_sequence<int, I...>) { (finish_part(IC<I>{}, PRC, acc, hp, q0, q1, op, vt), ...); }(std::make_integer_sequence<int, 6>{});
+    };
+    // chain hook = `base` (DMA / bookkeeping) + slice i - 1 of the previous tile's finish behind MFMA pair i = 1 .. 6
+    auto with_finish = [&](auto&& base, auto PRC, const f32x4 (&acc)[2], int (&hp)[2][2], int (&q0)[2][2], int (&q1)[2][2], i32x4 (&op)[2],
+                           int (&vt)[2][2]) __attribute__((always_inline)) {
+        return [&, PRC](auto IC_) __attribute__((always_inline)) {
+            constexpr int i = decltype(IC_)::value;
+            base(IC_);
+            if constexpr (i >= 1 && i <= 6) finish_part(IC<(i >= 1 && i <= 6 ? i - 1 : 0)>{}, PRC, acc, hp, q0, q1, op, vt);
+        };
     };
 
     // ---- residual skip rows: schedule as in rn_stage23.hip (the partner producer fetches the regular new row during the
@@ -174,15 +198,20 @@ __global__ __launch_bounds__(512, 2) void stage23x_kernel(const Stage23Args a) {
     const unsigned sk_goff0 = static_cast<unsigned>((xs0 + (lane >> 2)) * 64 + ((lane & 3) << 4));
     char* const skw = smem + X_SKIP_OFF + wq * (X_NSK * X_SKROW);
     const unsigned skw_lds = lds_addr(skw);
-    auto issue_skip_row = [&](int y, int slot) __attribute__((always_inline)) {
+    auto issue_skip_piece = [&](auto IC_, int y, int slot) __attribute__((always_inline)) {
+        constexpr int i = decltype(IC_)::value;
         const char* row = in_img + static_cast<int64_t>(y) * static_cast<int64_t>(Win * 64);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            unsigned off = sk_goff0;
-            asm volatile("" : "+v"(off));
-            dma16(row + i * 1024 + off, skw + slot * X_SKROW + i * 1024);
-        }
+        unsigned off = sk_goff0;
+        asm volatile("" : "+v"(off));
+        dma16(row + i * 1024 + off, skw + slot * X_SKROW + i * 1024);
     };
+    auto issue_skip_row = [&](int y, int slot) __attribute__((always_inline)) {
+        issue_skip_piece(IC<0>{}, y, slot);
+        issue_skip_piece(IC<1>{}, y, slot);
+        issue_skip_piece(IC<2>{}, y, slot);
+        issue_skip_piece(IC<3>{}, y, slot);
+    };
+    auto no_hook = [](auto) __attribute__((always_inline)) {};
     struct VLerp {
         int ylo;
         float yl;
@@ -222,16 +251,23 @@ __global__ __launch_bounds__(512, 2) void stage23x_kernel(const Stage23Args a) {
             const int p = q >> 2, c = q & 3;
             ld_goff_tail = static_cast<unsigned>(min(p, W - 1) * 64 + ((c ^ swzx(p)) << 4));
         }
-        auto issue_A_pieces = [&](const char* row, int slot) __attribute__((always_inline)) {
-#pragma unroll
-            for (int i = 0; i < 3; ++i) {
+        auto issue_A_piece = [&](auto IC_, const char* row, int slot) __attribute__((always_inline)) {
+            constexpr int i = decltype(IC_)::value;
+            if constexpr (i < 3) {
                 unsigned off = ld_goff;
                 asm volatile("" : "+v"(off));
                 dma16(row + i * 4096 + off, ringA + slot * X_ROWA + (i * 256 + wq * 64) * 16);
+            } else {
+                unsigned off = ld_goff_tail;
+                asm volatile("" : "+v"(off));
+                dma16_masked(row + off, ringA + slot * X_ROWA + (768 + tailn * wq) * 16, tail_mask);
             }
-            unsigned off = ld_goff_tail;
-            asm volatile("" : "+v"(off));
-            dma16_masked(row + off, ringA + slot * X_ROWA + (768 + tailn * wq) * 16, tail_mask);
+        };
+        auto issue_A_pieces = [&](const char* row, int slot) __attribute__((always_inline)) {
+            issue_A_piece(IC<0>{}, row, slot);
+            issue_A_piece(IC<1>{}, row, slot);
+            issue_A_piece(IC<2>{}, row, slot);
+            issue_A_piece(IC<3>{}, row, slot);
         };
         const char* a_next = in_blk + static_cast<int64_t>(yo0) * (Win * 64);
         unsigned baseA[3], wbB[4];
@@ -262,6 +298,7 @@ __global__ __launch_bounds__(512, 2) void stage23x_kernel(const Stage23Args a) {
 #pragma unroll
                 for (int j = 0; j < 2; ++j) hp[k][h][j] = q0[k][h][j] = q1[k][h][j] = 0;
         issue_A_pieces(a_next, 0);
+        int ylo_nxt = ylo_step(0);                       // lo skip row of the output row the coming step finishes
         wait_vmcnt<0>();
 #pragma unroll
         for (int f = 0; f < 2 * X_KT; ++f) asm volatile("" : "+v"(w2[f]));
@@ -269,6 +306,10 @@ __global__ __launch_bounds__(512, 2) void stage23x_kernel(const Stage23Args a) {
 
         auto out = [&](auto KC, auto PC, const i32x4 (&opk)[2], const i32x4 (&opn)[2], bool cross) __attribute__((always_inline)) {
             constexpr int k = decltype(KC)::value, P = decltype(PC)::value;
+#ifdef RN_X_NOOUT_P
+            asm volatile("" ::"v"(opk[0]), "v"(opk[1]), "v"(opn[0]), "v"(opn[1]));
+            return;
+#endif
             constexpr int off = ((P + 3) % X_NB) * X_ROWB;       // B row t-5
             f32x4 H[2];
 #pragma unroll
@@ -291,37 +332,61 @@ __global__ __launch_bounds__(512, 2) void stage23x_kernel(const Stage23Args a) {
             constexpr int P = decltype(PC)::value;
             constexpr int PR = P & 1;
             if (t < nrows + 9) a_next += Win * 64;
-            issue_A_pieces(a_next, (P + 1) % X_NA);                  // A row t+1
-            {
-                const int need_cur = min(ylo_step(t) + 1, Win - 1);
-                if (sk_f < need_cur) {                      // the consumer fetches this one itself (lo row jumped by 2)
-                    ++sk_f;
-                    sk_slot = sk_slot == X_NSK - 1 ? 0 : sk_slot + 1;
+            // A row t+1: two DMA pieces behind MFMA pairs of the first tile's chain, two behind the second's.  Skip rows of the
+            // partner consumer: decided behind the first chain's MFMAs, fetched behind the third tile's; when no new row is
+            // due the newest one is fetched again into its own slot (same bytes), so there is no branch around a DMA
+            auto hook0 = [&](auto IC_) __attribute__((always_inline)) {
+                constexpr int i = decltype(IC_)::value;
+                if constexpr (i == 1) issue_A_piece(IC<0>{}, a_next, (P + 1) % X_NA);
+                if constexpr (i == 5) issue_A_piece(IC<1>{}, a_next, (P + 1) % X_NA);
+                if constexpr (i == 3) {
+                    const int need_cur = min(ylo_nxt + 1, Win - 1);              // ylo_nxt: lo row of this step's output row
+                    if (sk_f < need_cur) {                  // the consumer fetches this one itself (lo row jumped by 2)
+                        ++sk_f;
+                        sk_slot = sk_slot == X_NSK - 1 ? 0 : sk_slot + 1;
+                    }
                 }
-                const int need_next = min(ylo_step(t + 1) + 1, Win - 1);
-                if (sk_f < need_next) {
-                    ++sk_f;
-                    sk_slot = sk_slot == X_NSK - 1 ? 0 : sk_slot + 1;
-                    issue_skip_row(sk_f, sk_slot);
+                if constexpr (i == 7) {
+                    ylo_nxt = ylo_step(t + 1);
+                    const int need_next = min(ylo_nxt + 1, Win - 1);
+                    if (sk_f < need_next) {
+                        ++sk_f;
+                        sk_slot = sk_slot == X_NSK - 1 ? 0 : sk_slot + 1;
+                    }
                 }
-            }
-            f32x4 acc[2];
+            };
+            auto hook1 = [&](auto IC_) __attribute__((always_inline)) {
+                constexpr int i = decltype(IC_)::value;
+                if constexpr (i == 1) issue_A_piece(IC<2>{}, a_next, (P + 1) % X_NA);
+                if constexpr (i == 5) issue_A_piece(IC<3>{}, a_next, (P + 1) % X_NA);
+            };
+            auto hook2 = [&](auto IC_) __attribute__((always_inline)) {
+                constexpr int i = decltype(IC_)::value;
+                if constexpr (i == 0) issue_skip_piece(IC<0>{}, sk_f, sk_slot);
+                if constexpr (i == 2) issue_skip_piece(IC<1>{}, sk_f, sk_slot);
+                if constexpr (i == 4) issue_skip_piece(IC<2>{}, sk_f, sk_slot);
+                if constexpr (i == 6) issue_skip_piece(IC<3>{}, sk_f, sk_slot);
+            };
+            // tile k's ReLU6 / pack / pair sums ride behind the MFMAs of tile k + 1's chain (two accumulator pairs alternate)
+            f32x4 accA[2], accB[2];
+            int vt[2][2];
             i32x4 op[4][2];
             op[3][0] = op[3][1] = i32x4{0, 0, 0, 0};
-            chain(IC<(P + 2) % 4>{}, IC<X_ROWA>{}, IC<0>{}, baseA, w2, acc);      // conv row t-2: A rows t-2 .. t
-            finish(IC<PR>{}, acc, hp[0], q0[0], q1[0], op[0]);
-            chain(IC<(P + 2) % 4>{}, IC<X_ROWA>{}, IC<1>{}, baseA, w2, acc);
-            finish(IC<PR>{}, acc, hp[1], q0[1], q1[1], op[1]);
+            chain(IC<(P + 2) % 4>{}, IC<X_ROWA>{}, IC<0>{}, baseA, w2, accA, hook0);      // conv row t-2: A rows t-2 .. t
+            chain(IC<(P + 2) % 4>{}, IC<X_ROWA>{}, IC<1>{}, baseA, w2, accB, with_finish(hook1, IC<PR>{}, accA, hp[0], q0[0], q1[0], op[0], vt));
+            chain(IC<(P + 2) % 4>{}, IC<X_ROWA>{}, IC<2>{}, baseA, w2, accA, with_finish(hook2, IC<PR>{}, accB, hp[1], q0[1], q1[1], op[1], vt));
             out(IC<0>{}, PC, op[0], op[1], true);
-            chain(IC<(P + 2) % 4>{}, IC<X_ROWA>{}, IC<2>{}, baseA, w2, acc);
-            finish(IC<PR>{}, acc, hp[2], q0[2], q1[2], op[2]);
-            out(IC<1>{}, PC, op[1], op[2], true);
             if (has4) {
-                chain(IC<(P + 2) % 4>{}, IC<X_ROWA>{}, IC<3>{}, baseA, w2, acc);
-                finish(IC<PR>{}, acc, hp[3], q0[3], q1[3], op[3]);
+                chain(IC<(P + 2) % 4>{}, IC<X_ROWA>{}, IC<3>{}, baseA, w2, accB, with_finish(no_hook, IC<PR>{}, accA, hp[2], q0[2], q1[2], op[2], vt));
+                out(IC<1>{}, PC, op[1], op[2], true);
+                finish(IC<PR>{}, accB, hp[3], q0[3], q1[3], op[3]);
+                out(IC<2>{}, PC, op[2], op[3], true);
+                out(IC<3>{}, PC, op[3], op[3], false);
+            } else {
+                finish(IC<PR>{}, accA, hp[2], q0[2], q1[2], op[2]);
+                out(IC<1>{}, PC, op[1], op[2], true);
+                out(IC<2>{}, PC, op[2], op[3], true);         // op[3] = 0, and columns 13..15 of the third tile go to the dummy column
             }
-            out(IC<2>{}, PC, op[2], op[3], true);             // (3-tile waves: op[3] = 0, and columns 13..15 go to the dummy column)
-            if (has4) out(IC<3>{}, PC, op[3], op[3], false);
             wait_vmcnt<0>();
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             raw_barrier();
@@ -408,6 +473,7 @@ __global__ __launch_bounds__(512, 2) void stage23x_kernel(const Stage23Args a) {
         int emit_mask;
     };
     VLerp vl_cur = vlerp_of(yo0);
+    VLerp vl_pre = vl_cur;                                // interpolation of the NEXT step's output row, one step ahead
     int slot_cur = 0;
     RowCtx cx{};
     wait_vmcnt<0>();                                      // the weight fragments have landed
@@ -415,10 +481,20 @@ __global__ __launch_bounds__(512, 2) void stage23x_kernel(const Stage23Args a) {
     for (int f = 0; f < 2 * X_KT; ++f) asm volatile("" : "+v"(w3[f]));
     lds_barrier();
 
-    auto out = [&](auto KC, const i32x4 (&opk)[2], const i32x4 (&opn)[2], bool cross) __attribute__((always_inline)) {
-        constexpr int k = decltype(KC)::value;
-        // residual: R_lo / R_hi [cout][xo] = Skip^T [cout][32 source columns] * Wx on the matrix cores
+    // The LDS reads of a tile's epilogue (8 transposed reads of the skip rows, 6 table reads) are issued in FRONT of the next
+    // tile's ReLU6 / pack work (out_reads), their consumers run behind it (out_rest): the pack's ~25 VALU instructions cover
+    // the LDS round trip that used to stand exposed between the reads and the residual MFMAs.
+    struct OutRegs {
         i32x2 tq[2][2][2];                      // [lo / hi][half][block]
+        f32x4 tsc1[2], tsh1[2], tsc2[2];
+    };
+    auto out_reads = [&](auto KC, OutRegs& R) __attribute__((always_inline)) {
+        constexpr int k = decltype(KC)::value;
+#ifdef RN_X_NOOUT_C
+        return;
+#endif
+        auto& tq = R.tq;
+        // residual: R_lo / R_hi [cout][xo] = Skip^T [cout][32 source columns] * Wx on the matrix cores
         const unsigned alo = a_off[k] + cx.sk_lo, ahi = a_off[k] + cx.sk_hi;
         asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(tq[0][0][0]) : "v"(alo));
         asm volatile("ds_read_b64_tr_b16 %0, %1 offset:256" : "=v"(tq[0][0][1]) : "v"(alo));
@@ -428,12 +504,11 @@ __global__ __launch_bounds__(512, 2) void stage23x_kernel(const Stage23Args a) {
         asm volatile("ds_read_b64_tr_b16 %0, %1 offset:256" : "=v"(tq[1][0][1]) : "v"(ahi));
         asm volatile("ds_read_b64_tr_b16 %0, %1 offset:8" : "=v"(tq[1][1][0]) : "v"(ahi));
         asm volatile("ds_read_b64_tr_b16 %0, %1 offset:264" : "=v"(tq[1][1][1]) : "v"(ahi));
-        f32x4 tsc1[2], tsh1[2], tsc2[2];
         {
             const unsigned ta = tabl_lds;
-            auto& t1 = tsc1;
-            auto& t2 = tsh1;
-            auto& t3 = tsc2;
+            auto& t1 = R.tsc1;
+            auto& t2 = R.tsh1;
+            auto& t3 = R.tsc2;
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(t1[h]) : "v"(ta), "n"(16 * h));
@@ -441,6 +516,17 @@ __global__ __launch_bounds__(512, 2) void stage23x_kernel(const Stage23Args a) {
                 asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(t3[h]) : "v"(ta), "n"(256 + 16 * h));
             }
         }
+    };
+    auto out_rest = [&](auto KC, OutRegs& R, const i32x4 (&opk)[2], const i32x4 (&opn)[2], bool cross) __attribute__((always_inline)) {
+        constexpr int k = decltype(KC)::value;
+#ifdef RN_X_NOOUT_C
+        asm volatile("" ::"v"(opk[0]), "v"(opk[1]), "v"(opn[0]), "v"(opn[1]));
+        return;
+#endif
+        auto& tq = R.tq;
+        auto& tsc1 = R.tsc1;
+        auto& tsh1 = R.tsh1;
+        auto& tsc2 = R.tsc2;
         f32x4 H[2];
 #pragma unroll
         for (int h = 0; h < 2; ++h) H[h] = mfma16<RN_DTYPE_F16>(opk[h], pm, zero4);
@@ -482,7 +568,7 @@ __global__ __launch_bounds__(512, 2) void stage23x_kernel(const Stage23Args a) {
         cx.row = out_row;
         cx.emit_mask = jo >= 0 ? 0 : OOB;
         if (jo >= 0 && jo < nrows - 1) out_row += out_row_bytes;
-        const VLerp vl_next = vlerp_of(yo0 + min(max(jo + 1, 0), nrows - 1));
+        const VLerp vl_next = vl_pre;                  // (computed behind the previous step's third chain)
         {
             const int need_cur = min(vl_cur.ylo + 1, Win - 1);
             if (sk_f < need_cur) {
@@ -496,24 +582,41 @@ __global__ __launch_bounds__(512, 2) void stage23x_kernel(const Stage23Args a) {
                 sk_slot = sk_slot == X_NSK - 1 ? 0 : sk_slot + 1;
             }
         }
-        f32x4 acc[2];
+        // Tile k's ReLU6 / pack / pair sums ride behind the MFMAs of tile k + 1's chain; the LDS reads of tile k's epilogue go
+        // out in front of tile k + 2's chain and are consumed behind it (they return in order, ahead of the chain's first
+        // fragment: ~50 cycles of LDS array time at the head of the chain instead of an exposed round trip behind it)
+        f32x4 accA[2], accB[2];
+        int vt[2][2];
         i32x4 op[4][2];
         op[3][0] = op[3][1] = i32x4{0, 0, 0, 0};
-        chain(IC<P>{}, IC<X_ROWB>{}, IC<0>{}, baseB, w3, acc);           // conv row t-8: B rows t-8 .. t-6
-        finish(IC<PR>{}, acc, hp[0], q0[0], q1[0], op[0]);
-        chain(IC<P>{}, IC<X_ROWB>{}, IC<1>{}, baseB, w3, acc);
-        finish(IC<PR>{}, acc, hp[1], q0[1], q1[1], op[1]);
+        OutRegs R;
+        auto hook_c2 = [&](auto IC_) __attribute__((always_inline)) {
+            if constexpr (decltype(IC_)::value == 7) vl_pre = vlerp_of(yo0 + min(max(jo + 2, 0), nrows - 1));
+        };
+        chain(IC<P>{}, IC<X_ROWB>{}, IC<0>{}, baseB, w3, accA, no_hook);           // conv row t-8: B rows t-8 .. t-6
+        chain(IC<P>{}, IC<X_ROWB>{}, IC<1>{}, baseB, w3, accB, with_finish(no_hook, IC<PR>{}, accA, hp[0], q0[0], q1[0], op[0], vt));
         wait_vmcnt<0>();                                       // a skip row fetched at the top of this step has landed
-        out(IC<0>{}, op[0], op[1], true);
-        chain(IC<P>{}, IC<X_ROWB>{}, IC<2>{}, baseB, w3, acc);
-        finish(IC<PR>{}, acc, hp[2], q0[2], q1[2], op[2]);
-        out(IC<1>{}, op[1], op[2], true);
+        out_reads(IC<0>{}, R);
+        chain(IC<P>{}, IC<X_ROWB>{}, IC<2>{}, baseB, w3, accA, with_finish(hook_c2, IC<PR>{}, accB, hp[1], q0[1], q1[1], op[1], vt));
+        out_rest(IC<0>{}, R, op[0], op[1], true);
         if (has4) {
-            chain(IC<P>{}, IC<X_ROWB>{}, IC<3>{}, baseB, w3, acc);
-            finish(IC<PR>{}, acc, hp[3], q0[3], q1[3], op[3]);
+            out_reads(IC<1>{}, R);
+            chain(IC<P>{}, IC<X_ROWB>{}, IC<3>{}, baseB, w3, accB, with_finish(no_hook, IC<PR>{}, accA, hp[2], q0[2], q1[2], op[2], vt));
+            out_rest(IC<1>{}, R, op[1], op[2], true);
+            out_reads(IC<2>{}, R);
+            finish(IC<PR>{}, accB, hp[3], q0[3], q1[3], op[3]);
+            __builtin_amdgcn_sched_barrier(0);
+            out_rest(IC<2>{}, R, op[2], op[3], true);
+            out_reads(IC<3>{}, R);
+            out_rest(IC<3>{}, R, op[3], op[3], false);
+        } else {
+            out_reads(IC<1>{}, R);
+            finish(IC<PR>{}, accA, hp[2], q0[2], q1[2], op[2]);
+            __builtin_amdgcn_sched_barrier(0);
+            out_rest(IC<1>{}, R, op[1], op[2], true);
+            out_reads(IC<2>{}, R);
+            out_rest(IC<2>{}, R, op[2], op[3], true);        // op[3] = 0: columns 13..15 of the third tile are not stored
         }
-        out(IC<2>{}, op[2], op[3], true);
-        if (has4) out(IC<3>{}, op[3], op[3], false);
         {
             int sl = slot_cur + (vl_next.ylo - vl_cur.ylo);
             slot_cur = sl >= X_NSK ? sl - X_NSK : sl;
