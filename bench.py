@@ -468,8 +468,8 @@ def main():
                 elif len(dom_stages) > 1 and dom_stages[-1] == len(graph.stages) - 1:
                     kname = "tail_kernel, stages %s + dense head fused" % "+".join(map(str, dom_stages))
                 elif len(dom_stages) > 1:
-                    kname = "stage23pc_kernel, stages %s fused (%d->%d ch x%d + residual)" % (
-                        "+".join(map(str, dom_stages)), s0.cin, s0.cout, len(dom_stages))
+                    kname = "%s, stages %s fused (%d->%d ch x%d + residual)" % (
+                        "stage23pc_kernel" if args.pair32 else "stage23x_kernel", "+".join(map(str, dom_stages)), s0.cin, s0.cout, len(dom_stages))
                 elif dom_stages[0] == 0:
                     kname = "stage0_kernel"
                 else:

@@ -128,6 +128,9 @@ __global__ __launch_bounds__(512, 2) void stage23x_kernel(const Stage23Args a) {
     // `hook(IC<tap>)` runs behind the tap's MFMA pair: DMA issue and scalar bookkeeping ride in the MFMAs' shadow
     auto chain = [&](auto S0C, auto ROWC, auto KC, const unsigned (&base)[3], const i32x4 (&wr)[2 * X_KT], f32x4 (&acc)[2], auto&& hook) __attribute__((always_inline)) {
         constexpr int S0 = decltype(S0C)::value, ROW = decltype(ROWC)::value, k = decltype(KC)::value;
+#if defined(RN_X_PRIO) && RN_X_PRIO == 3
+        __builtin_amdgcn_s_setprio(1);
+#endif
 #ifdef RN_X_NOCHAIN      // (timing experiments only, tools/build_variant.sh: wrong results)
         acc[0] = acc[1] = zero4;
         asm volatile("" : "+v"(acc[0]), "+v"(acc[1]));
@@ -154,6 +157,9 @@ __global__ __launch_bounds__(512, 2) void stage23x_kernel(const Stage23Args a) {
              }()),
              ...);
         }(std::make_integer_sequence<int, X_KT>{});
+#if defined(RN_X_PRIO) && RN_X_PRIO == 3
+        __builtin_amdgcn_s_setprio(0);
+#endif
     };
     // ReLU6 -> fp16 pairs -> vertical pair sums; the pooling operand of the tile half = [pair sums two rows back | current]
     // Cut into six slices (per 16-cout half: pack rows 0-1, pack rows 2-3, pair sums + operand), so that the slices of tile k
@@ -232,6 +238,9 @@ __global__ __launch_bounds__(512, 2) void stage23x_kernel(const Stage23Args a) {
 
     if (wave < 4) {
         // =============================================================== producer: first stage, A ring -> B ring
+#if defined(RN_X_PRIO) && RN_X_PRIO == 2
+        __builtin_amdgcn_s_setprio(1);
+#endif
         const bool has4 = wq < 2;                                   // tiles of this wave: 4 4 3 3
         const int xw = xp_start(wq);
         i32x4 w2[2 * X_KT];
@@ -407,7 +416,12 @@ __global__ __launch_bounds__(512, 2) void stage23x_kernel(const Stage23Args a) {
     }
 
     // =================================================================== consumer: second stage, B ring -> HBM
+#ifndef RN_X_PRIO
+#define RN_X_PRIO 1
+#endif
+#if RN_X_PRIO == 1
     __builtin_amdgcn_s_setprio(1);
+#endif
     const bool has4 = wq >= 2;                                      // tiles of this wave: 3 3 4 4
     const int xw = xc_start(wq);
     const int xend = wq == 3 ? Wo : min(xc_start(wq + 1), Wo);      // this wave stores output columns [xw, xend)
