@@ -17,7 +17,7 @@ for f in rn_api rn_kernels_f32 rn_fused rn_imageops rn_group rn_tail rn_conv16; 
 done
 # MFMA results stay in VGPRs: the epilogue reads every accumulator with the VALU, and AGPR
 # accumulators cost one v_accvgpr_read each (64 per row in the residual variant).
-# (max-ilp scheduling was measured slower)
+# (max-ilp scheduling was measured slower, see NOTES.md)
 "$HIPCC" "${CFLAGS[@]}" ${RN_RW_FLAGS:--mllvm -amdgpu-mfma-vgpr-form} -c "$HERE/rn_stage_rw.hip" -o "$OBJ/rn_stage_rw.o" &
 "$HIPCC" "${CFLAGS[@]}" ${RN_RW_FLAGS:--mllvm -amdgpu-mfma-vgpr-form} -c "$HERE/rn_stage23.hip" -o "$OBJ/rn_stage23.o" &
 "$HIPCC" "${CFLAGS[@]}" ${RN_RW_FLAGS:--mllvm -amdgpu-mfma-vgpr-form} -c "$HERE/rn_stage23x.hip" -o "$OBJ/rn_stage23x.o" &

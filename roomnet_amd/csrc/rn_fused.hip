@@ -485,7 +485,7 @@ unsigned short f32_to_f16(float f) {
 
 // Cost of running `wgs` equal workgroups of `rows` row steps each with `slots` of them resident at a time, for the
 // variants with several small workgroups per CU (they are back-filled as slots free up, so a launch does not run in
-// whole rounds of the chip).  Fitted to band-count sweeps on the GPU ("Band counts"):
+// whole rounds of the chip).  Fitted to band-count sweeps on the GPU (NOTES.md, rounds 1-2, "Band counts"):
 //   * 2-wave workgroups, four per CU (32->64 stage): the fractional number of rounds plus an eighth of a round for the
 //     ragged end, 1.5 row steps of prologue per workgroup (224: 2 bands; 600: 4);
 //   * 4-wave workgroups, two per CU (64->128 stage): a partial last round costs at least 0.6 of a round (1.125 and 2.25

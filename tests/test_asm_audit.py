@@ -1,6 +1,6 @@
 """Static hazard audit of the generated gfx950 code of the stage kernels (CPU test: hipcc -S cross-compiles).
 
-Two failure classes that passed every functional test until a particular schedule exposed them:
+Two failure classes that passed every functional test until a particular schedule exposed them (NOTES.md, rounds 1-2 section 4):
  * a VALU instruction overwriting the data registers of a 128-bit store in the very next issue slot;
  * an inline-asm LDS read whose destination registers are touched before the s_waitcnt that retires it."""
 import os

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Flag VALU / LDS-return writes to the data VGPRs of a wide store issued fewer than W instructions earlier.
 A VALU write right behind the store (+1) is the hazard hipcc does not pad for buffer stores with an SGPR soffset
-(DESIGN.md section 4); an LDS read returning into the registers is harmless (its data arrives 64+ cycles later) and is
+(NOTES.md, rounds 1-2 section 4); an LDS read returning into the registers is harmless (its data arrives 64+ cycles later) and is
 listed as "lds".   usage: asm_store_audit.py file.s <kernel-substring> [W=4]"""
 import re, sys
 s = open(sys.argv[1]).read(); pat = sys.argv[2]; W = int(sys.argv[3]) if len(sys.argv) > 3 else 4

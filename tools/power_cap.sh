@@ -1,5 +1,5 @@
 #!/bin/bash
-# GPU box: sustained MFMA / HBM rates at the power cap, and clock + power of the RoomNet forward pass
+# GPU box: sustained MFMA / HBM rates at the power cap, and clock + power of the RoomNet forward pass (NOTES.md, rounds 1-2 section 5a)
 cd $GRAFT_REPO_ROOT
 smi() { rocm-smi --showclocks --showpower 2>&1 | grep -E "sclk|Package Power" | sed -e 's/.*sclk clock level: [0-9S]*: //' -e 's/.*Power (W): /W /' | tr '\n' ' '; echo; }
 (while true; do echo "   [smi] $(smi)"; sleep 1; done) &
