@@ -497,6 +497,52 @@ static double rn_backfill_cost(long wgs, long slots, int rows, int wgs_per_cu) {
     return (whole + (frac > 1e-9 ? std::max(frac, 0.6) : 0.0)) * (rows + 3.0);
 }
 
+#ifdef RN_CLOCK
+// diagnostic build: every launch of a forward pass gets its own region of one host-visible buffer for the per-workgroup
+// (delta s_memtime, delta s_memrealtime) pairs; nothing is synchronised or printed unless RN_CLOCK_REPORT is set in the
+// environment WHEN the pass is enqueued (tools/gpu_clock.sh sets it for the last pass of a multi-second run), so the
+// stamped pass runs back to back with the ones before it
+struct ClockRegion {
+    char what[32];
+    size_t off, nwg;
+};
+static unsigned long long* g_clock_buf = nullptr;
+static std::vector<ClockRegion> g_clock_regions;
+static size_t g_clock_used = 0;
+static unsigned long long* rn_clock_region(const char* what, size_t nwg) {
+    if (!g_clock_buf) (void)hipHostMalloc(reinterpret_cast<void**>(&g_clock_buf), 16u << 20, 0);
+    ClockRegion r{};
+    snprintf(r.what, sizeof r.what, "%s", what);
+    r.off = g_clock_used;
+    r.nwg = nwg;
+    g_clock_used += 2 * nwg;
+    g_clock_regions.push_back(r);
+    return g_clock_buf + r.off;
+}
+static void rn_clock_begin() {
+    g_clock_regions.clear();
+    g_clock_used = 0;
+}
+static void rn_clock_end(hipStream_t stream) {
+    if (!getenv("RN_CLOCK_REPORT")) return;
+    (void)hipStreamSynchronize(stream);
+    for (const ClockRegion& r : g_clock_regions) {
+        const unsigned long long* buf = g_clock_buf + r.off;
+        std::vector<double> ghz, us;
+        for (size_t k = 0; k < r.nwg; ++k)
+            if (buf[2 * k + 1]) {
+                ghz.push_back(static_cast<double>(buf[2 * k]) / static_cast<double>(buf[2 * k + 1]) * 0.1);
+                us.push_back(static_cast<double>(buf[2 * k + 1]) * 0.01);
+            }
+        if (ghz.empty()) continue;
+        std::sort(ghz.begin(), ghz.end());
+        std::sort(us.begin(), us.end());
+        fprintf(stderr, "[clock] %-12s in-kernel clock %.3f GHz (median of %zu workgroups; 10th / 90th percentile %.3f / %.3f), workgroup lifetime %.1f us median\n",
+                r.what, ghz[ghz.size() / 2], ghz.size(), ghz[ghz.size() / 10], ghz[ghz.size() * 9 / 10], us[us.size() / 2]);
+    }
+}
+#endif
+
 struct FusedStage {
     bool use_rw = false;         // register-weights kernel (rn_stage_rw.hip) covers this stage
     bool use_c16 = false;        // 16x16x32-tile kernel (rn_conv16.hip) runs this stage instead
@@ -851,6 +897,9 @@ int rn_fused_forward(rn_handle* h, const uint8_t* d_bgr, const float* d_rgb, int
         return RN_E_STATE;
     }
     const int dti = h->dtype == RN_DTYPE_BF16 ? 0 : 1;
+#ifdef RN_CLOCK
+    rn_clock_begin();
+#endif
     // stage 0 (a launch of its own unless stage 1's kernel computes it)
     if (fs->fuse_s0) {
         rn_record_event(h, 2);
@@ -898,6 +947,9 @@ int rn_fused_forward(rn_handle* h, const uint8_t* d_bgr, const float* d_rgb, int
             if (rc != RN_OK) return rc;
             rn_record_event(h, 2 + static_cast<int>(i) + 1);
             rn_record_event(h, 2 + static_cast<int>(h->stages.size()));
+#ifdef RN_CLOCK
+            rn_clock_end(h->stream);
+#endif
             return RN_OK;
         }
         if (static_cast<int>(i) == fs->pair_first) {
@@ -948,6 +1000,9 @@ int rn_fused_forward(rn_handle* h, const uint8_t* d_bgr, const float* d_rgb, int
             if (!stamp_host23) (void)hipHostMalloc(reinterpret_cast<void**>(&stamp_host23), 16u << 20, 0);
             std::memset(stamp_host23, 0, nwaves23 * 96);
             fa.stamp_buf = stamp_host23;
+#endif
+#ifdef RN_CLOCK
+            if (fs->pair_x16) fa.stamp_buf = rn_clock_region("stages 2+3", static_cast<size_t>(fa.n_bands) * fa.n_cblocks * n);
 #endif
             int rc = fs->pair_x16 ? rn_stage23x_launch(h->dtype, h->stream, fa, n) : rn_stage23_launch(h->dtype, h->stream, fa, n);
             if (rc != RN_OK) return rc;
@@ -1128,6 +1183,13 @@ int rn_fused_forward(rn_handle* h, const uint8_t* d_bgr, const float* d_rgb, int
             std::memset(stamp_host, 0, nwaves * 32);
             a.stamp_buf = stamp_host;
 #endif
+#ifdef RN_CLOCK
+            {
+                char what[32];
+                snprintf(what, sizeof what, a.s0_bgr ? "stages 0+%zu" : "stage %zu", i);
+                a.stamp_buf = rn_clock_region(what, static_cast<size_t>(grid.x) * grid.y);
+            }
+#endif
             int rc = rn_rw_launch(f.rw, h->dtype, h->stream, a, grid);
             if (rc != RN_OK) return rc;
 #ifdef RN_STAMPS
@@ -1226,5 +1288,8 @@ int rn_fused_forward(rn_handle* h, const uint8_t* d_bgr, const float* d_rgb, int
     int rc = rn_run_head(h, n, d_probs, d_ids);
     if (rc != RN_OK) return rc;
     rn_record_event(h, 2 + static_cast<int>(h->stages.size()));
+#ifdef RN_CLOCK
+    rn_clock_end(h->stream);
+#endif
     return RN_OK;
 }

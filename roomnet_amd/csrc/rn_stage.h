@@ -126,6 +126,15 @@ __device__ __forceinline__ float mul_rounded(float a, float b) {
 
 __device__ __forceinline__ float relu6f(float v) { return __builtin_amdgcn_fmed3f(v, 0.f, 6.f); }
 
+#ifdef RN_CLOCK
+// Diagnostic build (-DRN_CLOCK, tools/build_clock.sh; never shipped): the in-kernel clock of a launch is
+// delta(s_memtime) / delta(s_memrealtime) x 100 MHz (MI355X_MICROARCH.md, DVFS give-back item 6), stamped once at the entry
+// and once at the exit of one wave per workgroup; the values go to a buffer of their own, nothing is computed from them.
+__device__ __forceinline__ void clock_pair(unsigned long long& t, unsigned long long& r) {
+    asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t), "=s"(r)::"memory");
+}
+#endif
+
 // ------------------------------------------------------------------------ LDS-DMA / barrier helpers
 template <int P>
 using IC = std::integral_constant<int, P>;

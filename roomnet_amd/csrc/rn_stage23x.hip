@@ -86,6 +86,10 @@ __global__ __launch_bounds__(512, 2) void stage23x_kernel(const Stage23Args a) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wq = wave & 3;
     const int px16 = lane & 15, g = lane >> 4;           // tile column / K group (conv operand), pixel / cout group (pooled tiles)
+#ifdef RN_CLOCK
+    unsigned long long ck_t0, ck_r0;
+    clock_pair(ck_t0, ck_r0);
+#endif
     const int cblk = blockIdx.x % a.n_cblocks, band = blockIdx.x / a.n_cblocks, n = blockIdx.y;
     const int Win = a.W, Hout = a.Wo, x0 = a.cb_x0[cblk];
     const int Wo = a.cb_wo[cblk], W = Wo + 10, Wb = W - 5;
@@ -651,6 +655,15 @@ __global__ __launch_bounds__(512, 2) void stage23x_kernel(const Stage23Args a) {
     if (rem > 1) step(IC<1>{}, t + 1);
     if (rem > 2) step(IC<2>{}, t + 2);
     wait_vmcnt<0>();
+#ifdef RN_CLOCK
+    if (a.stamp_buf && tid == 256) {
+        unsigned long long t1, r1;
+        clock_pair(t1, r1);
+        const int64_t wg = static_cast<int64_t>(blockIdx.y) * gridDim.x + blockIdx.x;
+        a.stamp_buf[wg * 2 + 0] = t1 - ck_t0;
+        a.stamp_buf[wg * 2 + 1] = r1 - ck_r0;
+    }
+#endif
 }
 
 }  // namespace

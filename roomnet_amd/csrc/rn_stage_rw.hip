@@ -173,6 +173,10 @@ __global__ __launch_bounds__(64 * NPT * ((COUT + 31) / 32) * KS, 1) void stage_r
 #ifdef RN_STAMPS
     const unsigned long long st_entry = stamp();
 #endif
+#ifdef RN_CLOCK
+    unsigned long long ck_t0, ck_r0;
+    clock_pair(ck_t0, ck_r0);
+#endif
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1070,6 +1074,15 @@ __global__ __launch_bounds__(64 * NPT * ((COUT + 31) / 32) * KS, 1) void stage_r
         ((s % RW_NSLOT == I ? (step(IC<I>{}, F{}, T{}, s), 0) : 0), ...);
     }(std::make_integer_sequence<int, RW_NSLOT>{});
     wait_vmcnt<0>();   // the clamped re-fetches of the last steps are still in flight
+#ifdef RN_CLOCK
+    if (a.stamp_buf && tid == 0) {
+        unsigned long long t1, r1;
+        clock_pair(t1, r1);
+        const int64_t wg = static_cast<int64_t>(blockIdx.y) * gridDim.x + blockIdx.x;
+        a.stamp_buf[wg * 2 + 0] = t1 - ck_t0;
+        a.stamp_buf[wg * 2 + 1] = r1 - ck_r0;
+    }
+#endif
 #ifdef RN_STAMPS
     if (a.stamp_buf && lane == 0) {
         const int64_t w = (static_cast<int64_t>(blockIdx.y) * gridDim.x + blockIdx.x) * (NTHREADS / 64) + wave;
