@@ -50,11 +50,13 @@ extern "C" {
  *     input levels);
  *   - avg-pool 4x4 stride 1 (stages 1-3): ReLU6 outputs are rounded to fp16, vertical pair
  *     sums are fp16 adds, and the window sums run on the matrix cores (fp16 x 0/1 band
- *     matrix, exact float32 accumulation); stride-2 pools are float32 VALU sums;
+ *     matrix, exact float32 accumulation); stride-2 pools are float32 VALU sums, except
+ *     stage 5 at 224 x 224 (rn_stage5x.hip), which pools like the stride-1 stages (fp16
+ *     ReLU6 outputs and pair sums, band-matrix MFMA);
  *   - residual resize: the horizontal interpolation is an MFMA against the interpolation
- *     matrix in the storage type -- stage 3: one operand, lerp fraction rounded to 2^-8
- *     (bf16) / 2^-11 (fp16) so that both weights are exact; stages 5, 9: hi + lo split
- *     (~16-bit weights). */
+ *     matrix in the storage type -- stage 3, and stage 5 at 224 x 224: one operand, lerp
+ *     fraction rounded to 2^-8 (bf16) / 2^-11 (fp16) so that both weights are exact;
+ *     stage 9, and stage 5 at other sizes: hi + lo split (~16-bit weights). */
 #define RN_DTYPE_F32 0      /* reference arithmetic type (TensorFlow float32)      */
 #define RN_DTYPE_BF16 1
 #define RN_DTYPE_F16 2
@@ -69,10 +71,12 @@ extern "C" {
                                that only feeds its fused successor is then never written) */
 #define RN_FLAG_GENERIC_KERNELS 4u /* 16-bit handles: every stage on the generic
                                stage_mfma_kernel (diagnostic cross-check of the tuned kernels) */
-#define RN_FLAG_PAIR_32X32 8u /* 16-bit handles: the cross-stage fused pair (last two steps of a
-                               depth-3 conv_block, network.py:183-203) on the round-2 32x32x16 kernel
-                               (rn_stage23.hip) instead of the 16x16x32 one (rn_stage23x.hip):
-                               comparison arm; results differ in the last 16-bit place at most */
+#define RN_FLAG_PAIR_32X32 8u /* 16-bit handles: the round-2 32x32x16 kernels instead of the round-3
+                               16x16x32 ones -- the cross-stage fused pair (last two steps of a depth-3
+                               conv_block, network.py:183-203: rn_stage23.hip instead of rn_stage23x.hip,
+                               bit-identical) and the residual step of the 64-channel block
+                               (network.py:228: rn_stage_rw.hip instead of rn_stage5x.hip; differs in
+                               the last 16-bit place).  Comparison arm */
 
 #define RN_MAX_STAGES 16
 #define RN_MAX_DENSE 8

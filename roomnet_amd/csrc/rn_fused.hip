@@ -547,6 +547,7 @@ struct FusedStage {
     bool use_rw = false;         // register-weights kernel (rn_stage_rw.hip) covers this stage
     bool use_c16 = false;        // 16x16x32-tile kernel (rn_conv16.hip) runs this stage instead
     bool use_c16p = false;       // ... its pooled 128 -> 16 sibling
+    bool use_s5x = false;        // the 64 -> 64 residual stage on 16x16x32 tiles with row-register blocking (rn_stage5x.hip)
     i32x4* wfrag16 = nullptr;    // its weight fragments
     RwPlan rw;
     float* ptab = nullptr;       // folded BN tables for the rw kernel
@@ -790,6 +791,22 @@ int rn_fused_prepare(rn_handle* h, const rn_weights* w) {
             RN_HIP(hipMemcpy(d16, f16.data(), f16.size() * 2, hipMemcpyHostToDevice));
             f.wfrag16 = static_cast<i32x4*>(d16);
             f.use_c16 = true;
+        }
+        if (f.use_rw && f.ptab && !(h->flags & (RN_FLAG_GENERIC_KERNELS | RN_FLAG_PAIR_32X32)) && s.skip_stage >= 0 &&
+            rn_stage5x_supported(s.cin, s.cout, s.pool_k, s.pool_s, true, s.in_side, s.skip_side) &&
+            s.skip_stage == static_cast<int>(i) - 1 && h->stages[s.skip_stage].node_bn2 < 0) {
+            // (the skip tensor must be the stage's own input: the kernel interpolates it from its input ring)
+            std::vector<unsigned short> f16;
+            rn_stage5x_pack(wsrc, h->dtype, f32_to_bf16, f32_to_f16, &f16);
+            void* d16 = nullptr;
+            if (hipMalloc(&d16, f16.size() * 2) != hipSuccess) {
+                rn_set_error("hipMalloc(stage5x weights) failed");
+                return RN_E_NOMEM;
+            }
+            h->allocs.push_back(d16);
+            RN_HIP(hipMemcpy(d16, f16.data(), f16.size() * 2, hipMemcpyHostToDevice));
+            f.wfrag16 = static_cast<i32x4*>(d16);
+            f.use_s5x = true;
         }
         if (f.use_rw && f.ptab && rn_conv16p_supported(s.cin, s.cout, s.pool_k, s.pool_s, s.skip_stage >= 0) &&
             !(h->flags & RN_FLAG_GENERIC_KERNELS)) {
@@ -1095,6 +1112,19 @@ int rn_fused_forward(rn_handle* h, const uint8_t* d_bgr, const float* d_rgb, int
             ca.rows_per_band = (s.out_side + bands - 1) / bands;
             ca.n_bands = (s.out_side + ca.rows_per_band - 1) / ca.rows_per_band;
             int rc = rn_conv16_launch(h->dtype, h->stream, ca, n);
+            if (rc != RN_OK) return rc;
+            rn_record_event(h, 2 + static_cast<int>(i));
+            continue;
+        }
+        if (f.use_s5x) {
+            a.wfrag = f.wfrag16;
+            a.ptab = f.ptab;
+            // one workgroup (8 waves, 127 KB of LDS) per CU: one band per image once the batch fills the chip
+            int bands = 1;
+            if (n < h->n_cu) bands = std::min((h->n_cu + n - 1) / n, std::max(1, s.out_side / 4));
+            a.rows_per_band = (s.out_side + bands - 1) / bands;
+            a.n_bands = (s.out_side + a.rows_per_band - 1) / a.rows_per_band;
+            int rc = rn_stage5x_launch(h->dtype, h->stream, a, n);
             if (rc != RN_OK) return rc;
             rn_record_event(h, 2 + static_cast<int>(i));
             continue;
