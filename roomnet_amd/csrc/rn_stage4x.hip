@@ -193,17 +193,27 @@ __global__ __launch_bounds__(512, 2) void stage4x_kernel(const StageArgs a) {
         for (int kx = 0; kx < 3; ++kx) bc[kx] = base[kx] + so;
         i32x4 op[U_NT + 1];
         op[U_NT - 1] = op[U_NT] = i32x4{0, 0, 0, 0};
-        auto tile = [&](auto KC) __attribute__((always_inline)) {
+        // operand fragments double-buffered across tiles: tile k + 1's three reads go out before tile k's MFMAs (a tile's
+        // chain is only 9 MFMAs long: the LDS round trip at its head was a bubble as long as the chain itself)
+        i32x4 fq[2][3];
+        auto reads = [&](auto KC) __attribute__((always_inline)) {
             constexpr int k = decltype(KC)::value;
-            i32x4 fq[3];
+            auto& dst = fq[k & 1];
+            auto& bcr = bc;                                            // (named outside the asm: implicit capture)
 #pragma unroll
-            for (int f = 0; f < 3; ++f) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fq[f]) : "v"(bc[f]), "n"(k * 1024));
+            for (int f = 0; f < 3; ++f) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst[f]) : "v"(bcr[f]), "n"(k * 1024));
+        };
+        auto tile = [&](auto KC, auto NEXTC) __attribute__((always_inline)) {
+            constexpr int k = decltype(KC)::value;
+            constexpr bool NEXT = decltype(NEXTC)::value != 0;        // tile k + 1's reads are issued here (3 more in flight)
+            if constexpr (NEXT) reads(IC<k + 1>{});
+            auto& cur = fq[k & 1];
             [&]<int... F>(std::integer_sequence<int, F...>) {
                 (([&] {
-                     asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(fq[F]) : "n"(2 - F));
-                     acc[iN][k] = mfma16<DT>(fq[F], wf[0 * 3 + F], F == 0 ? zero4 : acc[iN][k]);
-                     acc[iM][k] = mfma16<DT>(fq[F], wf[1 * 3 + F], acc[iM][k]);
-                     acc[iO][k] = mfma16<DT>(fq[F], wf[2 * 3 + F], acc[iO][k]);
+                     asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(cur[F]) : "n"((NEXT ? 3 : 0) + 2 - F));
+                     acc[iN][k] = mfma16<DT>(cur[F], wf[0 * 3 + F], F == 0 ? zero4 : acc[iN][k]);
+                     acc[iM][k] = mfma16<DT>(cur[F], wf[1 * 3 + F], acc[iM][k]);
+                     acc[iO][k] = mfma16<DT>(cur[F], wf[2 * 3 + F], acc[iO][k]);
                  }()),
                  ...);
             }(std::make_integer_sequence<int, 3>{});
@@ -222,13 +232,17 @@ __global__ __launch_bounds__(512, 2) void stage4x_kernel(const StageArgs a) {
                 pp2[k][1] = n1;
             }
         };
-        tile(IC<0>{});
-        tile(IC<1>{});
-        tile(IC<2>{});
-        tile(IC<3>{});
-        tile(IC<4>{});
-        tile(IC<5>{});
-        if (has7) tile(IC<6>{});
+        reads(IC<0>{});
+        tile(IC<0>{}, IC<1>{});
+        tile(IC<1>{}, IC<1>{});
+        tile(IC<2>{}, IC<1>{});
+        tile(IC<3>{}, IC<1>{});
+        tile(IC<4>{}, IC<1>{});
+        tile(IC<5>{}, IC<0>{});
+        if (has7) {                       // (the seventh tile's reads stay behind the branch: its tile code exists once)
+            reads(IC<6>{});
+            tile(IC<6>{}, IC<0>{});
+        }
         if constexpr (PAR == 1) {
             // odd conv row j = s - 2 >= 3 completes pooled row r = (j - 3) / 2
             const int r = (s - 5) >> 1;

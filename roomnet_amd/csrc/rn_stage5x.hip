@@ -239,21 +239,37 @@ __global__ __launch_bounds__(512, 2) void stage5x_kernel(const StageArgs a) {
         for (int kx = 0; kx < 3; ++kx)
 #pragma unroll
             for (int ch = 0; ch < 2; ++ch) bc[kx][ch] = base[kx][ch] + so;
-        auto tile = [&](auto KC) __attribute__((always_inline)) {
-            constexpr int k = decltype(KC)::value;
-            i32x4 fq[6];
+        // A tile's six operand fragments are read in two batches of three (channel half 0, then 1), double-buffered across
+        // batches AND tiles: batch b + 1's reads go out before batch b's nine MFMAs, so the LDS round trip never stands at
+        // the head of a chain (a batch is only 9 MFMAs long)
+        i32x4 fq[2][3];
+        auto reads = [&](auto BC) __attribute__((always_inline)) {
+            constexpr int b = decltype(BC)::value, k = b >> 1, ch = b & 1;
+            auto& dst = fq[b & 1];
+            auto& bcr = bc;                                            // (named outside the asm: implicit capture)
 #pragma unroll
-            for (int f = 0; f < 6; ++f) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fq[f]) : "v"(bc[f >> 1][f & 1]), "n"(k * 2048));
-            [&]<int... F>(std::integer_sequence<int, F...>) {
+            for (int kx = 0; kx < 3; ++kx) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst[kx]) : "v"(bcr[kx][ch]), "n"(k * 2048));
+        };
+        auto batch = [&](auto BC, auto NEXTC) __attribute__((always_inline)) {
+            constexpr int b = decltype(BC)::value, k = b >> 1, ch = b & 1;
+            constexpr bool NEXT = decltype(NEXTC)::value != 0;        // batch b + 1's reads are issued here (3 more in flight)
+            if constexpr (NEXT) reads(IC<b + 1>{});
+            auto& cur = fq[b & 1];
+            [&]<int... KX>(std::integer_sequence<int, KX...>) {
                 (([&] {
-                     asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(fq[F]) : "n"(5 - F));
-                     constexpr int kx = F >> 1, ch = F & 1;
-                     acc[iN][k] = mfma16<DT>(fq[F], wf[(0 * 3 + kx) * 2 + ch], F == 0 ? zero4 : acc[iN][k]);
-                     acc[iM][k] = mfma16<DT>(fq[F], wf[(1 * 3 + kx) * 2 + ch], acc[iM][k]);
-                     acc[iO][k] = mfma16<DT>(fq[F], wf[(2 * 3 + kx) * 2 + ch], acc[iO][k]);
+                     asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(cur[KX]) : "n"((NEXT ? 3 : 0) + 2 - KX));
+                     acc[iN][k] = mfma16<DT>(cur[KX], wf[(0 * 3 + KX) * 2 + ch], (ch == 0 && KX == 0) ? zero4 : acc[iN][k]);
+                     acc[iM][k] = mfma16<DT>(cur[KX], wf[(1 * 3 + KX) * 2 + ch], acc[iM][k]);
+                     acc[iO][k] = mfma16<DT>(cur[KX], wf[(2 * 3 + KX) * 2 + ch], acc[iO][k]);
                  }()),
                  ...);
-            }(std::make_integer_sequence<int, 6>{});
+            }(std::make_integer_sequence<int, 3>{});
+        };
+        auto tile = [&](auto KC, auto LASTC) __attribute__((always_inline)) {
+            constexpr int k = decltype(KC)::value;
+            constexpr bool LAST = decltype(LASTC)::value != 0;        // no batch follows this tile's second one
+            batch(IC<2 * k>{}, IC<1>{});
+            batch(IC<2 * k + 1>{}, IC<(LAST ? 0 : 1)>{});
         };
         // conv row j = s - 2 is complete in acc[iO] after the tile's chain: ReLU6 -> fp16 pairs; even rows wait in hp, odd
         // rows form the pair sum and the pooling operand [previous pair sum | this pair sum]
@@ -274,14 +290,16 @@ __global__ __launch_bounds__(512, 2) void stage5x_kernel(const StageArgs a) {
                 pp2[k][1] = n1;
             }
         };
-        tile(IC<0>{});
+        reads(IC<0>{});
+        tile(IC<0>{}, IC<0>{});
         finish(IC<0>{});
-        tile(IC<1>{});
+        tile(IC<1>{}, IC<0>{});
         finish(IC<1>{});
-        tile(IC<2>{});
+        tile(IC<2>{}, IC<1>{});
         finish(IC<2>{});
-        if (has4) {
-            tile(IC<3>{});
+        if (has4) {                       // (the fourth tile's first reads stay behind the branch)
+            reads(IC<6>{});
+            tile(IC<3>{}, IC<1>{});
             finish(IC<3>{});
         }
         if constexpr (PAR == 1) {
