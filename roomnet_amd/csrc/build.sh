@@ -23,12 +23,13 @@ done
 "$HIPCC" "${CFLAGS[@]}" ${RN_RW_FLAGS:--mllvm -amdgpu-mfma-vgpr-form} -c "$HERE/rn_stage23x.hip" -o "$OBJ/rn_stage23x.o" &
 "$HIPCC" "${CFLAGS[@]}" ${RN_RW_FLAGS:--mllvm -amdgpu-mfma-vgpr-form} -c "$HERE/rn_stage5x.hip" -o "$OBJ/rn_stage5x.o" &
 "$HIPCC" "${CFLAGS[@]}" ${RN_RW_FLAGS:--mllvm -amdgpu-mfma-vgpr-form} -c "$HERE/rn_stage4x.hip" -o "$OBJ/rn_stage4x.o" &
+"$HIPCC" "${CFLAGS[@]}" ${RN_RW_FLAGS:--mllvm -amdgpu-mfma-vgpr-form} -c "$HERE/rn_stage6x.hip" -o "$OBJ/rn_stage6x.o" &
 wait
-"$HIPCC" --offload-arch=gfx950 -shared -fPIC "$OBJ"/rn_api.o "$OBJ"/rn_kernels_f32.o "$OBJ"/rn_fused.o "$OBJ"/rn_imageops.o "$OBJ"/rn_group.o "$OBJ"/rn_tail.o "$OBJ"/rn_conv16.o "$OBJ"/rn_stage_rw.o "$OBJ"/rn_stage23.o "$OBJ"/rn_stage23x.o "$OBJ"/rn_stage5x.o "$OBJ"/rn_stage4x.o -ldl -lpthread \
+"$HIPCC" --offload-arch=gfx950 -shared -fPIC "$OBJ"/rn_api.o "$OBJ"/rn_kernels_f32.o "$OBJ"/rn_fused.o "$OBJ"/rn_imageops.o "$OBJ"/rn_group.o "$OBJ"/rn_tail.o "$OBJ"/rn_conv16.o "$OBJ"/rn_stage_rw.o "$OBJ"/rn_stage23.o "$OBJ"/rn_stage23x.o "$OBJ"/rn_stage5x.o "$OBJ"/rn_stage4x.o "$OBJ"/rn_stage6x.o -ldl -lpthread \
     ${RN_EXTRA_FLAGS:-} -o "$OUT/libroomnet_hip.so"
 echo "built $OUT/libroomnet_hip.so"
 # register report of the hot kernels: a spill in one of them costs ~25 % of its time (seen on the fused stage pair) and
 # hipcc does not warn about it
 if [ -x "$ROOT/tools/spills.sh" ]; then
-    "$ROOT/tools/spills.sh" "$OBJ"/rn_stage23.o "$OBJ"/rn_stage23x.o "$OBJ"/rn_stage5x.o "$OBJ"/rn_stage4x.o "$OBJ"/rn_stage_rw.o "$OBJ"/rn_tail.o "$OBJ"/rn_conv16.o | awk '$0 ~ /spills +[1-9]/ {print "  spills: " $0}' | cut -c1-70,95-200 || true
+    "$ROOT/tools/spills.sh" "$OBJ"/rn_stage23.o "$OBJ"/rn_stage23x.o "$OBJ"/rn_stage5x.o "$OBJ"/rn_stage4x.o "$OBJ"/rn_stage6x.o "$OBJ"/rn_stage_rw.o "$OBJ"/rn_tail.o "$OBJ"/rn_conv16.o | awk '$0 ~ /spills +[1-9]/ {print "  spills: " $0}' | cut -c1-70,95-200 || true
 fi

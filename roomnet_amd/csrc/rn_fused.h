@@ -54,6 +54,11 @@ void rn_conv16p_pack(const float* w_hwio, int dtype, unsigned short (*cvt_bf16)(
 int rn_conv16p_launch(int dtype, hipStream_t s, const rnk::Conv16Args& a, int n);
 bool rn_stage23_plan(int in_side, int* n_cblocks, int* x0, int* wo);   // column blocks (x0, wo: 4 entries)
 int rn_stage23_launch(int dtype, hipStream_t s, const rnk::Stage23Args& a, int n);
+// the un-pooled 64 -> 128 stage with row-register blocking (rn_stage6x.hip)
+bool rn_stage6x_supported(int cin, int cout, int pool_k, bool res, int in_side);
+void rn_stage6x_pack(const float* w_hwio, int dtype, unsigned short (*cvt_bf16)(float), unsigned short (*cvt_f16)(float),
+                     std::vector<unsigned short>* out);
+int rn_stage6x_launch(int dtype, hipStream_t s, const rnk::StageArgs& a, int n);
 // the 32 -> 64 stage with pool 4/2 on 16x16x32 tiles with row-register blocking (rn_stage4x.hip)
 bool rn_stage4x_supported(int cin, int cout, int pool_k, int pool_s, bool res, int in_side);
 void rn_stage4x_pack(const float* w_hwio, int dtype, unsigned short (*cvt_bf16)(float), unsigned short (*cvt_f16)(float),

@@ -549,6 +549,7 @@ struct FusedStage {
     bool use_c16p = false;       // ... its pooled 128 -> 16 sibling
     bool use_s5x = false;        // the 64 -> 64 residual stage on 16x16x32 tiles with row-register blocking (rn_stage5x.hip)
     bool use_s4x = false;        // the 32 -> 64 stage likewise (rn_stage4x.hip)
+    bool use_s6x = false;        // the un-pooled 64 -> 128 stage likewise (rn_stage6x.hip)
     i32x4* wfrag16 = nullptr;    // its weight fragments
     RwPlan rw;
     float* ptab = nullptr;       // folded BN tables for the rw kernel
@@ -792,6 +793,21 @@ int rn_fused_prepare(rn_handle* h, const rn_weights* w) {
             RN_HIP(hipMemcpy(d16, f16.data(), f16.size() * 2, hipMemcpyHostToDevice));
             f.wfrag16 = static_cast<i32x4*>(d16);
             f.use_c16 = true;
+        }
+        if (f.use_rw && f.ptab && !(h->flags & (RN_FLAG_GENERIC_KERNELS | RN_FLAG_PAIR_32X32)) &&
+            rn_stage6x_supported(s.cin, s.cout, s.pool_k, s.skip_stage >= 0, s.in_side)) {
+            std::vector<unsigned short> f16;
+            rn_stage6x_pack(wsrc, h->dtype, f32_to_bf16, f32_to_f16, &f16);
+            void* d16 = nullptr;
+            if (hipMalloc(&d16, f16.size() * 2) != hipSuccess) {
+                rn_set_error("hipMalloc(stage6x weights) failed");
+                return RN_E_NOMEM;
+            }
+            h->allocs.push_back(d16);
+            RN_HIP(hipMemcpy(d16, f16.data(), f16.size() * 2, hipMemcpyHostToDevice));
+            f.wfrag16 = static_cast<i32x4*>(d16);
+            f.use_s6x = true;
+            f.use_c16 = false;
         }
         if (f.use_rw && f.ptab && !(h->flags & (RN_FLAG_GENERIC_KERNELS | RN_FLAG_PAIR_32X32)) &&
             rn_stage4x_supported(s.cin, s.cout, s.pool_k, s.pool_s, s.skip_stage >= 0, s.in_side)) {
@@ -1131,7 +1147,7 @@ int rn_fused_forward(rn_handle* h, const uint8_t* d_bgr, const float* d_rgb, int
             rn_record_event(h, 2 + static_cast<int>(i));
             continue;
         }
-        if (f.use_s5x || f.use_s4x) {
+        if (f.use_s5x || f.use_s4x || f.use_s6x) {
             a.wfrag = f.wfrag16;
             a.ptab = f.ptab;
             // one workgroup (8 waves, 127 KB of LDS) per CU: one band per image once the batch fills the chip
@@ -1139,7 +1155,9 @@ int rn_fused_forward(rn_handle* h, const uint8_t* d_bgr, const float* d_rgb, int
             if (n < h->n_cu) bands = std::min((h->n_cu + n - 1) / n, std::max(1, s.out_side / 4));
             a.rows_per_band = (s.out_side + bands - 1) / bands;
             a.n_bands = (s.out_side + a.rows_per_band - 1) / a.rows_per_band;
-            int rc = f.use_s5x ? rn_stage5x_launch(h->dtype, h->stream, a, n) : rn_stage4x_launch(h->dtype, h->stream, a, n);
+            int rc = f.use_s5x   ? rn_stage5x_launch(h->dtype, h->stream, a, n)
+                     : f.use_s4x ? rn_stage4x_launch(h->dtype, h->stream, a, n)
+                                 : rn_stage6x_launch(h->dtype, h->stream, a, n);
             if (rc != RN_OK) return rc;
             rn_record_event(h, 2 + static_cast<int>(i));
             continue;

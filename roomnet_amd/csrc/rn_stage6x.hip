@@ -1,0 +1,233 @@
+// Un-pooled 64 -> 128 stage (reference network.py:229, conv_block(128, pooling=False)) on 16x16x32 matrix tiles with
+// ROW-REGISTER BLOCKING (the design of rn_stage4x.hip / rn_stage5x.hip):
+//
+//   in [N, W, W, 64] -> conv3x3 VALID -> ReLU6 -> BN(inference)  = out [N, W-2, W-2, 128]
+//
+// One workgroup = one image (x band of rows); eight waves = the eight 16-cout groups, each for all three 16-pixel tiles of
+// the row (46 conv columns at 224 x 224).  A wave keeps its 16 couts' weights in 72 registers (9 taps x 2 channel halves)
+// and the partial accumulators of conv rows s, s-1, s-2 for its three tiles in 36; every operand fragment of the NEWEST
+// input row feeds three MFMAs (kernel rows 0, 1, 2), so a step reads 6 fragments per tile for 18 MFMAs and the ring only
+// holds the newest row and the rows in flight.  Operands are NOT swapped here (D[cout][pixel]: a lane holds 4 consecutive
+// couts of one pixel = one 8-byte store): there is no pooling that would want the pixels in registers.
+// conv16_kernel (rn_conv16.hip) stays for the other sizes (W > 50).
+#include "rn_fused.h"
+#include "rn_stage.h"
+
+#include <atomic>
+#include <utility>
+
+using namespace rnk;
+
+namespace {
+
+constexpr int S6_NS = 4, S6_AHEAD = 3;
+constexpr int S6_RINGPX = 50;                     // 3 tiles + 2 halo columns
+constexpr int S6_ROW = 52 * 128;                  // bytes per ring row (padded)
+constexpr int S6_LDS = S6_NS * S6_ROW;
+constexpr int S6_WMIN = 35, S6_WMAX = 50;
+
+__device__ __forceinline__ unsigned lds_addr(const void* p) {
+    return static_cast<unsigned>(reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) const char*)p));
+}
+__device__ __forceinline__ int swz8(int pix) { return pix & 7; }
+
+using i32x2 = __attribute__((ext_vector_type(2))) int;
+
+template <int DT>
+__device__ __forceinline__ f32x4 mfma16(i32x4 a, i32x4 b, f32x4 c) {
+    if constexpr (DT == RN_DTYPE_BF16)
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    else
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+
+template <int DT>
+__global__ __launch_bounds__(512, 2) void stage6x_kernel(const StageArgs a) {
+    extern __shared__ __attribute__((aligned(64))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // = cout group (16 couts)
+    const int px16 = lane & 15, g = lane >> 4;
+    const int band = blockIdx.x, n = blockIdx.y;
+    const int W = a.W, Wo = a.Wo, Ho = a.Ho;
+    const int yo0 = band * a.rows_per_band;
+    const int nrows = min(Ho, yo0 + a.rows_per_band) - yo0;
+    const int nin = nrows + 2;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    constexpr int OOB = 0x40000000;
+
+    char* const ring = smem;
+    const unsigned ring_lds = lds_addr(ring);
+    // pixels W .. 51 of every slot are never written by the row DMA: zero them once
+    for (int i = tid; i < S6_NS * (52 - S6_WMIN) * 8; i += 512) {
+        const int slot = i / ((52 - S6_WMIN) * 8), rest = i % ((52 - S6_WMIN) * 8);
+        const int p = S6_WMIN + rest / 8, c = rest % 8;
+        if (p >= W) *reinterpret_cast<i32x4*>(ring + slot * S6_ROW + p * 128 + c * 16) = i32x4{0, 0, 0, 0};
+    }
+
+    // ---- weights: fragment f = (ky * 3 + kx) * 2 + ch, A operand of D[cout][pixel]
+    i32x4 wf[18];
+#pragma unroll
+    for (int f = 0; f < 18; ++f) {
+        const i32x4* src = a.wfrag + (f * 8 + wave) * 64 + lane;
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(wf[f]) : "v"(src) : "memory");
+    }
+
+    // ---- input rows by LDS-DMA: one lane-masked piece per wave and row (W x 8 chunks, W per wave)
+    const char* const in_img = reinterpret_cast<const char*>(a.in + static_cast<int64_t>(n) * W * W * 64);
+    const int row_bytes = W * 128;
+    const unsigned long long dma_mask = (1ull << W) - 1ull;
+    unsigned goff;
+    {
+        const int q = wave * W + min(lane, W - 1);
+        const int p = q >> 3, c = q & 7;
+        goff = static_cast<unsigned>(p * 128 + ((c ^ swz8(p)) << 4));
+    }
+    auto issue_row = [&](int y, int slot) __attribute__((always_inline)) {
+        const char* row = in_img + static_cast<int64_t>(yo0 + min(y, nin - 1)) * row_bytes;
+        unsigned o = goff;
+        asm volatile("" : "+v"(o));
+        dma16_masked(row + o, ring + slot * S6_ROW + wave * W * 16, dma_mask);
+    };
+
+    unsigned base[3][2];
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+        for (int ch = 0; ch < 2; ++ch) {
+            const int p = px16 + kx;
+            base[kx][ch] = ring_lds + static_cast<unsigned>(p * 128 + (((4 * ch + g) ^ swz8(p)) << 4));
+        }
+    int voff[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int xo = 16 * k + px16;
+        voff[k] = xo < Wo ? (xo * 128 + 16 * wave + 4 * g) * 2 : OOB;
+    }
+    const f32x4 sc = *reinterpret_cast<const f32x4*>(a.ptab + 16 * wave + 4 * g);
+    const f32x4 sh = *reinterpret_cast<const f32x4*>(a.ptab + 128 + 16 * wave + 4 * g);
+
+    f32x4 acc[3][3];
+#pragma unroll
+    for (int r3 = 0; r3 < 3; ++r3)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) acc[r3][k] = zero4;
+    const int out_row_bytes = Wo * 256;
+    const char* const out_img = reinterpret_cast<const char*>(a.out + static_cast<int64_t>(n) * Ho * Wo * 128);
+
+#pragma unroll
+    for (int j = 0; j < S6_AHEAD; ++j) issue_row(j, j);
+    wait_vmcnt<0>();
+#pragma unroll
+    for (int f = 0; f < 18; ++f) asm volatile("" : "+v"(wf[f]));
+    lds_barrier();
+
+    int slot_cur = 0;
+    auto step = [&](auto RC, int s) __attribute__((always_inline)) {
+        constexpr int R = decltype(RC)::value;
+        constexpr int iN = R, iM = (R + 2) % 3, iO = (R + 1) % 3;
+        wait_vmcnt<S6_AHEAD - 1>();                                     // row s has landed (rows s+1, s+2 may be in flight)
+        raw_barrier();
+        {
+            int sl = slot_cur + S6_AHEAD;
+            sl = sl >= S6_NS ? sl - S6_NS : sl;
+            issue_row(s + S6_AHEAD, sl);
+        }
+        const unsigned so = static_cast<unsigned>(slot_cur * S6_ROW);
+        unsigned bc[3][2];
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+            for (int ch = 0; ch < 2; ++ch) bc[kx][ch] = base[kx][ch] + so;
+        const int j = s - 2;                                            // conv row completed by this step
+        const int jr = min(max(j, 0), nrows - 1);
+        const char* orow = out_img + static_cast<int64_t>(yo0 + jr) * out_row_bytes;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(orow), 0, out_row_bytes, 0x00020000);
+        const int emask = (j >= 0 && j < nrows) ? 0 : OOB;
+        i32x4 fq[2][3];
+        auto reads = [&](auto BC) __attribute__((always_inline)) {
+            constexpr int b = decltype(BC)::value, k = b >> 1, ch = b & 1;
+            auto& dst = fq[b & 1];
+            auto& bcr = bc;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst[kx]) : "v"(bcr[kx][ch]), "n"(k * 2048));
+        };
+        auto batch = [&](auto BC, auto NEXTC) __attribute__((always_inline)) {
+            constexpr int b = decltype(BC)::value, k = b >> 1, ch = b & 1;
+            constexpr bool NEXT = decltype(NEXTC)::value != 0;
+            if constexpr (NEXT) reads(IC<b + 1>{});
+            auto& cur = fq[b & 1];
+            [&]<int... KX>(std::integer_sequence<int, KX...>) {
+                (([&] {
+                     asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(cur[KX]) : "n"((NEXT ? 3 : 0) + 2 - KX));
+                     acc[iN][k] = mfma16<DT>(wf[(0 * 3 + KX) * 2 + ch], cur[KX], (ch == 0 && KX == 0) ? zero4 : acc[iN][k]);
+                     acc[iM][k] = mfma16<DT>(wf[(1 * 3 + KX) * 2 + ch], cur[KX], acc[iM][k]);
+                     acc[iO][k] = mfma16<DT>(wf[(2 * 3 + KX) * 2 + ch], cur[KX], acc[iO][k]);
+                 }()),
+                 ...);
+            }(std::make_integer_sequence<int, 3>{});
+        };
+        auto emit = [&](auto KC) __attribute__((always_inline)) {
+            constexpr int k = decltype(KC)::value;
+            const f32x4 v = acc[iO][k];
+            float y[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) y[i] = __builtin_fmaf(relu6f(v[i]), sc[i], sh[i]);
+            const i32x2 d = {static_cast<int>(pack2<DT>(y[0], y[1])), static_cast<int>(pack2<DT>(y[2], y[3]))};
+            __builtin_amdgcn_raw_buffer_store_b64(d, rs, voff[k] | emask, 0, 0);
+        };
+        reads(IC<0>{});
+        batch(IC<0>{}, IC<1>{});
+        batch(IC<1>{}, IC<1>{});
+        emit(IC<0>{});
+        batch(IC<2>{}, IC<1>{});
+        batch(IC<3>{}, IC<1>{});
+        emit(IC<1>{});
+        batch(IC<4>{}, IC<1>{});
+        batch(IC<5>{}, IC<0>{});
+        emit(IC<2>{});
+        slot_cur = slot_cur == S6_NS - 1 ? 0 : slot_cur + 1;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    };
+    int s = 0;
+    for (; s + 2 < nin; s += 3) {
+        step(IC<0>{}, s);
+        step(IC<1>{}, s + 1);
+        step(IC<2>{}, s + 2);
+    }
+    const int rem = nin - s;
+    if (rem > 0) step(IC<0>{}, s);
+    if (rem > 1) step(IC<1>{}, s + 1);
+    wait_vmcnt<0>();
+}
+
+}  // namespace
+
+bool rn_stage6x_supported(int cin, int cout, int pool_k, bool res, int in_side) {
+    return cin == 64 && cout == 128 && pool_k == 0 && !res && in_side >= S6_WMIN && in_side <= S6_WMAX;
+}
+
+// A-operand fragments: frag[f = (ky * 3 + kx) * 2 + ch][cout group q][lane][j] = W[tap][channel 32 ch + 8 (lane / 16) + j][cout 16 q + lane % 16]
+void rn_stage6x_pack(const float* w_hwio, int dtype, unsigned short (*cvt_bf16)(float), unsigned short (*cvt_f16)(float),
+                     std::vector<unsigned short>* out) {
+    out->assign(static_cast<size_t>(18) * 8 * 64 * 8, 0);
+    for (int f = 0; f < 18; ++f)
+        for (int q = 0; q < 8; ++q)
+            for (int l = 0; l < 64; ++l)
+                for (int j = 0; j < 8; ++j) {
+                    const int tap = f >> 1, ch = f & 1;
+                    const int k = tap * 64 + 32 * ch + 8 * (l >> 4) + j, co = 16 * q + (l & 15);
+                    const float v = w_hwio[static_cast<size_t>(k) * 128 + co];
+                    (*out)[((static_cast<size_t>(f) * 8 + q) * 64 + l) * 8 + j] = dtype == RN_DTYPE_BF16 ? cvt_bf16(v) : cvt_f16(v);
+                }
+}
+
+int rn_stage6x_launch(int dtype, hipStream_t s, const StageArgs& a, int n) {
+    auto launch = [&](auto kern) -> int {
+        hipLaunchKernelGGL(kern, dim3(a.n_bands, n), dim3(512), S6_LDS, s, a);
+        RN_CHECK_LAUNCH();
+        return RN_OK;
+    };
+    if (dtype == RN_DTYPE_BF16) return launch(stage6x_kernel<RN_DTYPE_BF16>);
+    return launch(stage6x_kernel<RN_DTYPE_F16>);
+}

@@ -16,6 +16,7 @@ for f in rn_api rn_kernels_f32 rn_fused rn_imageops rn_group rn_tail rn_conv16; 
 /opt/rocm/bin/hipcc "${FLAGS[@]}" -mllvm -amdgpu-mfma-vgpr-form -c "$SRC/rn_stage23x.hip" -o "$OBJ/rn_stage23x.o" &
 /opt/rocm/bin/hipcc "${FLAGS[@]}" -mllvm -amdgpu-mfma-vgpr-form -c "$SRC/rn_stage5x.hip" -o "$OBJ/rn_stage5x.o" &
 /opt/rocm/bin/hipcc "${FLAGS[@]}" -mllvm -amdgpu-mfma-vgpr-form -c "$SRC/rn_stage4x.hip" -o "$OBJ/rn_stage4x.o" &
+/opt/rocm/bin/hipcc "${FLAGS[@]}" -mllvm -amdgpu-mfma-vgpr-form -c "$SRC/rn_stage6x.hip" -o "$OBJ/rn_stage6x.o" &
 wait
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC "$OBJ"/*.o -ldl -lpthread -o "$ROOT/roomnet_amd/lib/libroomnet_hip_stamps$SUF.so"
 echo "built $ROOT/roomnet_amd/lib/libroomnet_hip_stamps$SUF.so"
