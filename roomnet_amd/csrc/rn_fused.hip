@@ -1155,6 +1155,13 @@ int rn_fused_forward(rn_handle* h, const uint8_t* d_bgr, const float* d_rgb, int
             if (n < h->n_cu) bands = std::min((h->n_cu + n - 1) / n, std::max(1, s.out_side / 4));
             a.rows_per_band = (s.out_side + bands - 1) / bands;
             a.n_bands = (s.out_side + a.rows_per_band - 1) / a.rows_per_band;
+#ifdef RN_CLOCK
+            {
+                char what[32];
+                snprintf(what, sizeof what, "stage %d", static_cast<int>(i));
+                a.stamp_buf = rn_clock_region(what, static_cast<size_t>(a.n_bands) * n);
+            }
+#endif
             int rc = f.use_s5x   ? rn_stage5x_launch(h->dtype, h->stream, a, n)
                      : f.use_s4x ? rn_stage4x_launch(h->dtype, h->stream, a, n)
                                  : rn_stage6x_launch(h->dtype, h->stream, a, n);

@@ -58,6 +58,10 @@ __device__ __forceinline__ f32x4 mfma16(i32x4 a, i32x4 b, f32x4 c) {
 
 template <int DT>
 __global__ __launch_bounds__(512, 2) void stage5x_kernel(const StageArgs a) {
+#ifdef RN_CLOCK
+    unsigned long long ck_t0, ck_r0;
+    clock_pair(ck_t0, ck_r0);
+#endif
     extern __shared__ __attribute__((aligned(64))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -379,6 +383,15 @@ __global__ __launch_bounds__(512, 2) void stage5x_kernel(const StageArgs a) {
     if (rem > 3) step(IC<0>{}, IC<1>{}, s + 3);
     if (rem > 4) step(IC<1>{}, IC<0>{}, s + 4);
     wait_vmcnt<0>();
+#ifdef RN_CLOCK
+    if (a.stamp_buf && threadIdx.x == 256) {
+        unsigned long long t1, r1;
+        clock_pair(t1, r1);
+        const int64_t wg = static_cast<int64_t>(blockIdx.y) * gridDim.x + blockIdx.x;
+        a.stamp_buf[wg * 2 + 0] = t1 - ck_t0;
+        a.stamp_buf[wg * 2 + 1] = r1 - ck_r0;
+    }
+#endif
 }
 
 }  // namespace

@@ -68,7 +68,7 @@ def pytest_sessionfinish(session, exitstatus):
     path = os.environ.get("RN_PARITY_REPORT", os.path.join(ROOT, "gpurun_out", "parity_report.json"))
     os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
     doc = {"what": "GPU parity evidence recorded by tests/ (HIP path through the C ABI vs the oracle / fp64 goldens / float32 HIP path)",
-           "tolerances": {"logits_abs_16bit": 0.1, "id_margin_16bit": 0.2, "stage_rel_bf16": 0.04, "stage_rel_f16": 0.006,
+           "tolerances": {"logits_abs_16bit": 0.1, "id_margin_16bit": 0.2, "stage_rel_bf16": 0.0125, "stage_rel_f16": 0.006,
                           "note": "stage_rel = max |got - oracle| / absmax(oracle tensor); oracle parity with TensorFlow itself is unpinned (SURVEY 8c)"},
            "pytest_exitstatus": int(exitstatus)}
     doc.update(_PARITY)

@@ -62,10 +62,10 @@ def test_hbm_traffic_summary_is_reproducible_from_the_pmc_passes():
             # stages 0+1: the 8-channel tensor between them (1.55 of 4.65 MB) is gone: 0.67
             assert 0.39 <= s["traffic_over_algorithmic"] <= 0.70, s
         else:
-            # one launch per stage: every tensor once (stage 5's skip tensor is partly served on-die: 0.6); stages 4 and 7
-            # run in two bands whose 4-row halos are read twice, stage 4's one-tile workgroups also re-read 4 halo
-            # columns per 30, most of them from L2: up to 1.12
-            assert 0.55 <= s["traffic_over_algorithmic"] <= (1.12 if s["stage"] in (4, 7) else 1.05), s
+            # one launch per stage: every tensor once (stage 5 takes its residual from the input rows already in LDS, the
+            # model counts that tensor twice: 0.54); stage 7 runs in two bands whose 4-row halos are read twice, the
+            # round-2 stage 4 re-read 4 halo columns per 30: up to 1.12
+            assert 0.50 <= s["traffic_over_algorithmic"] <= (1.12 if s["stage"] in (4, 7) else 1.05), s
     b = json.load(open(os.path.join(PROF, tag + "_bench.json")))
     dom = [s for s in t["stages"] if s["algorithmic_bytes"] == b["roofline"]["algorithmic_bytes_per_launch"]]
     assert dom and abs(dom[0]["traffic_bytes"] - b["roofline"]["traffic"]) <= 1e-3 * dom[0]["traffic_bytes"]

@@ -4,4 +4,4 @@
 # Run AFTER >= 2 s of back-to-back launches (tools/gpu_clock.sh does that).  (run csrc/build.sh first: other objects are reused)
 set -euo pipefail
 ROOT="$(cd "$(dirname "${BASH_SOURCE[0]}")/.." && pwd)"
-exec "$ROOT/tools/build_variant2.sh" clock "rn_fused rn_stage_rw rn_stage23x" -DRN_CLOCK
+exec "$ROOT/tools/build_variant2.sh" clock "rn_fused rn_stage_rw rn_stage23x rn_stage4x rn_stage5x rn_stage6x" -DRN_CLOCK
