@@ -214,6 +214,7 @@ struct StageArgs {
     const i32x4* s0_wfrag;        // [3 (ky)][64 lanes] stage-0 A fragments (fp16, K = (kx < 4, c < 4))
     const float* s0_ptab;         // [2][8] stage-0 folded BN: scale (inv / 9), shift
     int s0_S;                     // image side
+    int s0_private;               // stage-0 fusion: keep the wave-private rings (round-2 form; A/B arm)
 };
 
 // launch arguments of the cross-stage fused kernel (rn_stage23.hip): the last two steps of a depth-3 conv_block

@@ -52,11 +52,17 @@ constexpr int rw_tile_stride(int pk, int ps, bool wide = false) { return pk ? rw
 #endif
 constexpr int RW_SKIPBUF = 3;   // staged skip-row pairs (residual): 1 being read + 2 in flight
 
-template <int DT, int CIN, int COUT, int PK, int PS, bool RES, int NPT, int KS = 1, bool S0F_ = false, bool WIDE_ = false>
+template <int DT, int CIN, int COUT, int PK, int PS, bool RES, int NPT, int KS = 1, bool S0F_ = false, bool WIDE_ = false, bool S0SH_ = false>
 struct RwCfg {
     // S0F: stage 0 (uint8 image -> conv 3->8 -> ReLU6 -> pool 3/1 -> BN) is computed by the SAME wave, row by row,
     // straight into its private ring: the 8-channel tensor between stages 0 and 1 never reaches HBM (see s0_feed)
     static constexpr bool S0F = S0F_;
+    // S0SH (with S0F, one column block): the stage-0 rows go to ONE ring shared by the workgroup -- wave w computes the 29
+    // stage-0 columns [29 w, 29 w + 29) (one 32-column tile instead of two: the second tile of the private form exists
+    // for 5 halo columns only and costs as much as the first) and reads its 34-column window once its neighbours are done
+    static constexpr bool S0SH = S0SH_;
+    static_assert(!S0SH || S0F, "shared stage-0 ring is a form of the stage-0 fusion");
+    static constexpr int S0_TILES = S0SH ? 1 : 2;
     static_assert(!S0F || (CIN == 8 && !RES && KS == 1 && COUT == 32), "stage-0 fusion feeds the 8-channel private-ring variant");
     // Ring depth: at step s the DMA for input row s + AHEAD is issued; NSLOT = AHEAD + 1 slots
     // (3 live rows + AHEAD - 2 in flight).  Rows of the 8-channel stage are only ~3.8 KB, so it
@@ -97,7 +103,7 @@ struct RwCfg {
     // Only for single-cout-tile stages: with several cout tiles the waves of one pixel tile would each
     // fetch the same input, and once they drift apart the duplicates miss L2 (measured on the 32->64
     // stage: 1.65x the algorithmic HBM bytes); those stages keep the workgroup-shared ring.
-    static constexpr bool PRIV = !RES && KS == 1 && CT == 1;
+    static constexpr bool PRIV = !RES && KS == 1 && CT == 1 && !S0SH;
     static constexpr int RINGCOLS = PRIV ? 34 : (NPT - 1) * TSTRIDE + 34;
     static constexpr int LOADERS = PRIV ? 64 : NTHREADS;       // lanes cooperating on one ring row
     static constexpr int NRINGS = PRIV ? NPT * CT : 1;
@@ -161,9 +167,9 @@ __device__ __forceinline__ unsigned long long stamp() {
 }
 #endif
 
-template <int DT, int CIN, int COUT, int PK, int PS, bool RES, int NPT, int KS, bool S0F, bool WIDE>
+template <int DT, int CIN, int COUT, int PK, int PS, bool RES, int NPT, int KS, bool S0F, bool WIDE, bool S0SH>
 __global__ __launch_bounds__(64 * NPT * ((COUT + 31) / 32) * KS, 1) void stage_rw_kernel(const StageArgs a) {
-    using C = RwCfg<DT, CIN, COUT, PK, PS, RES, NPT, KS, S0F, WIDE>;
+    using C = RwCfg<DT, CIN, COUT, PK, PS, RES, NPT, KS, S0F, WIDE, S0SH>;
     constexpr int CP = C::CP, KC = C::KC, CT = C::CT, CPO = C::CPO, TSTRIDE = C::TSTRIDE, NOUT_T = C::NOUT_T;
     constexpr int RINGCOLS = C::RINGCOLS, ROWB = C::ROWB, NTHREADS = C::NTHREADS, LPT = C::LPT, SLPT = C::SLPT;
     constexpr int PIXB = CIN * 2, NG = C::NG;
@@ -344,12 +350,12 @@ __global__ __launch_bounds__(64 * NPT * ((COUT + 31) / 32) * KS, 1) void stage_r
         s0_scale = *reinterpret_cast<const f32x4*>(a.s0_ptab + 4 * hh);
         s0_shift = *reinterpret_cast<const f32x4*>(a.s0_ptab + 8 + 4 * hh);
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int xt0 = x_ring0 + 29 * u;                          // first conv / image column of the tile
+        for (int u = 0; u < C::S0_TILES; ++u) {
+            const int xt0 = x0c + pt * TSTRIDE + 29 * u;               // first conv / image column of the tile
             const int px = min(xt0 + r + 2 * hh, a.s0_S - 1);           // this lane's image column (clamped at the edge)
             s0_sh[u] = px == a.s0_S - 1 ? 8 : 0;                        // last column: load one byte early and shift
             s0_src[u] = a.s0_bgr + (static_cast<int64_t>(n) * a.s0_S * a.s0_S + static_cast<int64_t>(yc0) * a.s0_S + px) * 3 - (s0_sh[u] >> 3);
-            const int oc = 29 * u + r;                                  // ring column of this lane's output pixel
+            const int oc = (C::S0SH ? pt * TSTRIDE : 0) + 29 * u + r;   // ring column of this lane's output pixel
             s0_wr[u] = (r < (u == 0 ? 29 : 5) && oc < RINGCOLS) ? oc * PIXB + 8 * hh : -1;
 #pragma unroll
             for (int j = 0; j < 4; ++j) s0_h1[u][j] = s0_h2[u][j] = 0.f;
@@ -369,7 +375,7 @@ __global__ __launch_bounds__(64 * NPT * ((COUT + 31) / 32) * KS, 1) void stage_r
             const unsigned nb_mask = hh ? 0u : 0xffffffffu;
             const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
+            for (int u = 0; u < C::S0_TILES; ++u) {
                 // ((x / 255.) * 2) - 1 of network.py:129 as one fp32 fma (the host checked that it rounds to the same
                 // fp16 as the float64 expression for all 256 inputs, rn_fused_prepare)
                 const unsigned w = s0_pw[u][Q] >> s0_sh[u];              // bytes: B, G, R
@@ -413,8 +419,15 @@ __global__ __launch_bounds__(64 * NPT * ((COUT + 31) / 32) * KS, 1) void stage_r
     };
     // ---- prologue: rows 0 .. RW_AHEAD-1 in flight (clamped: a no-pool band can be shorter)
     if constexpr (C::S0F) {
+        if constexpr (C::S0SH) {
+            // ring columns 232 .. of every slot are written by nobody and feed discarded lanes only: finite values
+            static_assert(!C::S0SH || (TSTRIDE == 29 && NPT == 8), "shared stage-0 ring: 8 tiles of 29 columns");
+            constexpr int Z0 = NPT * 29 * PIXB, ZN = (ROWB - Z0) / 16;
+            for (int i = tid; i < RW_NSLOT * ZN; i += NTHREADS)
+                *reinterpret_cast<i32x4*>(ring + (i / ZN) * ROWB + Z0 + (i % ZN) * 16) = i32x4{0, 0, 0, 0};
+        }
 #pragma unroll
-        for (int u = 0; u < 2; ++u)
+        for (int u = 0; u < C::S0_TILES; ++u)
 #pragma unroll
             for (int k = 0; k < S0_AHEAD; ++k) s0_pw[u][k] = s0_load(u, k);
         static_assert(!C::S0F || (RW_NSLOT == 4 && S0_AHEAD == 4 && RW_AHEAD == 3), "queue phase = ring phase");
@@ -1046,6 +1059,7 @@ __global__ __launch_bounds__(64 * NPT * ((COUT + 31) / 32) * KS, 1) void stage_r
 #ifdef RN_STAMPS
         const unsigned long long ts2 = stamp();
 #endif
+        if constexpr (C::S0SH) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // this step's stage-0 row is in LDS
         if constexpr (!C::PRIV) raw_barrier();
 #ifdef RN_STAMPS
         const unsigned long long ts3 = stamp();
@@ -1107,10 +1121,10 @@ __global__ __launch_bounds__(64 * NPT * ((COUT + 31) / 32) * KS, 1) void stage_r
 #endif
 }
 
-template <int DT, int CIN, int COUT, int PK, int PS, bool RES, int NPT, int KS = 1, bool S0F = false, bool WIDE = false>
+template <int DT, int CIN, int COUT, int PK, int PS, bool RES, int NPT, int KS = 1, bool S0F = false, bool WIDE = false, bool S0SH = false>
 int launch_rw(hipStream_t s, const StageArgs& a, dim3 grid) {
-    using C = RwCfg<DT, CIN, COUT, PK, PS, RES, NPT, KS, S0F, WIDE>;
-    auto kern = stage_rw_kernel<DT, CIN, COUT, PK, PS, RES, NPT, KS, S0F, WIDE>;
+    using C = RwCfg<DT, CIN, COUT, PK, PS, RES, NPT, KS, S0F, WIDE, S0SH>;
+    auto kern = stage_rw_kernel<DT, CIN, COUT, PK, PS, RES, NPT, KS, S0F, WIDE, S0SH>;
     // the attribute is per device: remember which devices of this process have it (one handle per GPU per process
     // is the normal deployment, several handles on several GPUs / threads in one process must work too)
     static std::atomic<unsigned long long> attr_devices{0};
@@ -1136,10 +1150,10 @@ int launch_rw(hipStream_t s, const StageArgs& a, dim3 grid) {
     return RN_OK;
 }
 
-template <int CIN, int COUT, int PK, int PS, bool RES, int NPT, int KS = 1, bool S0F = false, bool WIDE = false>
+template <int CIN, int COUT, int PK, int PS, bool RES, int NPT, int KS = 1, bool S0F = false, bool WIDE = false, bool S0SH = false>
 int launch_rw_dt(int dtype, hipStream_t s, const StageArgs& a, dim3 grid) {
-    if (dtype == RN_DTYPE_BF16) return launch_rw<RN_DTYPE_BF16, CIN, COUT, PK, PS, RES, NPT, KS, S0F, WIDE>(s, a, grid);
-    return launch_rw<RN_DTYPE_F16, CIN, COUT, PK, PS, RES, NPT, KS, S0F, WIDE>(s, a, grid);
+    if (dtype == RN_DTYPE_BF16) return launch_rw<RN_DTYPE_BF16, CIN, COUT, PK, PS, RES, NPT, KS, S0F, WIDE, S0SH>(s, a, grid);
+    return launch_rw<RN_DTYPE_F16, CIN, COUT, PK, PS, RES, NPT, KS, S0F, WIDE, S0SH>(s, a, grid);
 }
 
 }  // namespace
@@ -1220,6 +1234,9 @@ int rn_rw_launch(const RwPlan& p, int dtype, hipStream_t s, const StageArgs& a, 
             if (a.s0_bgr) return launch_rw_dt<8, 32, 4, 1, false, 4, 1, true>(dtype, s, a, grid);
             return launch_rw_dt<8, 32, 4, 1, false, 4>(dtype, s, a, grid);
         case 0 * 16 + 8:
+            // one column block whose stage-0 columns (outputs + 5) all come from the eight 29-column tiles: shared ring
+            if (a.s0_bgr && a.n_colblocks == 1 && a.Wo + 5 <= 8 * 29 && !a.s0_private)
+                return launch_rw_dt<8, 32, 4, 1, false, 8, 1, true, false, true>(dtype, s, a, grid);
             if (a.s0_bgr) return launch_rw_dt<8, 32, 4, 1, false, 8, 1, true>(dtype, s, a, grid);
             return launch_rw_dt<8, 32, 4, 1, false, 8>(dtype, s, a, grid);
         case 1 * 16 + 4: return launch_rw_dt<32, 32, 4, 1, false, 4>(dtype, s, a, grid);
