@@ -528,26 +528,6 @@ static void rn_clock_end(hipStream_t stream) {
     (void)hipStreamSynchronize(stream);
     for (const ClockRegion& r : g_clock_regions) {
         const unsigned long long* buf = g_clock_buf + r.off;
-#ifdef RN_CLOCK_ABS
-        if (!strncmp(r.what, "stages 0+", 9) || (!strncmp(r.what, "stage ", 6) && r.nwg > 4096)) {
-            std::vector<double> in, out;
-            unsigned long long t0 = ~0ull;
-            for (size_t k = 0; k < r.nwg; ++k)
-                if (buf[2 * k + 1]) t0 = std::min(t0, buf[2 * k]);
-            for (size_t k = 0; k < r.nwg; ++k)
-                if (buf[2 * k + 1]) {
-                    in.push_back((buf[2 * k] - t0) * 0.01);
-                    out.push_back((buf[2 * k + 1] - t0) * 0.01);
-                }
-            if (in.empty()) continue;
-            std::sort(in.begin(), in.end());
-            std::sort(out.begin(), out.end());
-            auto q = [](const std::vector<double>& v, double f) { return v[static_cast<size_t>(f * (v.size() - 1))]; };
-            fprintf(stderr, "[clock-abs] %-12s %zu waves: entry us min/50/90/99/max %.1f %.1f %.1f %.1f %.1f | exit us min/10/50/90/99/max %.1f %.1f %.1f %.1f %.1f %.1f\n",
-                    r.what, in.size(), q(in, 0), q(in, .5), q(in, .9), q(in, .99), q(in, 1), q(out, 0), q(out, .1), q(out, .5), q(out, .9), q(out, .99), q(out, 1));
-            continue;
-        }
-#endif
         std::vector<double> ghz, us;
         for (size_t k = 0; k < r.nwg; ++k)
             if (buf[2 * k + 1]) {
@@ -1278,11 +1258,7 @@ int rn_fused_forward(rn_handle* h, const uint8_t* d_bgr, const float* d_rgb, int
             {
                 char what[32];
                 snprintf(what, sizeof what, a.s0_bgr ? "stages 0+%zu" : "stage %zu", i);
-#ifdef RN_CLOCK_ABS
-                a.stamp_buf = rn_clock_region(what, static_cast<size_t>(grid.x) * grid.y * 16);
-#else
                 a.stamp_buf = rn_clock_region(what, static_cast<size_t>(grid.x) * grid.y);
-#endif
             }
 #endif
             int rc = rn_rw_launch(f.rw, h->dtype, h->stream, a, grid);

@@ -429,6 +429,35 @@ def test_cross_stage_fusion_geometry_sweep(weights, side, blocks):
         plain.close()
 
 
+@pytest.mark.parametrize("side", [190, 225, 236, 237, 260])
+def test_stage0_fusion_shared_ring_edges(weights, side):
+    """Stages 0+1 in one launch: up to 227 output columns (side 236) the stage-0 rows sit in ONE ring shared by the
+    workgroup (each wave computes 29 stage-0 columns; waves whose tile lies right of a narrow image still take part in the
+    barrier), wider images keep the wave-private rings (237: one column block; 260: two).  Stage-1 output must be the
+    two-launch path's bit for bit, at batch sizes that give one and several row bands."""
+    from oracle import roomnet_ref as R
+    from roomnet_amd.synth import parity_batch
+    g = build_graph(6, side)
+    w = dict(weights)
+    w["dense/kernel"] = R.synth_dense_kernel_600(g.flat_len)
+    ims = parity_batch(side, seed=2)[[3, 17, 29]]
+    fused = _capi.Engine(g, w, device=0, dtype="bf16", max_batch=3)
+    plain = _capi.Engine(g, w, device=0, dtype="bf16", max_batch=3, stage_launches=True)
+    try:
+        assert [0, 1] in [list(x) for x in fused.launch_groups()]
+        for nb in (3, 1):
+            ids_f, probs_f = fused.forward_u8(ims[:nb])
+            ids_p, probs_p = plain.forward_u8(ims[:nb])
+            a, b = fused.tap("s1.bn", nb), plain.tap("s1.bn", nb)
+            bad = np.argwhere(a != b)
+            assert bad.size == 0, (side, nb, len(bad), bad[:8].tolist())
+            np.testing.assert_array_equal(probs_f, probs_p)
+            np.testing.assert_array_equal(ids_f, ids_p)
+    finally:
+        fused.close()
+        plain.close()
+
+
 @pytest.mark.parametrize("side", [190, 202, 300, 420])
 def test_conv16_stage_matches_the_generic_kernel_at_odd_sizes(weights, side):
     """The 64->128 and the pooled 128->16 stage run on 16x16x32 tiles (rn_conv16.hip): column blocks of 48 / 21 outputs,
