@@ -12,19 +12,35 @@ FLAGS=(--offload-arch=gfx950 -O3 -std=c++20 -fno-slp-vectorize -fPIC -shared -fv
 OBJ="$ROOT/build/obj"
 mkdir -p "$OBJ"
 CFLAGS=("${FLAGS[@]/-shared/}")
+# (a failed background compile must fail the build: a bare `wait` returns 0 and the link would pick up a stale object)
+PIDS=()
 for f in rn_api rn_kernels_f32 rn_fused rn_imageops rn_group rn_tail rn_conv16; do
+    rm -f "$OBJ/$f.o"
     "$HIPCC" "${CFLAGS[@]}" -c "$HERE/$f.hip" -o "$OBJ/$f.o" &
+    PIDS+=($!)
 done
 # MFMA results stay in VGPRs: the epilogue reads every accumulator with the VALU, and AGPR
 # accumulators cost one v_accvgpr_read each (64 per row in the residual variant).
 # (max-ilp scheduling was measured slower, see NOTES.md)
+rm -f "$OBJ/rn_stage_rw.o"
 "$HIPCC" "${CFLAGS[@]}" ${RN_RW_FLAGS:--mllvm -amdgpu-mfma-vgpr-form} -c "$HERE/rn_stage_rw.hip" -o "$OBJ/rn_stage_rw.o" &
+PIDS+=($!)
+rm -f "$OBJ/rn_stage23.o"
 "$HIPCC" "${CFLAGS[@]}" ${RN_RW_FLAGS:--mllvm -amdgpu-mfma-vgpr-form} -c "$HERE/rn_stage23.hip" -o "$OBJ/rn_stage23.o" &
+PIDS+=($!)
+rm -f "$OBJ/rn_stage23x.o"
 "$HIPCC" "${CFLAGS[@]}" ${RN_RW_FLAGS:--mllvm -amdgpu-mfma-vgpr-form} -c "$HERE/rn_stage23x.hip" -o "$OBJ/rn_stage23x.o" &
+PIDS+=($!)
+rm -f "$OBJ/rn_stage5x.o"
 "$HIPCC" "${CFLAGS[@]}" ${RN_RW_FLAGS:--mllvm -amdgpu-mfma-vgpr-form} -c "$HERE/rn_stage5x.hip" -o "$OBJ/rn_stage5x.o" &
+PIDS+=($!)
+rm -f "$OBJ/rn_stage4x.o"
 "$HIPCC" "${CFLAGS[@]}" ${RN_RW_FLAGS:--mllvm -amdgpu-mfma-vgpr-form} -c "$HERE/rn_stage4x.hip" -o "$OBJ/rn_stage4x.o" &
+PIDS+=($!)
+rm -f "$OBJ/rn_stage6x.o"
 "$HIPCC" "${CFLAGS[@]}" ${RN_RW_FLAGS:--mllvm -amdgpu-mfma-vgpr-form} -c "$HERE/rn_stage6x.hip" -o "$OBJ/rn_stage6x.o" &
-wait
+PIDS+=($!)
+for p in "${PIDS[@]}"; do wait "$p"; done
 "$HIPCC" --offload-arch=gfx950 -shared -fPIC "$OBJ"/rn_api.o "$OBJ"/rn_kernels_f32.o "$OBJ"/rn_fused.o "$OBJ"/rn_imageops.o "$OBJ"/rn_group.o "$OBJ"/rn_tail.o "$OBJ"/rn_conv16.o "$OBJ"/rn_stage_rw.o "$OBJ"/rn_stage23.o "$OBJ"/rn_stage23x.o "$OBJ"/rn_stage5x.o "$OBJ"/rn_stage4x.o "$OBJ"/rn_stage6x.o -ldl -lpthread \
     ${RN_EXTRA_FLAGS:-} -o "$OUT/libroomnet_hip.so"
 echo "built $OUT/libroomnet_hip.so"

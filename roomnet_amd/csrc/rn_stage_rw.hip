@@ -417,6 +417,61 @@ __global__ __launch_bounds__(64 * NPT * ((COUT + 31) / 32) * KS, 1) void stage_r
             }
         }
     };
+    // The same row cut into pieces for the steady state: the front (operand + the three MFMAs) runs at the top of a step, the
+    // rest rides in the chain slots of stage 1's conv row (s0_part<0,1>: ReLU6 + 3x3 sums of two channels each, <2>: BN +
+    // write) -- one wave's stage-0 row is a long dependent sequence (MFMA chain -> DPP sums -> BN -> LDS), and both waves
+    // of a SIMD ran it at the same time (stamps: 755 cycles a row for ~260 cycles of issue)
+    f32x16 s0_acc[2];
+    float s0_y[2][4];
+    auto s0_front = [&](auto QC, int i) __attribute__((always_inline)) {
+        constexpr int Q = decltype(QC)::value;
+        if constexpr (C::S0F) {
+            const unsigned nb_mask = hh ? 0u : 0xffffffffu;
+            const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int u = 0; u < C::S0_TILES; ++u) {
+                const unsigned w = s0_pw[u][Q] >> s0_sh[u];              // bytes: B, G, R
+                const float fb = fmaf(static_cast<float>(w & 0xff), 2.0f / 255.0f, -1.0f);
+                const float fg = fmaf(static_cast<float>((w >> 8) & 0xff), 2.0f / 255.0f, -1.0f);
+                const float fr = fmaf(static_cast<float>((w >> 16) & 0xff), 2.0f / 255.0f, -1.0f);
+                const int d0 = static_cast<int>(pack2<RN_DTYPE_F16>(fr, fg));
+                const int d1 = static_cast<int>(pack2<RN_DTYPE_F16>(fb, 0.f));
+                s0_pw[u][Q] = s0_load(u, i + S0_AHEAD);
+                i32x4 f;
+                f[0] = d0;
+                f[1] = d1;
+                f[2] = static_cast<int>(static_cast<unsigned>(__builtin_amdgcn_update_dpp(0, d0, 0x130, 0xf, 0xf, true)) & nb_mask);
+                f[3] = static_cast<int>(static_cast<unsigned>(__builtin_amdgcn_update_dpp(0, d1, 0x130, 0xf, 0xf, true)) & nb_mask);
+                f32x16 acc = mfma32<RN_DTYPE_F16>(s0_w[0], s0_bfr[u][0], zero);
+                acc = mfma32<RN_DTYPE_F16>(s0_w[1], s0_bfr[u][1], acc);
+                s0_acc[u] = mfma32<RN_DTYPE_F16>(s0_w[2], f, acc);
+                s0_bfr[u][0] = s0_bfr[u][1];
+                s0_bfr[u][1] = f;
+            }
+        }
+    };
+    auto s0_part = [&](auto KC_, int slot) __attribute__((always_inline)) {
+        constexpr int k = decltype(KC_)::value;
+        if constexpr (C::S0F) {
+#pragma unroll
+            for (int u = 0; u < C::S0_TILES; ++u) {
+                if constexpr (k < 2) {
+#pragma unroll
+                    for (int j = 2 * k; j < 2 * k + 2; ++j) {
+                        const float v = relu6f(s0_acc[u][j]);
+                        const float v1 = lane_next(v);
+                        const float hs = (v + v1) + lane_next(v1);
+                        s0_y[u][j] = fmaf((s0_h2[u][j] + s0_h1[u][j]) + hs, s0_scale[j], s0_shift[j]);
+                        s0_h2[u][j] = s0_h1[u][j];
+                        s0_h1[u][j] = hs;
+                    }
+                } else {
+                    if (s0_wr[u] >= 0)
+                        *reinterpret_cast<uint2*>(ring + slot * ROWB + s0_wr[u]) = pack4<DT>(s0_y[u][0], s0_y[u][1], s0_y[u][2], s0_y[u][3]);
+                }
+            }
+        }
+    };
     // ---- prologue: rows 0 .. RW_AHEAD-1 in flight (clamped: a no-pool band can be shorter)
     if constexpr (C::S0F) {
         if constexpr (C::S0SH) {
@@ -464,6 +519,21 @@ __global__ __launch_bounds__(64 * NPT * ((COUT + 31) / 32) * KS, 1) void stage_r
             b8_off[kc] = (xrel0 + kx) * PIXB;
         }
     }
+    // 8-channel stage: K-chunk kc holds taps 2 kc (lower half-wave) and 2 kc + 1 (upper): both lie in ONE kernel row except
+    // for chunk 1 (taps 2 | 3 = rows 0 | 1), so the ring slot of a chunk is a compile-time DS offset on a lane-constant base
+    // (chunk 1: one precomputed address per ring phase) -- no per-row address arithmetic, and the reads are inline asm so
+    // they go out where they are written (stage-0 fusion: all five at the top of the step, behind them the stage-0 row)
+    constexpr bool B8_ASM = CIN == 8 && RW_NSLOT <= 4;
+    unsigned b8_base[CIN >= 16 ? 1 : KC], b8_k1[B8_ASM ? RW_NSLOT : 1];
+    if constexpr (B8_ASM) {
+        static_assert(!B8_ASM || (RW_NSLOT - 1) * ROWB + 16 <= 65535, "ring slot as a DS immediate offset");
+        const unsigned ring_lds0 = static_cast<unsigned>(reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) char*)ring));
+#pragma unroll
+        for (int kc = 0; kc < KC; ++kc) b8_base[kc] = ring_lds0 + static_cast<unsigned>(b8_off[kc]);
+#pragma unroll
+        for (int p = 0; p < RW_NSLOT; ++p) b8_k1[p] = b8_base[1] + static_cast<unsigned>(((p + hh) % RW_NSLOT) * ROWB);
+    }
+    i32x4 b8_pre[B8_ASM ? KC : 1];
     // output column of this lane: MFMA-pooled tiles deliver window i of the tile on lane i (see POOLM), gapped
     // tiles the window that starts at the lane's own conv column
     const int xo = C::DPP2 ? (x0c + pt * TSTRIDE + pm) / PS : (PK ? (x0c + pt * TSTRIDE) / PS : x0c + pt * TSTRIDE) + r;
@@ -665,6 +735,26 @@ __global__ __launch_bounds__(64 * NPT * ((COUT + 31) / 32) * KS, 1) void stage_r
                          : "v"(bbase1[kx][cc]), "n"((slot - SLOT_SPLIT) * ROWB), "v"(dep));
         return v;
     };
+    auto b8_issue = [&](auto PC) __attribute__((always_inline)) {
+        constexpr int P = decltype(PC)::value;
+        if constexpr (B8_ASM) {
+            static_assert(!B8_ASM || KC == 5, "taps 0..8 in five chunks");
+            [&]<int... KCI>(std::integer_sequence<int, KCI...>) {
+                (([&] {
+                     auto& pre = b8_pre;            // (asm operands of a nested lambda must name its own locals)
+                     auto& base = b8_base;
+                     auto& k1 = b8_k1;
+                     if constexpr (KCI == 1) {
+                         asm volatile("ds_read_b128 %0, %1" : "=v"(pre[1]) : "v"(k1[P]));
+                     } else {
+                         constexpr int ky = (2 * KCI > 8 ? 8 : 2 * KCI) / 3;
+                         asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(pre[KCI]) : "v"(base[KCI]), "n"(((P + ky) % RW_NSLOT) * ROWB));
+                     }
+                 }()),
+                 ...);
+            }(std::make_integer_sequence<int, KC>{});
+        }
+    };
     // MFMA chain of one conv row over the K-chunks [KB, KB + KCW) (KB = 0 unless K is split)
     // `slot(IC<I>)` runs right behind MFMA I: the epilogue micro-ops of that chain slot (see step())
     auto mma_chain = [&](auto PC, auto KBC, f32x16& acc, auto&& slot) __attribute__((always_inline)) {
@@ -689,6 +779,18 @@ __global__ __launch_bounds__(64 * NPT * ((COUT + 31) / 32) * KS, 1) void stage_r
                  }()),
                  ...);
             }(std::make_integer_sequence<int, KCW>{});
+        } else if constexpr (B8_ASM) {
+            // fragments were issued by b8_issue() at the top of the step
+            [&]<int... I>(std::integer_sequence<int, I...>) {
+                (([&] {
+                     auto& pre = b8_pre;
+                     if constexpr (I == 0)
+                         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(pre[0]), "+v"(pre[1]), "+v"(pre[2]), "+v"(pre[3]), "+v"(pre[4]));
+                     acc = C::POOLM ? mfma32<DT>(pre[I], wreg[I], I == 0 ? zero : acc) : mfma32<DT>(wreg[I], pre[I], I == 0 ? zero : acc);
+                     slot(IC<I>{});
+                 }()),
+                 ...);
+            }(std::make_integer_sequence<int, KC>{});
         } else {
             bq[0] = b_frag(PC, IC<0>{});
             [&]<int... I>(std::integer_sequence<int, I...>) {
@@ -997,6 +1099,7 @@ __global__ __launch_bounds__(64 * NPT * ((COUT + 31) / 32) * KS, 1) void stage_r
                      ...);
                 }(std::make_integer_sequence<int, NPIECE>{});
             }
+            if constexpr (MMA && C::S0F && I < 3) s0_part(IC<(I < 3 ? I : 0)>{}, (P + RW_AHEAD) % RW_NSLOT);
             if constexpr (EPI && SLICED) {
                 [&]<int... K>(std::integer_sequence<int, K...>) {
                     (([&] {
@@ -1007,12 +1110,13 @@ __global__ __launch_bounds__(64 * NPT * ((COUT + 31) / 32) * KS, 1) void stage_r
             }
             if constexpr (SLICED) __builtin_amdgcn_sched_barrier(0);
         };
+        if constexpr (MMA) b8_issue(PC);
         if constexpr (MMA) {
             // (past the end of the band the last row is fetched again into a free slot: the number of
             //  DMA pieces per step stays constant, so the counted waits and the code path do too)
             if constexpr (!RN_SPREAD_DMA && !C::S0F) issue_row(min(s + RW_AHEAD, nin - 1), (P + RW_AHEAD) % RW_NSLOT);
             // S0F: image row s + RW_AHEAD + 4 completes stage-0 output row s + RW_AHEAD -> the slot the DMA would fill
-            if constexpr (C::S0F) s0_feed(IC<1>{}, IC<(P + RW_AHEAD + 4) % 4>{}, s + RW_AHEAD + 4, (P + RW_AHEAD) % RW_NSLOT);
+            if constexpr (C::S0F) s0_front(IC<(P + RW_AHEAD + 4) % 4>{}, s + RW_AHEAD + 4);      // the rest: chain slots 0..2
             if constexpr (RES && (PS == 1 || (P & 1) == 0)) {
                 // pair for the epilogue of conv row s+1 (runs in step s+2): e = (s + 1 - 3) / PS
                 // (stride 2: only odd conv rows emit, so pairs are issued on even steps)

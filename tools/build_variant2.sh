@@ -5,14 +5,17 @@ ROOT="$(cd "$(dirname "${BASH_SOURCE[0]}")/.." && pwd)"
 SRC="$ROOT/roomnet_amd/csrc"
 NAME="$1"; FILES="$2"; shift 2
 OBJ="$ROOT/build/var_$NAME"; mkdir -p "$OBJ"
+PIDS=()
 for FILE in $FILES; do
   EXTRA="-mllvm -amdgpu-mfma-vgpr-form"
+  rm -f "$OBJ/$FILE.o"
   case "$FILE" in rn_api|rn_kernels_f32|rn_fused|rn_imageops|rn_group|rn_tail|rn_conv16) EXTRA="";; esac
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++20 -fno-slp-vectorize -fPIC -fvisibility=hidden -I"$ROOT/include" -I"$SRC" \
       -Wall -Wno-unused-function -Wno-unused-variable -Wno-unused-but-set-variable -DRN_BUILDING $EXTRA "$@" \
       -c "$SRC/$FILE.hip" -o "$OBJ/$FILE.o" &
+  PIDS+=($!)
 done
-wait
+for p in "${PIDS[@]}"; do wait "$p"; done
 OBJS=()
 for f in rn_api rn_kernels_f32 rn_fused rn_imageops rn_group rn_tail rn_conv16 rn_stage_rw rn_stage23 rn_stage23x rn_stage5x rn_stage4x rn_stage6x; do
   if [[ " $FILES " == *" $f "* ]]; then OBJS+=("$OBJ/$f.o"); else OBJS+=("$ROOT/build/obj/$f.o"); fi
