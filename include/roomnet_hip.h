@@ -51,8 +51,9 @@ extern "C" {
  *   - avg-pool 4x4 stride 1 (stages 1-3): ReLU6 outputs are rounded to fp16, vertical pair
  *     sums are fp16 adds, and the window sums run on the matrix cores (fp16 x 0/1 band
  *     matrix, exact float32 accumulation); stride-2 pools are float32 VALU sums, except
- *     stage 5 at 224 x 224 (rn_stage5x.hip), which pools like the stride-1 stages (fp16
- *     ReLU6 outputs and pair sums, band-matrix MFMA);
+ *     stages 4 and 5 at 224-class sizes (rn_stage4x.hip: 193-206 input columns,
+ *     rn_stage5x.hip: 66-110), which pool like the stride-1 stages (fp16 ReLU6 outputs and
+ *     pair sums, band-matrix MFMA);
  *   - residual resize: the horizontal interpolation is an MFMA against the interpolation
  *     matrix in the storage type -- stage 3, and stage 5 at 224 x 224: one operand, lerp
  *     fraction rounded to 2^-8 (bf16) / 2^-11 (fp16) so that both weights are exact;
@@ -71,12 +72,14 @@ extern "C" {
                                that only feeds its fused successor is then never written) */
 #define RN_FLAG_GENERIC_KERNELS 4u /* 16-bit handles: every stage on the generic
                                stage_mfma_kernel (diagnostic cross-check of the tuned kernels) */
-#define RN_FLAG_PAIR_32X32 8u /* 16-bit handles: the round-2 32x32x16 kernels instead of the round-3
-                               16x16x32 ones -- the cross-stage fused pair (last two steps of a depth-3
-                               conv_block, network.py:183-203: rn_stage23.hip instead of rn_stage23x.hip,
-                               bit-identical) and the residual step of the 64-channel block
-                               (network.py:228: rn_stage_rw.hip instead of rn_stage5x.hip; differs in
-                               the last 16-bit place).  Comparison arm */
+#define RN_FLAG_PAIR_32X32 8u /* 16-bit handles: the round-2 kernels instead of the round-3 ones (comparison
+                               arm, bench.py --pair32): the cross-stage fused pair of the 32-channel block
+                               (network.py:183-203: rn_stage23.hip instead of rn_stage23x.hip, bit-identical);
+                               the first step of the 64-channel block, its residual step and the 128-channel
+                               step (network.py:216-235: rn_stage_rw.hip / rn_conv16.hip instead of
+                               rn_stage4x/5x/6x.hip; these differ in the last 16-bit place: other
+                               accumulation order, pooling of stride-2 steps as fp16 band-matrix MFMAs); the
+                               stage-0 fusion with wave-private rings instead of the shared ring (bit-identical) */
 
 #define RN_MAX_STAGES 16
 #define RN_MAX_DENSE 8
