@@ -489,6 +489,40 @@ def test_conv16_stage_matches_the_generic_kernel_at_odd_sizes(weights, side):
             ref.close()
 
 
+@pytest.mark.parametrize("side", [205, 211, 212, 219, 225, 226, 240])
+def test_row_blocked_stage_kernels_match_the_round2_kernels_at_their_geometry_edges(weights, side):
+    """Stages 4, 5 and 6 run one workgroup per image with row-register blocking where their input is 193-206 / 66-110 /
+    35-50 columns wide (rn_stage4x/5x/6x.hip: sides 212-225 for all three, stages 5 and 6 alone a little beyond), and on the
+    round-2 kernels elsewhere.  `pair32=True` forces the round-2 kernels everywhere: the 32-channel block is bit-identical in
+    both arms, so stage 4 sees identical inputs and may differ by the last 16-bit place (other accumulation order, fp16
+    band-matrix pooling instead of fp32 sums); stages 5 and 6 inherit that.  1 and 3 images (one band / several bands)."""
+    from oracle import roomnet_ref as R
+    from roomnet_amd.synth import parity_batch
+    g = build_graph(6, side)
+    w = dict(weights)
+    w["dense/kernel"] = R.synth_dense_kernel_600(g.flat_len)
+    ims = parity_batch(side, seed=3)[[5, 11, 38]]
+    for dtype in ("bf16", "f16"):
+        fast = _capi.Engine(g, w, device=0, dtype=dtype, max_batch=3)
+        ref = _capi.Engine(g, w, device=0, dtype=dtype, max_batch=3, pair32=True)
+        try:
+            for nb in (3, 1):
+                ids_a, _ = fast.forward_u8(ims[:nb])
+                ids_b, _ = ref.forward_u8(ims[:nb])
+                np.testing.assert_array_equal(fast.tap("s3.bn2", nb), ref.tap("s3.bn2", nb))
+                ulp = 2.0 ** (-8 if dtype == "bf16" else -11)
+                for name, n_ulp in (("s4.bn", 2), ("s5.bn2", 4), ("s6.bn", 4)):
+                    a, b = fast.tap(name, nb), ref.tap(name, nb)
+                    assert a.shape == b.shape and np.isfinite(a).all()
+                    scale = float(np.abs(b).max())
+                    err = float(np.abs(a - b).max())
+                    assert err <= n_ulp * ulp * scale, (name, side, dtype, nb, err / (ulp * scale))
+                np.testing.assert_array_equal(ids_a, ids_b)
+        finally:
+            fast.close()
+            ref.close()
+
+
 def test_results_are_reproducible_run_to_run(engine, parity_images):
     """Every kernel synchronises its LDS rings with counted waits and bare barriers; a race shows as run-to-run noise
     (one was found that way in a stage-5 variant that never shipped).  Six passes over the same batch must agree bit for
