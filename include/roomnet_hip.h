@@ -53,7 +53,9 @@ extern "C" {
  *     matrix, exact float32 accumulation); stride-2 pools are float32 VALU sums, except
  *     stages 4 and 5 at 224-class sizes (rn_stage4x.hip: 193-206 input columns,
  *     rn_stage5x.hip: 66-110), which pool like the stride-1 stages (fp16 ReLU6 outputs and
- *     pair sums, band-matrix MFMA);
+ *     pair sums, band-matrix MFMA) and keep their conv weights DIVIDED BY 6 (rounded to the
+ *     16-bit type after the division): relu6(6 x) / 6 = clamp(x, 0, 1) is then the free
+ *     clamp of the fp16 conversion, and the folded BN scale carries the 6;
  *   - residual resize: the horizontal interpolation is an MFMA against the interpolation
  *     matrix in the storage type -- stage 3, and stage 5 at 224 x 224: one operand, lerp
  *     fraction rounded to 2^-8 (bf16) / 2^-11 (fp16) so that both weights are exact;

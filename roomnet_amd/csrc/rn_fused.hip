@@ -550,6 +550,7 @@ struct FusedStage {
     bool use_s5x = false;        // the 64 -> 64 residual stage on 16x16x32 tiles with row-register blocking (rn_stage5x.hip)
     bool use_s4x = false;        // the 32 -> 64 stage likewise (rn_stage4x.hip)
     bool use_s6x = false;        // the un-pooled 64 -> 128 stage likewise (rn_stage6x.hip)
+    bool sixth = false;          // conv weights stored / 6, folded BN scale x 6 (pack2_relu6_sixth in the stage's kernel)
     i32x4* wfrag16 = nullptr;    // its weight fragments
     RwPlan rw;
     float* ptab = nullptr;       // folded BN tables for the rw kernel
@@ -707,6 +708,16 @@ int rn_fused_prepare(rn_handle* h, const rn_weights* w) {
         }
         f.use_rw = rn_rw_supported(s.cin, s.cout, s.pool_k, s.pool_s, s.skip_stage >= 0, s.out_side, s.skip_side,
                                    &f.rw) && !(h->flags & RN_FLAG_GENERIC_KERNELS);
+        // The row-blocked stride-2 stages (rn_stage4x / rn_stage5x) store their conv weights divided by 6: their ReLU6 is then
+        // the free [0, 1] clamp of the fp16 conversion (pack2_relu6_sixth) and the folded BN scale carries the 6.  (Tried on
+        // the pool 4/1 stages too: no gain there, and the fused pair then differed from the stage launches in 1 element of
+        // 4.4e7 -- the fp32 order of the pooling sums shows through the fp16 rounding -- NOTES.md.)
+        const bool want_s4x = f.use_rw && !(h->flags & (RN_FLAG_GENERIC_KERNELS | RN_FLAG_PAIR_32X32)) &&
+                              rn_stage4x_supported(s.cin, s.cout, s.pool_k, s.pool_s, s.skip_stage >= 0, s.in_side);
+        const bool want_s5x = f.use_rw && !(h->flags & (RN_FLAG_GENERIC_KERNELS | RN_FLAG_PAIR_32X32)) && s.skip_stage >= 0 &&
+                              rn_stage5x_supported(s.cin, s.cout, s.pool_k, s.pool_s, true, s.in_side, s.skip_side) &&
+                              s.skip_stage == static_cast<int>(i) - 1 && h->stages[s.skip_stage].node_bn2 < 0;
+        f.sixth = want_s4x || want_s5x;
         if (f.use_rw) {
             // y = S * (inv / k^2) + (beta - mean * inv);  y2 = (y + r) * inv2 + (beta2 - mean2 * inv2)
             const rn_conv_stage& ws = w->stages[i];
@@ -725,6 +736,7 @@ int rn_fused_prepare(rn_handle* h, const rn_weights* w) {
                     tab[s.cout + c] = tab[s.cout + c] * inv2 + sh2;
                     tab[c] = tab[c] * inv2;
                 }
+                if (f.sixth) tab[c] *= 6.0f;
             }
             void* dt = nullptr;
             hipError_t e2 = hipMalloc(&dt, tab.size() * 4);
@@ -759,6 +771,12 @@ int rn_fused_prepare(rn_handle* h, const rn_weights* w) {
         std::vector<unsigned short> frag(static_cast<size_t>(kc) * ct_n * 64 * 8, 0);
         const float* wsrc = w->stages[i].kernel;   // HWIO == [k = tap*cin + c][cout]
         const int K = 9 * s.cin;
+        std::vector<float> wsixth;
+        if (f.sixth) {
+            wsixth.assign(wsrc, wsrc + static_cast<size_t>(K) * s.cout);
+            for (float& v : wsixth) v /= 6.0f;
+            wsrc = wsixth.data();
+        }
         for (int c = 0; c < kc; ++c)
             for (int t = 0; t < ct_n; ++t)
                 for (int l = 0; l < 64; ++l)
@@ -809,8 +827,7 @@ int rn_fused_prepare(rn_handle* h, const rn_weights* w) {
             f.use_s6x = true;
             f.use_c16 = false;
         }
-        if (f.use_rw && f.ptab && !(h->flags & (RN_FLAG_GENERIC_KERNELS | RN_FLAG_PAIR_32X32)) &&
-            rn_stage4x_supported(s.cin, s.cout, s.pool_k, s.pool_s, s.skip_stage >= 0, s.in_side)) {
+        if (f.ptab && want_s4x) {
             std::vector<unsigned short> f16;
             rn_stage4x_pack(wsrc, h->dtype, f32_to_bf16, f32_to_f16, &f16);
             void* d16 = nullptr;
@@ -823,9 +840,7 @@ int rn_fused_prepare(rn_handle* h, const rn_weights* w) {
             f.wfrag16 = static_cast<i32x4*>(d16);
             f.use_s4x = true;
         }
-        if (f.use_rw && f.ptab && !(h->flags & (RN_FLAG_GENERIC_KERNELS | RN_FLAG_PAIR_32X32)) && s.skip_stage >= 0 &&
-            rn_stage5x_supported(s.cin, s.cout, s.pool_k, s.pool_s, true, s.in_side, s.skip_side) &&
-            s.skip_stage == static_cast<int>(i) - 1 && h->stages[s.skip_stage].node_bn2 < 0) {
+        if (f.ptab && want_s5x) {
             // (the skip tensor must be the stage's own input: the kernel interpolates it from its input ring)
             std::vector<unsigned short> f16;
             rn_stage5x_pack(wsrc, h->dtype, f32_to_bf16, f32_to_f16, &f16);

@@ -61,6 +61,19 @@ __device__ __forceinline__ unsigned pack2(float a, float b) {
     }
 }
 
+// ReLU6 of two accumulators of a stage whose conv weights are stored DIVIDED BY 6 (rn_fused_prepare: `sixth`), as one
+// instruction: relu6(6 x) / 6 = clamp(x, 0, 1), and the [0, 1] clamp is the free output modifier of the fp16 conversion
+// (LLVM folds the packed min / max into `v_cvt_pk_f16_f32 ... clamp`).  The pooled sums stay scaled by 1/6; the folded BN
+// scale of such a stage carries the 6.
+__device__ __forceinline__ unsigned pack2_relu6_sixth(float a, float b) {
+    using f16x2 = __attribute__((ext_vector_type(2))) _Float16;
+    const f32x2 v = {a, b};
+    f16x2 h = __builtin_convertvector(v, f16x2);
+    const f16x2 z = {static_cast<_Float16>(0.f), static_cast<_Float16>(0.f)}, o = {static_cast<_Float16>(1.f), static_cast<_Float16>(1.f)};
+    h = __builtin_elementwise_min(__builtin_elementwise_max(h, z), o);
+    return __builtin_bit_cast(unsigned, h);
+}
+
 template <int DT>
 __device__ __forceinline__ uint2 pack4(float a, float b, float c, float d) {
     uint2 r;

@@ -224,8 +224,8 @@ __global__ __launch_bounds__(512, 2) void stage4x_kernel(const StageArgs a) {
             // conv row j = s - 2 of this tile is complete: ReLU6 -> fp16 pairs; even rows wait in hp, odd rows form the pair
             // sum and the pooling operand [previous pair sum | this pair sum]
             const f32x4 v = acc[iO][k];
-            const int v0 = static_cast<int>(pack2<RN_DTYPE_F16>(relu6f(v[0]), relu6f(v[1])));
-            const int v1 = static_cast<int>(pack2<RN_DTYPE_F16>(relu6f(v[2]), relu6f(v[3])));
+            const int v0 = static_cast<int>(pack2_relu6_sixth(v[0], v[1]));
+            const int v1 = static_cast<int>(pack2_relu6_sixth(v[2], v[3]));
             if constexpr (PAR == 0) {
                 hp[k][0] = v0;
                 hp[k][1] = v1;
