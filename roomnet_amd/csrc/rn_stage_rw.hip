@@ -52,7 +52,7 @@ constexpr int rw_tile_stride(int pk, int ps, bool wide = false) { return pk ? rw
 #endif
 constexpr int RW_SKIPBUF = 3;   // staged skip-row pairs (residual): 1 being read + 2 in flight
 
-template <int DT, int CIN, int COUT, int PK, int PS, bool RES, int NPT, int KS = 1, bool S0F_ = false, bool WIDE_ = false, bool S0SH_ = false>
+template <int DT, int CIN, int COUT, int PK, int PS, bool RES, int NPT, int KS = 1, bool S0F_ = false, bool WIDE_ = false, int S0SH_ = 0>
 struct RwCfg {
     // S0F: stage 0 (uint8 image -> conv 3->8 -> ReLU6 -> pool 3/1 -> BN) is computed by the SAME wave, row by row,
     // straight into its private ring: the 8-channel tensor between stages 0 and 1 never reaches HBM (see s0_feed)
@@ -60,9 +60,14 @@ struct RwCfg {
     // S0SH (with S0F, one column block): the stage-0 rows go to ONE ring shared by the workgroup -- wave w computes the 29
     // stage-0 columns [29 w, 29 w + 29) (one 32-column tile instead of two: the second tile of the private form exists
     // for 5 halo columns only and costs as much as the first) and reads its 34-column window once its neighbours are done
-    static constexpr bool S0SH = S0SH_;
+    static constexpr bool S0SH = S0SH_ != 0;
     static_assert(!S0SH || S0F, "shared stage-0 ring is a form of the stage-0 fusion");
-    static constexpr int S0_TILES = S0SH ? 1 : 2;
+    // S0SH_ == 2 (S0HW): NPT / 2 extra "helper" waves compute the stage-0 rows (two 29-column tiles each) and the NPT tile
+    // waves run stage 1 only: 12 waves of <= 168 registers = three per SIMD instead of two, and the stage-0 row (a long
+    // dependent sequence: image bytes -> operand -> 3 MFMAs -> DPP sums -> BN -> LDS) runs beside the stage-1 chains of the
+    // SIMD's other waves instead of in front of them
+    static constexpr bool S0HW = S0SH_ == 2;
+    static constexpr int S0_TILES = S0HW ? 2 : (S0SH ? 1 : 2);
     static_assert(!S0F || (CIN == 8 && !RES && KS == 1 && COUT == 32), "stage-0 fusion feeds the 8-channel private-ring variant");
     // Ring depth: at step s the DMA for input row s + AHEAD is issued; NSLOT = AHEAD + 1 slots
     // (3 live rows + AHEAD - 2 in flight).  Rows of the 8-channel stage are only ~3.8 KB, so it
@@ -92,7 +97,7 @@ struct RwCfg {
     static constexpr bool DPP2 = PK == 4 && PS == 2;           // stride-2 pooling by DPP (gapped or wide)
     // KS = 3: the K dimension is split by kernel row over three waves per pixel tile (each keeps one
     // kernel row's weight fragments in registers); partial accumulators meet in LDS (K = 1152 stage)
-    static constexpr int NTHREADS = 64 * NPT * CT * KS;
+    static constexpr int NTHREADS = 64 * NPT * CT * KS + (S0SH_ == 2 ? 64 * (NPT / 2) : 0);
     static constexpr int KCW = KC / KS;                        // K-chunks per wave
     // PRIV: every wave owns a private ring holding just its own 34-column input tile and fetches
     // it itself.  No wave ever reads another wave's LDS data, so the row loop needs NO workgroup
@@ -125,7 +130,7 @@ struct RwCfg {
     static constexpr bool STAGE_OUT = COUT == 32 && !RES;
     // folded-BN tables: persistent registers where the register file has room (one wave per SIMD, or the
     // small 8-channel stage); otherwise one batched LDS read at the start of every epilogue
-    static constexpr bool PTAB_REGS = NTHREADS <= 256 || CIN == 8 || (CIN == 32 && COUT == 64);
+    static constexpr bool PTAB_REGS = (NTHREADS <= 256 || CIN == 8 || (CIN == 32 && COUT == 64)) && !S0HW;   // (S0HW: 168 registers per wave)
     // ... except the 8-wave 32->32 variant, which sits at the 256-register cap: it reads each group's
     // table entries late (right before use) so they never pin registers across the MFMA chain
     static constexpr bool PTAB_LATE = !PTAB_REGS && CIN == 32 && COUT == 32;
@@ -167,8 +172,8 @@ __device__ __forceinline__ unsigned long long stamp() {
 }
 #endif
 
-template <int DT, int CIN, int COUT, int PK, int PS, bool RES, int NPT, int KS, bool S0F, bool WIDE, bool S0SH>
-__global__ __launch_bounds__(64 * NPT * ((COUT + 31) / 32) * KS, 1) void stage_rw_kernel(const StageArgs a) {
+template <int DT, int CIN, int COUT, int PK, int PS, bool RES, int NPT, int KS, bool S0F, bool WIDE, int S0SH>
+__global__ __launch_bounds__((RwCfg<DT, CIN, COUT, PK, PS, RES, NPT, KS, S0F, WIDE, S0SH>::NTHREADS), 1) void stage_rw_kernel(const StageArgs a) {
     using C = RwCfg<DT, CIN, COUT, PK, PS, RES, NPT, KS, S0F, WIDE, S0SH>;
     constexpr int CP = C::CP, KC = C::KC, CT = C::CT, CPO = C::CPO, TSTRIDE = C::TSTRIDE, NOUT_T = C::NOUT_T;
     constexpr int RINGCOLS = C::RINGCOLS, ROWB = C::ROWB, NTHREADS = C::NTHREADS, LPT = C::LPT, SLPT = C::SLPT;
@@ -187,6 +192,8 @@ __global__ __launch_bounds__(64 * NPT * ((COUT + 31) / 32) * KS, 1) void stage_r
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int pt = wave % NPT, ct = (wave / NPT) % CT;
+    const bool helper = C::S0HW && wave >= NPT;      // stage-0 helper wave (wave-uniform); tiles 2 hq, 2 hq + 1
+    const int hq = wave - NPT;
     const int ks = __builtin_amdgcn_readfirstlane(wave / (NPT * CT));     // kernel row of this wave (K split)
     constexpr int KCW = C::KCW;
     const int r = lane & 31, hh = lane >> 5;
@@ -344,19 +351,20 @@ __global__ __launch_bounds__(64 * NPT * ((COUT + 31) / 32) * KS, 1) void stage_r
     float s0_h1[2][4], s0_h2[2][4];
     int s0_wr[2] = {0, 0};                 // byte offset of this lane's 8-byte piece inside a ring row, or -1
     const int s0_rows = nin + 4;           // image rows this band reads
-    if constexpr (C::S0F) {
+    if (C::S0F && (!C::S0HW || helper)) {
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky) s0_w[ky] = a.s0_wfrag[ky * 64 + lane];
         s0_scale = *reinterpret_cast<const f32x4*>(a.s0_ptab + 4 * hh);
         s0_shift = *reinterpret_cast<const f32x4*>(a.s0_ptab + 8 + 4 * hh);
 #pragma unroll
         for (int u = 0; u < C::S0_TILES; ++u) {
-            const int xt0 = x0c + pt * TSTRIDE + 29 * u;               // first conv / image column of the tile
+            const int tix = C::S0HW ? 2 * hq + u : pt;                   // shared ring: the 29-column tile this (wave, u) produces
+            const int xt0 = x0c + (C::S0HW ? tix * 29 : pt * TSTRIDE + 29 * u);   // first conv / image column of the tile
             const int px = min(xt0 + r + 2 * hh, a.s0_S - 1);           // this lane's image column (clamped at the edge)
             s0_sh[u] = px == a.s0_S - 1 ? 8 : 0;                        // last column: load one byte early and shift
             s0_src[u] = a.s0_bgr + (static_cast<int64_t>(n) * a.s0_S * a.s0_S + static_cast<int64_t>(yc0) * a.s0_S + px) * 3 - (s0_sh[u] >> 3);
-            const int oc = (C::S0SH ? pt * TSTRIDE : 0) + 29 * u + r;   // ring column of this lane's output pixel
-            s0_wr[u] = (r < (u == 0 ? 29 : 5) && oc < RINGCOLS) ? oc * PIXB + 8 * hh : -1;
+            const int oc = C::S0HW ? tix * 29 + r : (C::S0SH ? pt * TSTRIDE : 0) + 29 * u + r;   // ring column of this lane's output pixel
+            s0_wr[u] = (r < (u == 0 || C::S0HW ? 29 : 5) && oc < RINGCOLS) ? oc * PIXB + 8 * hh : -1;
 #pragma unroll
             for (int j = 0; j < 4; ++j) s0_h1[u][j] = s0_h2[u][j] = 0.f;
 #pragma unroll
@@ -481,18 +489,20 @@ __global__ __launch_bounds__(64 * NPT * ((COUT + 31) / 32) * KS, 1) void stage_r
             for (int i = tid; i < RW_NSLOT * ZN; i += NTHREADS)
                 *reinterpret_cast<i32x4*>(ring + (i / ZN) * ROWB + Z0 + (i % ZN) * 16) = i32x4{0, 0, 0, 0};
         }
-#pragma unroll
-        for (int u = 0; u < C::S0_TILES; ++u)
-#pragma unroll
-            for (int k = 0; k < S0_AHEAD; ++k) s0_pw[u][k] = s0_load(u, k);
         static_assert(!C::S0F || (RW_NSLOT == 4 && S0_AHEAD == 4 && RW_AHEAD == 3), "queue phase = ring phase");
-        s0_feed(IC<0>{}, IC<0>{}, 0, 0);
-        s0_feed(IC<0>{}, IC<1>{}, 1, 0);
-        s0_feed(IC<0>{}, IC<2>{}, 2, 0);
-        s0_feed(IC<0>{}, IC<3>{}, 3, 0);
-        s0_feed(IC<1>{}, IC<0>{}, 4, 0);                   // emits ring rows 0 .. RW_AHEAD-1
-        s0_feed(IC<1>{}, IC<1>{}, 5, 1);
-        s0_feed(IC<1>{}, IC<2>{}, 6, 2);
+        if (!C::S0HW || helper) {
+#pragma unroll
+            for (int u = 0; u < C::S0_TILES; ++u)
+#pragma unroll
+                for (int k = 0; k < S0_AHEAD; ++k) s0_pw[u][k] = s0_load(u, k);
+            s0_feed(IC<0>{}, IC<0>{}, 0, 0);
+            s0_feed(IC<0>{}, IC<1>{}, 1, 0);
+            s0_feed(IC<0>{}, IC<2>{}, 2, 0);
+            s0_feed(IC<0>{}, IC<3>{}, 3, 0);
+            s0_feed(IC<1>{}, IC<0>{}, 4, 0);               // emits ring rows 0 .. RW_AHEAD-1
+            s0_feed(IC<1>{}, IC<1>{}, 5, 1);
+            s0_feed(IC<1>{}, IC<2>{}, 6, 2);
+        }
     } else {
 #pragma unroll
         for (int j = 0; j < RW_AHEAD; ++j) issue_row(min(j, nin - 1), j);
@@ -685,6 +695,34 @@ __global__ __launch_bounds__(64 * NPT * ((COUT + 31) / 32) * KS, 1) void stage_r
 
     wait_vmcnt<0>();
     lds_barrier();
+
+    if constexpr (C::S0HW) {
+        if (helper) {
+            // stage-0 helper: one ring row per step, in step with the tile waves' barriers (nconv + 1 of them: the first
+            // step, nconv - 1 full steps, the drain step); step k produces ring row k + RW_AHEAD, read from step k + 1 on
+            auto hstep = [&](auto PC, int k) __attribute__((always_inline)) {
+                constexpr int P = decltype(PC)::value;
+                s0_front(IC<(P + RW_AHEAD + 4) % 4>{}, k + RW_AHEAD + 4);
+                s0_part(IC<0>{}, (P + RW_AHEAD) % RW_NSLOT);
+                s0_part(IC<1>{}, (P + RW_AHEAD) % RW_NSLOT);
+                s0_part(IC<2>{}, (P + RW_AHEAD) % RW_NSLOT);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                raw_barrier();
+            };
+            int k = 0;
+            for (; k + 3 < nconv; k += 4) {
+                hstep(IC<0>{}, k);
+                hstep(IC<1>{}, k + 1);
+                hstep(IC<2>{}, k + 2);
+                hstep(IC<3>{}, k + 3);
+            }
+            if (k < nconv) hstep(IC<0>{}, k++);
+            if (k < nconv) hstep(IC<1>{}, k++);
+            if (k < nconv) hstep(IC<2>{}, k++);
+            raw_barrier();          // the tile waves' drain step
+            return;
+        }
+    }
 
     // B fragment of K-chunk kc for the conv row whose first input row sits in ring slot P
     // (compiler-visible load; used by the 8-channel variant whose tap row is lane dependent)
@@ -1099,7 +1137,7 @@ __global__ __launch_bounds__(64 * NPT * ((COUT + 31) / 32) * KS, 1) void stage_r
                      ...);
                 }(std::make_integer_sequence<int, NPIECE>{});
             }
-            if constexpr (MMA && C::S0F && I < 3) s0_part(IC<(I < 3 ? I : 0)>{}, (P + RW_AHEAD) % RW_NSLOT);
+            if constexpr (MMA && C::S0F && !C::S0HW && I < 3) s0_part(IC<(I < 3 ? I : 0)>{}, (P + RW_AHEAD) % RW_NSLOT);
             if constexpr (EPI && SLICED) {
                 [&]<int... K>(std::integer_sequence<int, K...>) {
                     (([&] {
@@ -1116,7 +1154,7 @@ __global__ __launch_bounds__(64 * NPT * ((COUT + 31) / 32) * KS, 1) void stage_r
             //  DMA pieces per step stays constant, so the counted waits and the code path do too)
             if constexpr (!RN_SPREAD_DMA && !C::S0F) issue_row(min(s + RW_AHEAD, nin - 1), (P + RW_AHEAD) % RW_NSLOT);
             // S0F: image row s + RW_AHEAD + 4 completes stage-0 output row s + RW_AHEAD -> the slot the DMA would fill
-            if constexpr (C::S0F) s0_front(IC<(P + RW_AHEAD + 4) % 4>{}, s + RW_AHEAD + 4);      // the rest: chain slots 0..2
+            if constexpr (C::S0F && !C::S0HW) s0_front(IC<(P + RW_AHEAD + 4) % 4>{}, s + RW_AHEAD + 4);      // the rest: chain slots 0..2
             if constexpr (RES && (PS == 1 || (P & 1) == 0)) {
                 // pair for the epilogue of conv row s+1 (runs in step s+2): e = (s + 1 - 3) / PS
                 // (stride 2: only odd conv rows emit, so pairs are issued on even steps)
@@ -1225,7 +1263,7 @@ __global__ __launch_bounds__(64 * NPT * ((COUT + 31) / 32) * KS, 1) void stage_r
 #endif
 }
 
-template <int DT, int CIN, int COUT, int PK, int PS, bool RES, int NPT, int KS = 1, bool S0F = false, bool WIDE = false, bool S0SH = false>
+template <int DT, int CIN, int COUT, int PK, int PS, bool RES, int NPT, int KS = 1, bool S0F = false, bool WIDE = false, int S0SH = 0>
 int launch_rw(hipStream_t s, const StageArgs& a, dim3 grid) {
     using C = RwCfg<DT, CIN, COUT, PK, PS, RES, NPT, KS, S0F, WIDE, S0SH>;
     auto kern = stage_rw_kernel<DT, CIN, COUT, PK, PS, RES, NPT, KS, S0F, WIDE, S0SH>;
@@ -1254,7 +1292,7 @@ int launch_rw(hipStream_t s, const StageArgs& a, dim3 grid) {
     return RN_OK;
 }
 
-template <int CIN, int COUT, int PK, int PS, bool RES, int NPT, int KS = 1, bool S0F = false, bool WIDE = false, bool S0SH = false>
+template <int CIN, int COUT, int PK, int PS, bool RES, int NPT, int KS = 1, bool S0F = false, bool WIDE = false, int S0SH = 0>
 int launch_rw_dt(int dtype, hipStream_t s, const StageArgs& a, dim3 grid) {
     if (dtype == RN_DTYPE_BF16) return launch_rw<RN_DTYPE_BF16, CIN, COUT, PK, PS, RES, NPT, KS, S0F, WIDE, S0SH>(s, a, grid);
     return launch_rw<RN_DTYPE_F16, CIN, COUT, PK, PS, RES, NPT, KS, S0F, WIDE, S0SH>(s, a, grid);
@@ -1332,6 +1370,13 @@ bool rn_rw_supported(int cin, int cout, int pool_k, int pool_s, bool res, int ou
     return rw_plan(cin, cout, pool_k, pool_s, res, out_side, skip_side, false, plan);
 }
 
+// 1: shared stage-0 ring, every wave computes its own stage-0 tile (0.216-0.22 ms at batch 256).
+// 2: + four stage-0 helper waves (12-wave workgroups, three waves per SIMD): bit-identical, but the stage-1 waves need ~200
+//    registers and get 168 -- 46 spilled -- 0.227-0.234 ms.  Kept as a build switch: the direction needs a stage-1 wave
+//    designed for 168 registers (NOTES.md).
+#ifndef RN_S0_MODE
+#define RN_S0_MODE 1
+#endif
 int rn_rw_launch(const RwPlan& p, int dtype, hipStream_t s, const StageArgs& a, dim3 grid) {
     switch (p.variant * 16 + p.npt) {
         case 0 * 16 + 4:
@@ -1340,7 +1385,7 @@ int rn_rw_launch(const RwPlan& p, int dtype, hipStream_t s, const StageArgs& a, 
         case 0 * 16 + 8:
             // one column block whose stage-0 columns (outputs + 5) all come from the eight 29-column tiles: shared ring
             if (a.s0_bgr && a.n_colblocks == 1 && a.Wo + 5 <= 8 * 29 && !a.s0_private)
-                return launch_rw_dt<8, 32, 4, 1, false, 8, 1, true, false, true>(dtype, s, a, grid);
+                return launch_rw_dt<8, 32, 4, 1, false, 8, 1, true, false, RN_S0_MODE>(dtype, s, a, grid);
             if (a.s0_bgr) return launch_rw_dt<8, 32, 4, 1, false, 8, 1, true>(dtype, s, a, grid);
             return launch_rw_dt<8, 32, 4, 1, false, 8>(dtype, s, a, grid);
         case 1 * 16 + 4: return launch_rw_dt<32, 32, 4, 1, false, 4>(dtype, s, a, grid);
