@@ -16,10 +16,10 @@ Before anything is timed the SAME handle classifies the 40 parity images (roomne
 result is checked against tests/golden/parity_224.npz at the SURVEY 8c tolerance: the timed kernels are the tested ones.
 
 Clock spin-up: the engine clock takes tens of milliseconds of load to leave its idle state and the driver's W = 5 warm-up
-steps are 7 ms, so `--spinup-s` seconds (default 0.3) of the same passes run, untimed, BEFORE the W warm-up steps; then W
+steps are 7 ms, so `--spinup-steps` (default 240, ~0.3 s) of the same passes run, untimed, BEFORE the W warm-up steps; then W
 warm-up steps, then EXACTLY K timed steps between barriers as the contract says.  A 20-step sample then shows the sustained
 rate a 200- or 6000-step run shows (measured on one box: 190 k img/s cold, 202 k with the spin-up, 202 k at 200 steps);
-the count is reported as `spinup_steps`, `--spinup-s 0` turns it off.
+the count is reported as `spinup_steps`, `--spinup-steps 0` turns it off.
 
 Rank 0 prints ONE JSON line.  Extra objects:
   roofline      the dominant launch (longest kernel, timed live with HIP events on the launch stream): ALGORITHMIC
@@ -219,9 +219,10 @@ def main():
     ap.add_argument("--event-steps", type=int, default=30, help="iterations of the per-step hipEvent timing pass (median reported)")
     ap.add_argument("--pair32", action="store_true", help="fused stage pair on the round-2 32x32x16 kernel (RN_FLAG_PAIR_32X32: comparison arm)")
     ap.add_argument("--no-parity-check", action="store_true", help="skip the golden check (timing experiments with garbage results)")
-    ap.add_argument("--spinup-s", type=float, default=0.3,
-                    help="untimed passes for this many seconds BEFORE the W warm-up steps: the engine clock needs tens of ms of load to "
-                         "leave its idle state, and W = 5 steps are 7 ms (reported as `spinup_steps`; 0 = none)")
+    ap.add_argument("--spinup-steps", type=int, default=240,
+                    help="untimed passes BEFORE the W warm-up steps (~0.3 s at batch 256, 224 x 224): the engine clock needs tens of ms "
+                         "of load to leave its idle state, and W = 5 steps are 7 ms.  A fixed count, the same on every rank (a step "
+                         "holds a collective when N > 1).  Reported as `spinup_steps`; 0 = none")
     ap.add_argument("--stage-launches", action="store_true",
                     help="one launch per conv stage (RN_FLAG_STAGE_LAUNCHES): the unfused comparison arm")
     ap.add_argument("--stub-engine", action="store_true", help=argparse.SUPPRESS)    # CPU tensors + gloo (tests)
@@ -346,14 +347,12 @@ def main():
     sync()
     spinup_steps = 0
     with on_stream():
-        if args.spinup_s > 0 and not stub:
+        if args.spinup_steps > 0 and not stub:
             # bring the chip to its sustained clock / power state: not part of W, not timed
-            t_spin = time.perf_counter()
-            while time.perf_counter() - t_spin < args.spinup_s:
-                for _ in range(10):
-                    step()
-                sync()
-                spinup_steps += 10
+            for _ in range(args.spinup_steps):
+                step()
+                spinup_steps += 1
+            sync()
         for _ in range(args.warmup):
             step()
         sync()

@@ -8,5 +8,5 @@ ROOMNET_HIP_LIB=roomnet_amd/lib/libroomnet_hip_$V.so timeout 900 python -m pytes
 echo "pytest rc=$?"; tail -5 gpurun_out/r3/pytest_$V.log
 tools/gpu_var.sh base "$@" base "$@" | tee gpurun_out/r3/ab_$V.txt
 if [ -f roomnet_amd/lib/libroomnet_hip_stamps.so ]; then
-ROOMNET_HIP_LIB=roomnet_amd/lib/libroomnet_hip_stamps.so python bench.py --steps 2 --warmup 1 --no-cpu-baseline --profile-steps 1 2>&1 | grep -E "stamps" | grep -v "stage [145]" | tail -12 | tee gpurun_out/r3/stamps_$V.txt
+ROOMNET_HIP_LIB=roomnet_amd/lib/libroomnet_hip_stamps.so python bench.py --steps 2 --warmup 1 --spinup-steps 0 --no-cpu-baseline --profile-steps 1 2>&1 | grep -E "stamps" | grep -v "stage [145]" | tail -12 | tee gpurun_out/r3/stamps_$V.txt
 fi
