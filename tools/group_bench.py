@@ -36,6 +36,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--spinup-steps", type=int, default=240, help="untimed passes before the warm-up steps (engine clock out of idle; see bench.py)")
     ap.add_argument("--batch", type=int, default=None, help="images per GPU (default 256 at 224, 64 at 600)")
     ap.add_argument("--side", type=int, default=224)
     ap.add_argument("--dtype", default=None, choices=["bf16", "f16"])
@@ -67,7 +68,7 @@ def main():
     def step():
         _capi._check(lib, lib.rn_group_forward_u8_device(grp._g, shards, counts), "rn_group_forward_u8_device")
 
-    for _ in range(args.warmup):
+    for _ in range(args.spinup_steps + args.warmup):
         step()
     _capi._check(lib, lib.rn_group_sync(grp._g), "rn_group_sync")
     t0 = time.perf_counter()
@@ -95,7 +96,7 @@ def main():
     value = N * B * args.steps / elapsed
     bytes_per_img = graph.boundary_elements_per_image() * 2
     out = {"metric": "images/sec, %dx%d batch-%d RoomNet inference" % (args.side, args.side, B),
-           "value": value, "unit": "images/sec", "n_gpus": N, "steps": args.steps, "warmup": args.warmup,
+           "value": value, "unit": "images/sec", "n_gpus": N, "steps": args.steps, "warmup": args.warmup, "spinup_steps": args.spinup_steps,
            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
            "dtype": dtype, "data": "synthetic",
            "config": {"workload": "RoomNet forward (reference final_model weights), uint8 BGR %dx%dx3 resident in each GPU's HBM -> "
