@@ -21,6 +21,12 @@ warm-up steps, then EXACTLY K timed steps between barriers as the contract says.
 rate a 200- or 6000-step run shows (measured on one box: 190 k img/s cold, 202 k with the spin-up, 202 k at 200 steps);
 the count is reported as `spinup_steps`, `--spinup-steps 0` turns it off.
 
+Two handles: the steps alternate between two engine handles (own activation tensors, own stream, own result buffer), so the
+small launches at the end of step k (stages 6, 7 and the tail: one latency-bound workgroup per image) overlap the first launch
+of step k + 1: +1-1.5 % (`--handles 1`: one handle, strictly serial steps).  Every step is one complete pass over one
+resident batch; both handles pass the parity gate; `ms_per_step` = elapsed / K can be a little below the sum of the launch
+times, which are measured on one handle alone.
+
 Rank 0 prints ONE JSON line.  Extra objects:
   roofline      the dominant launch (longest kernel, timed live with HIP events on the launch stream): ALGORITHMIC
                 stage-boundary bytes of the stages it computes / duration vs 8 TB/s (SURVEY.md 8d byte model; a
@@ -219,6 +225,10 @@ def main():
     ap.add_argument("--event-steps", type=int, default=30, help="iterations of the per-step hipEvent timing pass (median reported)")
     ap.add_argument("--pair32", action="store_true", help="fused stage pair on the round-2 32x32x16 kernel (RN_FLAG_PAIR_32X32: comparison arm)")
     ap.add_argument("--no-parity-check", action="store_true", help="skip the golden check (timing experiments with garbage results)")
+    ap.add_argument("--handles", type=int, default=2, choices=(1, 2),
+                    help="engine handles (each with its own activation tensors and stream) that take the steps in turn: with 2, the "
+                         "small launches at the end of step k (stages 6, 7, tail: one latency-bound workgroup per image) overlap the "
+                         "first launch of step k + 1.  Every step is still one complete pass over one resident batch")
     ap.add_argument("--spinup-steps", type=int, default=240,
                     help="untimed passes BEFORE the W warm-up steps (~0.3 s at batch 256, 224 x 224): the engine clock needs tens of ms "
                          "of load to leave its idle state, and W = 5 steps are 7 ms.  A fixed count, the same on every rank (a step "
@@ -276,6 +286,10 @@ def main():
                 -0.04, 0.04, (graph.flat_len, 32)).astype(np.float32)
         eng = _capi.Engine(graph, weights, device=local_rank, dtype=args.dtype, max_batch=B,
                            stage_launches=args.stage_launches, pair32=args.pair32)
+    engs = [eng]
+    if not stub and args.handles == 2:
+        engs.append(_capi.Engine(graph, weights, device=local_rank, dtype=args.dtype, max_batch=B,
+                                 stage_launches=args.stage_launches, pair32=args.pair32))
 
     ims = torch.from_numpy(perf_batch(B, args.side, seed=rank)).to(dev)
     # probs [B,6] fp32 and ids [B] int64 live in ONE byte buffer per rank, so the result exchange is a single
@@ -293,8 +307,11 @@ def main():
 
     # ONE explicit stream for the library's kernels and the collective: torch's default stream is the null stream,
     # which the library's own (non-blocking) stream is not ordered against.
+    # (two handles: handle k & 1, stream k & 1 and result buffer k & 1 belong together, so every ordering argument below
+    #  holds per parity exactly as it does for one handle)
     if stub:
         stream = None
+        streams = [None, None]
 
         def sync():
             drain()
@@ -304,13 +321,17 @@ def main():
     else:
         stream = torch.cuda.Stream(dev)
         eng.set_stream(stream.cuda_stream)
+        streams = [stream, stream]
+        if len(engs) == 2:
+            streams[1] = torch.cuda.Stream(dev)
+            engs[1].set_stream(streams[1].cuda_stream)
 
         def sync():
             drain()
             torch.cuda.synchronize()
 
         def forward(k=0):
-            eng.forward_u8_device(ims.data_ptr(), B, bufs[k][1].data_ptr(), bufs[k][2].data_ptr())
+            engs[k % len(engs)].forward_u8_device(ims.data_ptr(), B, bufs[k][1].data_ptr(), bufs[k][2].data_ptr())
 
     def drain():
         for k in range(2):
@@ -321,11 +342,12 @@ def main():
     def step():
         k = n_steps_done[0] & 1
         n_steps_done[0] += 1
-        if multi and works[k] is not None:
-            works[k].wait()                   # the gather that read buffer k two steps ago
-        forward(k)
-        if multi:
-            works[k] = dist.all_gather_into_tensor(g_bufs[k], bufs[k][0], async_op=True)
+        with (torch.cuda.stream(streams[k]) if streams[k] is not None else contextlib.nullcontext()):
+            if multi and works[k] is not None:
+                works[k].wait()                   # the gather that read buffer k two steps ago
+            forward(k)
+            if multi:
+                works[k] = dist.all_gather_into_tensor(g_bufs[k], bufs[k][0], async_op=True)
 
     def on_stream():
         return torch.cuda.stream(stream) if stream is not None else contextlib.nullcontext()
@@ -343,6 +365,17 @@ def main():
             torch.cuda.synchronize()
             return i.cpu().numpy(), p.cpu().numpy()
         parity = check_parity(fwd_host, args.side, args.dtype, B)
+        if len(engs) == 2:            # the second handle is timed too: same gate
+            def fwd_host2(batch):
+                t = torch.from_numpy(np.ascontiguousarray(batch)).to(dev)
+                p = torch.empty((len(batch), graph.num_classes), dtype=torch.float32, device=dev)
+                i = torch.empty((len(batch),), dtype=torch.int64, device=dev)
+                torch.cuda.synchronize()
+                with torch.cuda.stream(streams[1]):
+                    engs[1].forward_u8_device(t.data_ptr(), len(batch), p.data_ptr(), i.data_ptr())
+                torch.cuda.synchronize()
+                return i.cpu().numpy(), p.cpu().numpy()
+            check_parity(fwd_host2, args.side, args.dtype, B)
 
     sync()
     spinup_steps = 0
@@ -462,7 +495,7 @@ def main():
                                       ", RCCL all-gather of probs+ids" if multi else ""),
                        "images_per_gpu": B, "global_batch": world * B, "im_side": args.side,
                        "parallelism": "dp%d" % world},
-            "parity": parity, "spinup_steps": spinup_steps,
+            "parity": parity, "spinup_steps": spinup_steps, "handles": len(engs),
         }
         if not stub:
             dom = int(np.argmax(group_ms))
@@ -524,7 +557,8 @@ def main():
                 out["cpu_baseline"] = cpu_baseline(weights, args.side)
         print(json.dumps(out), flush=True)
     if not stub:
-        eng.close()
+        for e in engs:
+            e.close()
     if multi:
         dist.barrier()
         dist.destroy_process_group()
