@@ -184,7 +184,11 @@ __global__ __launch_bounds__(512, 2) void stage4x_kernel(const StageArgs a) {
     auto step = [&](auto RC, auto PARC, int s) __attribute__((always_inline)) {
         constexpr int R = decltype(RC)::value, PAR = decltype(PARC)::value;
         constexpr int iN = R, iM = (R + 2) % 3, iO = (R + 1) % 3;      // accumulators of conv rows s, s-1, s-2
-        wait_vmcnt<2 * (U_AHEAD - 1)>();                                // row s has landed (rows s+1, s+2 may be in flight)
+        // row s has landed.  VM_CNT counts the output stores too and retires in order: a step issues two DMA pieces at its
+        // top and, on odd rows, 3 (or 4: has7) stores at its end.  Younger than the DMA of row s (issued at step s - 3):
+        // even s: stores of s - 3, DMA of s - 2, DMA + stores of s - 1 = 3 + 2 + 2 + 3; odd s: DMA + stores of s - 2, DMA of
+        // s - 1 = 2 + 3 + 2.  (Counting the DMA pieces alone made every step wait for the previous step's stores.)
+        wait_vmcnt<PAR == 0 ? 10 : 7>();
         raw_barrier();
         {
             int sl = slot_cur + U_AHEAD;

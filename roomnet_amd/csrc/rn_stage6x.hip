@@ -130,7 +130,10 @@ __global__ __launch_bounds__(512, 2) void stage6x_kernel(const StageArgs a) {
     auto step = [&](auto RC, int s) __attribute__((always_inline)) {
         constexpr int R = decltype(RC)::value;
         constexpr int iN = R, iM = (R + 2) % 3, iO = (R + 1) % 3;
-        wait_vmcnt<S6_AHEAD - 1>();                                     // row s has landed (rows s+1, s+2 may be in flight)
+        // row s has landed.  VM_CNT counts the output stores too and retires in order: per step this wave issues one DMA
+        // piece and then three stores (always: masked lanes store out of range), so 3 + 4 + 4 operations are younger than
+        // the DMA of row s.  (Waiting for all but AHEAD - 1 made every step wait for the previous step's stores.)
+        wait_vmcnt<3 + 4 * (S6_AHEAD - 1)>();
         raw_barrier();
         {
             int sl = slot_cur + S6_AHEAD;
