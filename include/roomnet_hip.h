@@ -53,9 +53,11 @@ extern "C" {
  *     matrix, exact float32 accumulation); stride-2 pools are float32 VALU sums, except
  *     stages 4 and 5 at 224-class sizes (rn_stage4x.hip: 193-206 input columns,
  *     rn_stage5x.hip: 66-110), which pool like the stride-1 stages (fp16 ReLU6 outputs and
- *     pair sums, band-matrix MFMA) and keep their conv weights DIVIDED BY 6 (rounded to the
- *     16-bit type after the division): relu6(6 x) / 6 = clamp(x, 0, 1) is then the free
- *     clamp of the fp16 conversion, and the folded BN scale carries the 6;
+ *     pair sums, band-matrix MFMA);
+ *   - every stage that pools fp16 values on the matrix cores (stages 1-3 always, 4 and 5 where
+ *     the row-blocked kernels run) keeps its conv weights DIVIDED BY 6 (rounded to the 16-bit
+ *     type after the division): relu6(6 x) / 6 = clamp(x, 0, 1) is then the free clamp of the
+ *     fp16 conversion, and the folded BN scale carries the 6;
  *   - residual resize: the horizontal interpolation is an MFMA against the interpolation
  *     matrix in the storage type -- stage 3, and stage 5 at 224 x 224: one operand, lerp
  *     fraction rounded to 2^-8 (bf16) / 2^-11 (fp16) so that both weights are exact;
@@ -76,7 +78,8 @@ extern "C" {
                                stage_mfma_kernel (diagnostic cross-check of the tuned kernels) */
 #define RN_FLAG_PAIR_32X32 8u /* 16-bit handles: the round-2 kernels instead of the round-3 ones (comparison
                                arm, bench.py --pair32): the cross-stage fused pair of the 32-channel block
-                               (network.py:183-203: rn_stage23.hip instead of rn_stage23x.hip, bit-identical);
+                               (network.py:183-203: rn_stage23.hip instead of rn_stage23x.hip; equal up to the fp32 order of
+                               the pooling sums: ~1 value in 4e7 differs, by one 16-bit ulp);
                                the first step of the 64-channel block, its residual step and the 128-channel
                                step (network.py:216-235: rn_stage_rw.hip / rn_conv16.hip instead of
                                rn_stage4x/5x/6x.hip; these differ in the last 16-bit place: other

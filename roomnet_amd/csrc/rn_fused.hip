@@ -708,16 +708,15 @@ int rn_fused_prepare(rn_handle* h, const rn_weights* w) {
         }
         f.use_rw = rn_rw_supported(s.cin, s.cout, s.pool_k, s.pool_s, s.skip_stage >= 0, s.out_side, s.skip_side,
                                    &f.rw) && !(h->flags & RN_FLAG_GENERIC_KERNELS);
-        // The row-blocked stride-2 stages (rn_stage4x / rn_stage5x) store their conv weights divided by 6: their ReLU6 is then
-        // the free [0, 1] clamp of the fp16 conversion (pack2_relu6_sixth) and the folded BN scale carries the 6.  (Tried on
-        // the pool 4/1 stages too: no gain there, and the fused pair then differed from the stage launches in 1 element of
-        // 4.4e7 -- the fp32 order of the pooling sums shows through the fp16 rounding -- NOTES.md.)
+        // Stages whose kernel pools fp16 ReLU6 outputs on the matrix cores (the pool 4/1 register-weights variants and the
+        // cross-stage kernels built on them; rn_stage4x / rn_stage5x) store their conv weights divided by 6: the ReLU6 is
+        // then the free [0, 1] clamp of the fp16 conversion (pack2_relu6_sixth) and the folded BN scale carries the 6.
         const bool want_s4x = f.use_rw && !(h->flags & (RN_FLAG_GENERIC_KERNELS | RN_FLAG_PAIR_32X32)) &&
                               rn_stage4x_supported(s.cin, s.cout, s.pool_k, s.pool_s, s.skip_stage >= 0, s.in_side);
         const bool want_s5x = f.use_rw && !(h->flags & (RN_FLAG_GENERIC_KERNELS | RN_FLAG_PAIR_32X32)) && s.skip_stage >= 0 &&
                               rn_stage5x_supported(s.cin, s.cout, s.pool_k, s.pool_s, true, s.in_side, s.skip_side) &&
                               s.skip_stage == static_cast<int>(i) - 1 && h->stages[s.skip_stage].node_bn2 < 0;
-        f.sixth = want_s4x || want_s5x;
+        f.sixth = f.use_rw && ((s.pool_k == 4 && s.pool_s == 1) || want_s4x || want_s5x);
         if (f.use_rw) {
             // y = S * (inv / k^2) + (beta - mean * inv);  y2 = (y + r) * inv2 + (beta2 - mean2 * inv2)
             const rn_conv_stage& ws = w->stages[i];
@@ -899,7 +898,10 @@ int rn_fused_prepare(rn_handle* h, const rn_weights* w) {
             if (!(h->flags & RN_FLAG_PAIR_32X32)) {
                 for (int which = 0; which < 2; ++which) {
                     std::vector<unsigned short> f16;
-                    rn_stage23x_pack(w->stages[i + which].kernel, h->dtype, f32_to_bf16, f32_to_f16, &f16);
+                    // (both stages are pool 4/1 register-weights stages: `sixth` weights, like their fragments above)
+                    std::vector<float> w6(w->stages[i + which].kernel, w->stages[i + which].kernel + static_cast<size_t>(9) * 32 * 32);
+                    for (float& v : w6) v /= 6.0f;
+                    rn_stage23x_pack(w6.data(), h->dtype, f32_to_bf16, f32_to_f16, &f16);
                     void* d16 = nullptr;
                     if (hipMalloc(&d16, f16.size() * 2) != hipSuccess) {
                         rn_set_error("hipMalloc(fused pair weights) failed");

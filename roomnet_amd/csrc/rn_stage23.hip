@@ -166,7 +166,7 @@ __global__ __launch_bounds__(512, 2) void stage23pc_kernel(const Stage23Args a) 
         i32x4 qp[2];
 #pragma unroll
         for (int i2 = 0; i2 < 16; i2 += 2) {
-            const int vp = static_cast<int>(pack2<RN_DTYPE_F16>(relu6f(acce[i2]), relu6f(acce[i2 + 1])));
+            const int vp = static_cast<int>(pack2_relu6_sixth(acce[i2], acce[i2 + 1]));
             qp[i2 / 8][(i2 % 8) / 2] = pk_add_f16(hp[i2 / 8][(i2 % 8) / 2], vp);
             hp[i2 / 8][(i2 % 8) / 2] = vp;
         }
@@ -547,7 +547,7 @@ __global__ __launch_bounds__(512, 2) void stage23pc_kernel(const Stage23Args a) 
             auto& hpT = hp[T];
 #pragma unroll
             for (int i2 = 8 * hf; i2 < 8 * hf + 8; i2 += 2) {
-                const int vp = static_cast<int>(pack2<RN_DTYPE_F16>(relu6f(acce[i2]), relu6f(acce[i2 + 1])));
+                const int vp = static_cast<int>(pack2_relu6_sixth(acce[i2], acce[i2 + 1]));
                 qp[hf][(i2 % 8) / 2] = pk_add_f16(hpT[hf][(i2 % 8) / 2], vp);
                 hpT[hf][(i2 % 8) / 2] = vp;
             }

@@ -209,8 +209,8 @@ __global__ __launch_bounds__(512, 2) void stage23x_kernel(const Stage23Args a) {
                            int (&vt)[2][2]) __attribute__((always_inline)) {
         constexpr int part = decltype(PARTC)::value, PR = decltype(PRC)::value;
         constexpr int h = part / 3, sub = part % 3;
-        if constexpr (sub == 0) vt[h][0] = static_cast<int>(pack2<RN_DTYPE_F16>(relu6f(acc[h][0]), relu6f(acc[h][1])));
-        if constexpr (sub == 1) vt[h][1] = static_cast<int>(pack2<RN_DTYPE_F16>(relu6f(acc[h][2]), relu6f(acc[h][3])));
+        if constexpr (sub == 0) vt[h][0] = static_cast<int>(pack2_relu6_sixth(acc[h][0], acc[h][1]));
+        if constexpr (sub == 1) vt[h][1] = static_cast<int>(pack2_relu6_sixth(acc[h][2], acc[h][3]));
         if constexpr (sub == 2) {
             int(&qold)[2] = PR == 0 ? q0[h] : q1[h];
             const int n0 = pk_add_f16(hp[h][0], vt[h][0]), n1 = pk_add_f16(hp[h][1], vt[h][1]);
@@ -437,7 +437,9 @@ __global__ __launch_bounds__(512, 2) void stage23x_kernel(const Stage23Args a) {
                 out(IC<1>{}, PC, op[1], op[2], true);
                 out(IC<2>{}, PC, op[2], op[3], true);         // op[3] = 0, and columns 13..15 of the third tile go to the dummy column
             }
+#ifndef RN_Y_NOWAIT_P       // (timing experiment only: wrong results)
             wait_vmcnt<0>();
+#endif
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             raw_barrier();
         };
@@ -678,7 +680,9 @@ __global__ __launch_bounds__(512, 2) void stage23x_kernel(const Stage23Args a) {
         };
         chain(IC<P>{}, IC<X_ROWB>{}, IC<0>{}, baseB, w3, accA, no_hook, IC<RN_Y_WL>{});           // conv row t-8: B rows t-8 .. t-6
         chain(IC<P>{}, IC<X_ROWB>{}, IC<1>{}, baseB, w3, accB, with_finish(no_hook, IC<PR>{}, accA, hp[0], q0[0], q1[0], op[0], vt), IC<RN_Y_WL>{});
+#ifndef RN_Y_NOWAIT_C       // (timing experiment only: wrong results)
         wait_vmcnt<0>();                                       // a skip row fetched at the top of this step has landed
+#endif
         out_reads(IC<0>{}, R);
         chain(IC<P>{}, IC<X_ROWB>{}, IC<2>{}, baseB, w3, accA, with_finish(hook_c2, IC<PR>{}, accB, hp[1], q0[1], q1[1], op[1], vt), IC<RN_Y_WL>{});
         out_rest(IC<0>{}, R, op[0], op[1], true);

@@ -1013,7 +1013,7 @@ __global__ __launch_bounds__((RwCfg<DT, CIN, COUT, PK, PS, RES, NPT, KS, S0F, WI
                     // ReLU6 -> fp16 pair -> vertical pair sum q_j = v_{j-1} + v_j as one packed fp16 add (the previous
                     // row is kept as fp16 pairs: 8 registers instead of 16)
                     constexpr int i2 = 2 * (k - M_FRONT);
-                    const int vp = static_cast<int>(pack2<RN_DTYPE_F16>(relu6f(acc_old[i2]), relu6f(acc_old[i2 + 1])));
+                    const int vp = static_cast<int>(pack2_relu6_sixth(acc_old[i2], acc_old[i2 + 1]));
                     qp[i2 / 8][(i2 % 8) / 2] = pk_add_f16(hprevp[i2 / 8][(i2 % 8) / 2], vp);
                     hprevp[i2 / 8][(i2 % 8) / 2] = vp;
                 }
