@@ -93,6 +93,9 @@ __global__ __launch_bounds__(512, 2) void stage23x_kernel(const Stage23Args a) {
 #ifndef RN_Y_LATE_TAB      // consumer: BN tables read at the top of out_rest (behind the skip reads, in front of the eight
 #define RN_Y_LATE_TAB 1    // pooling / residual MFMAs) instead of a chain ahead (24 registers less across a chain)
 #endif
+#ifndef RN_Y_WAIT2         // chains: one counted LDS wait per pair of taps instead of one per tap (measured slower: 0.48-0.50 vs 0.475)
+#define RN_Y_WAIT2 0
+#endif
 #ifndef RN_Y_LIMOFF        // consumer: store mask from the store offset instead of the lane's pixel index
 #define RN_Y_LIMOFF 0
 #endif
@@ -174,8 +177,18 @@ __global__ __launch_bounds__(512, 2) void stage23x_kernel(const Stage23Args a) {
         [&]<int... I>(std::integer_sequence<int, I...>) {
             (([&] {
                  if constexpr (I + AHEAD < X_KT) fq[I + AHEAD] = rd(IC<(I + AHEAD < X_KT ? I + AHEAD : 0)>{}, I == 0 ? 0.f : acc[0][0]);
+#if RN_Y_WAIT2
+                 // one counted wait per PAIR of taps (even taps): it retires this tap's operand and the next one's, so the odd
+                 // taps need none -- a wave next to a busy matrix pipe issues ~one instruction per 10 cycles whatever its kind
+                 if constexpr ((I & 1) == 0) {
+                     constexpr int after = X_KT - 2 - I;                                 // reads issued behind tap I + 1's
+                     constexpr int newer2 = after < 0 ? 0 : (after < AHEAD - 1 ? after : AHEAD - 1);
+                     asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(fq[I]), "+v"(fq[I + 1 < X_KT ? I + 1 : I]) : "n"(newer2));
+                 }
+#else
                  constexpr int newer = (X_KT - 1 - I) < AHEAD ? (X_KT - 1 - I) : AHEAD;
                  asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(fq[I]) : "n"(newer));
+#endif
                  acc[0] = mfma16<DT>(fq[I], wr[2 * I], I == 0 ? zero4 : acc[0]);          // D'[pixel][cout], couts of half 0
                  if constexpr (WL && I == X_KT - 1) {
                      asm volatile("" : "+v"(wl));
