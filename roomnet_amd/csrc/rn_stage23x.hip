@@ -295,7 +295,11 @@ __global__ __launch_bounds__(512, 2) void stage23x_kernel(const Stage23Args a) {
 #if defined(RN_X_PRIO) && RN_X_PRIO == 2
         __builtin_amdgcn_s_setprio(1);
 #endif
+#ifdef RN_Y_P3ONLY      // (timing experiment: wrong results)
+        const bool has4 = false;
+#else
         const bool has4 = wq < 2;                                   // tiles of this wave: 4 4 3 3
+#endif
         const int xw = xp_start(wq);
         i32x4 w2[2 * X_KT];
 #pragma unroll
@@ -478,7 +482,11 @@ __global__ __launch_bounds__(512, 2) void stage23x_kernel(const Stage23Args a) {
 #if RN_X_PRIO == 1
     __builtin_amdgcn_s_setprio(1);
 #endif
+#ifdef RN_Y_C3ONLY      // (timing experiment: wrong results)
+    const bool has4 = false;
+#else
     const bool has4 = wq >= 2;                                      // tiles of this wave: 3 3 4 4
+#endif
     const int xw = xc_start(wq);
     const int xend = wq == 3 ? Wo : min(xc_start(wq + 1), Wo);      // this wave stores output columns [xw, xend)
     i32x4 w3[2 * X_KT];
