@@ -233,6 +233,9 @@ def main():
                     help="untimed passes BEFORE the W warm-up steps (~0.3 s at batch 256, 224 x 224): the engine clock needs tens of ms "
                          "of load to leave its idle state, and W = 5 steps are 7 ms.  A fixed count, the same on every rank (a step "
                          "holds a collective when N > 1).  Reported as `spinup_steps`; 0 = none")
+    ap.add_argument("--no-cold-pass", dest="cold_pass", action="store_false",
+                    help="skip the cold / contract pass (W warm-up + K timed steps on one handle, no spin-up) that is timed BEFORE the "
+                         "spin-up and reported as `cold_images_per_sec`")
     ap.add_argument("--stage-launches", action="store_true",
                     help="one launch per conv stage (RN_FLAG_STAGE_LAUNCHES): the unfused comparison arm")
     ap.add_argument("--stub-engine", action="store_true", help=argparse.SUPPRESS)    # CPU tensors + gloo (tests)
@@ -339,8 +342,10 @@ def main():
                 works[k].wait()
                 works[k] = None
 
-    def step():
-        k = n_steps_done[0] & 1
+    def step(serial=False):
+        """One complete pass over the resident batch (+ the all-gather when N > 1).  Returns the slot (handle, stream,
+        result buffer) it ran on.  `serial`: always slot 0 -- one handle, strictly serial steps (the cold / contract pass)."""
+        k = 0 if serial else n_steps_done[0] & 1
         n_steps_done[0] += 1
         with (torch.cuda.stream(streams[k]) if streams[k] is not None else contextlib.nullcontext()):
             if multi and works[k] is not None:
@@ -348,6 +353,7 @@ def main():
             forward(k)
             if multi:
                 works[k] = dist.all_gather_into_tensor(g_bufs[k], bufs[k][0], async_op=True)
+        return k
 
     def on_stream():
         return torch.cuda.stream(stream) if stream is not None else contextlib.nullcontext()
@@ -378,6 +384,30 @@ def main():
             check_parity(fwd_host2, args.side, args.dtype, B)
 
     sync()
+    # ---- cold / contract pass: exactly what the command line says and nothing else -- W warm-up steps, K timed steps, ONE
+    # handle, strictly serial, no spin-up, on a chip that idled through the parity check.  Reported as `cold_images_per_sec`
+    # next to `value` (which follows the spin-up and alternates two handles; both are complete passes).
+    cold_elapsed = None
+    if args.cold_pass:
+        with on_stream():
+            for _ in range(args.warmup):
+                step(serial=True)
+            sync()
+            if multi:
+                dist.barrier()
+            sync()
+            tc = time.perf_counter()
+            for _ in range(args.steps):
+                step(serial=True)
+            sync()
+            if multi:
+                dist.barrier()
+            sync()
+            cold_elapsed = time.perf_counter() - tc
+        if multi:
+            tcold = torch.tensor([cold_elapsed], dtype=torch.float64, device=dev)
+            dist.all_reduce(tcold, op=dist.ReduceOp.MAX)
+            cold_elapsed = float(tcold.item())
     spinup_steps = 0
     with on_stream():
         if args.spinup_steps > 0 and not stub:
@@ -449,10 +479,15 @@ def main():
         with on_stream():
             evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
                    for _ in range(max(3, args.event_steps))]
+            # each pair brackets ONE step on the stream that step runs on (two handles: the slots alternate and nothing orders
+            # streams[1] against streams[0], so a pair on the wrong stream would bracket none of the step's kernels); a step
+            # waits in its stream for the previous step of the SAME slot only, so with two handles a pair still sees its own
+            # launches plus whatever of the other slot's step overlaps them
             for a_ev, b_ev in evs:
-                a_ev.record(stream)
-                step()
-                b_ev.record(stream)
+                k = n_steps_done[0] & 1 if len(engs) == 2 else 0
+                a_ev.record(streams[k])
+                step(serial=len(engs) == 1)
+                b_ev.record(streams[k])
             sync()
         event_ms = [a_ev.elapsed_time(b_ev) for a_ev, b_ev in evs]
         if args.pcie and world == 1:
@@ -497,6 +532,11 @@ def main():
                        "parallelism": "dp%d" % world},
             "parity": parity, "spinup_steps": spinup_steps, "handles": len(engs),
         }
+        if cold_elapsed is not None:
+            out["cold_images_per_sec"] = world * B * args.steps / cold_elapsed
+            out["cold"] = {"ms_per_step": cold_elapsed / args.steps * 1e3, "steps": args.steps, "warmup": args.warmup, "handles": 1,
+                           "spinup_steps": 0, "what": "the same W + K steps timed BEFORE the spin-up on one handle, strictly serial: "
+                                                     "the figure of a strict reading of the command line"}
         if not stub:
             dom = int(np.argmax(group_ms))
             dom_stages = groups[dom]

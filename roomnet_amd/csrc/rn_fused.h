@@ -37,6 +37,7 @@ struct RwPlan {
 bool rn_rw_supported(int cin, int cout, int pool_k, int pool_s, bool res, int out_side, int skip_side,
                      RwPlan* plan);
 int rn_rw_launch(const RwPlan& p, int dtype, hipStream_t s, const rnk::StageArgs& a, dim3 grid);
+int rn_rw_s0sh_colblocks(int out_side);      // column blocks (227 wide) of the shared-ring stage 0 + 1 kernel
 
 // ---- cross-stage fused pair: conv-pool-BN -> conv-pool-BN + residual of a depth-3 block (rn_stage23.hip)
 bool rn_stage23_supported(int in_side);
@@ -56,16 +57,19 @@ bool rn_stage23_plan(int in_side, int* n_cblocks, int* x0, int* wo);   // column
 int rn_stage23_launch(int dtype, hipStream_t s, const rnk::Stage23Args& a, int n);
 // the un-pooled 64 -> 128 stage with row-register blocking (rn_stage6x.hip)
 bool rn_stage6x_supported(int cin, int cout, int pool_k, bool res, int in_side);
+bool rn_stage6x_plan(int out_side, int* n_cb, int* xo0, int* wo);       // column blocks (xo0, wo: 4 entries)
 void rn_stage6x_pack(const float* w_hwio, int dtype, unsigned short (*cvt_bf16)(float), unsigned short (*cvt_f16)(float),
                      std::vector<unsigned short>* out);
 int rn_stage6x_launch(int dtype, hipStream_t s, const rnk::StageArgs& a, int n);
 // the 32 -> 64 stage with pool 4/2 on 16x16x32 tiles with row-register blocking (rn_stage4x.hip)
 bool rn_stage4x_supported(int cin, int cout, int pool_k, int pool_s, bool res, int in_side);
+bool rn_stage4x_plan(int out_side, int* n_cb, int* xo0, int* wo);
 void rn_stage4x_pack(const float* w_hwio, int dtype, unsigned short (*cvt_bf16)(float), unsigned short (*cvt_f16)(float),
                      std::vector<unsigned short>* out);
 int rn_stage4x_launch(int dtype, hipStream_t s, const rnk::StageArgs& a, int n);
 // the 64 -> 64 residual stage with pool 4/2 on 16x16x32 tiles with row-register blocking (rn_stage5x.hip)
 bool rn_stage5x_supported(int cin, int cout, int pool_k, int pool_s, bool res, int in_side, int skip_side);
+bool rn_stage5x_plan(int out_side, int* n_cb, int* xo0, int* wo);
 void rn_stage5x_pack(const float* w_hwio, int dtype, unsigned short (*cvt_bf16)(float), unsigned short (*cvt_f16)(float),
                      std::vector<unsigned short>* out);
 int rn_stage5x_launch(int dtype, hipStream_t s, const rnk::StageArgs& a, int n);

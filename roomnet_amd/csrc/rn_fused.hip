@@ -1167,16 +1167,37 @@ int rn_fused_forward(rn_handle* h, const uint8_t* d_bgr, const float* d_rgb, int
         if (f.use_s5x || f.use_s4x || f.use_s6x) {
             a.wfrag = f.wfrag16;
             a.ptab = f.ptab;
-            // one workgroup (8 waves, 127 KB of LDS) per CU: one band per image once the batch fills the chip
+            const bool planned = f.use_s5x   ? rn_stage5x_plan(s.out_side, &a.n_cb, a.cb_xo0, a.cb_wo)
+                                 : f.use_s4x ? rn_stage4x_plan(s.out_side, &a.n_cb, a.cb_xo0, a.cb_wo)
+                                             : rn_stage6x_plan(s.out_side, &a.n_cb, a.cb_xo0, a.cb_wo);
+            if (!planned) {
+                rn_set_error("stage %zu: no column-block plan for output side %d", i, s.out_side);
+                return RN_E_STATE;
+            }
+            // one workgroup (8 waves) per CU, workgroup = image x column block x band of rows: whole rounds of the chip.  A
+            // band costs its input rows plus the rows its neighbour reads again (6 of the pooled stages, 2 of the un-pooled
+            // one); small batches take as many bands as it needs to fill the chip.
+            const long per_band = static_cast<long>(n) * a.n_cb;
+            const int rows_in = s.pool_k ? 2 : 1, overlap = s.pool_k ? 6 : 2;
+            const int max_bands = std::max(1, s.out_side / 4);
             int bands = 1;
-            if (n < h->n_cu) bands = std::min((h->n_cu + n - 1) / n, std::max(1, s.out_side / 4));
+            long best_cost = -1;
+            for (int b = 1; b <= 8 && b <= max_bands; ++b) {
+                const long rounds = (per_band * b + h->n_cu - 1) / h->n_cu;
+                const long cost = rounds * (rows_in * ((s.out_side + b - 1) / b) + overlap);
+                if (best_cost < 0 || cost < best_cost) {
+                    best_cost = cost;
+                    bands = b;
+                }
+            }
+            if (per_band * bands < h->n_cu) bands = static_cast<int>(std::min<long>((h->n_cu + per_band - 1) / per_band, max_bands));
             a.rows_per_band = (s.out_side + bands - 1) / bands;
             a.n_bands = (s.out_side + a.rows_per_band - 1) / a.rows_per_band;
 #ifdef RN_CLOCK
             {
                 char what[32];
                 snprintf(what, sizeof what, "stage %d", static_cast<int>(i));
-                a.stamp_buf = rn_clock_region(what, static_cast<size_t>(a.n_bands) * n);
+                a.stamp_buf = rn_clock_region(what, static_cast<size_t>(a.n_bands) * a.n_cb * n);
             }
 #endif
             int rc = f.use_s5x   ? rn_stage5x_launch(h->dtype, h->stream, a, n)
@@ -1220,6 +1241,12 @@ int rn_fused_forward(rn_handle* h, const uint8_t* d_bgr, const float* d_rgb, int
             continue;
         }
         if (f.use_rw) {
+            // `sixth` weights (/ 6, BN scale x 6) are only right for kernels that clamp to [0, 1]: the pool 4/1 variants of the
+            // register-weights kernel and rn_stage4x / 5x (handled above).  Its stride-2 (DPP) variants clamp at 6.
+            if (f.sixth && !(s.pool_k == 4 && s.pool_s == 1)) {
+                rn_set_error("16-bit path: stage %zu has weights / 6 but would run a kernel that applies ReLU6 at 6", i);
+                return RN_E_STATE;
+            }
 #ifdef RN_DIAG
             if (const char* dbg = getenv("RN_DEBUG_FLAGS")) a.dbg_flags = atoi(dbg);   // diagnostic builds only
 #endif
@@ -1233,6 +1260,9 @@ int rn_fused_forward(rn_handle* h, const uint8_t* d_bgr, const float* d_rgb, int
             a.ptab = f.ptab;
             a.skipcols = f.rw.skipcols;
             a.n_colblocks = f.rw.n_colblocks;
+            // the shared-ring form of the fused stages 0 + 1 cuts rows into 227-column blocks (eight 29-column tiles minus the
+            // 5 halo columns of the last one)
+            if (a.s0_bgr && !a.s0_private && f.rw.variant == 0 && f.rw.npt == 8) a.n_colblocks = rn_rw_s0sh_colblocks(s.out_side);
             a.npt = f.rw.npt;
             a.n_ctg = 1;
             // Workgroups per CU: one (8-wave variants; checked with HW_ID stamps) or four (the 2-wave workgroups of the
@@ -1240,7 +1270,7 @@ int rn_fused_forward(rn_handle* h, const uint8_t* d_bgr, const float* d_rgb, int
             // gives the least time.  One workgroup per CU runs in whole rounds of the chip: 1 band at batch 256 x 224^2,
             // 2 when e.g. 64 x 600^2 images x 6 column blocks = 384 workgroups would otherwise run 1.5 rounds.  Small
             // workgroups are back-filled as slots free up, so their cost is the fractional number of rounds (>= 1).
-            const int per_band = n * f.rw.n_colblocks;
+            const int per_band = n * a.n_colblocks;
             const long slots = static_cast<long>(h->n_cu) * f.rw.wgs_per_cu;
             const int max_bands = (s.out_side + 7) / 8;
             int bands = 1;

@@ -25,6 +25,7 @@
 #include <cstring>
 #include <mutex>
 #include <new>
+#include <exception>
 #include <thread>
 
 namespace {
@@ -304,11 +305,19 @@ extern "C" int rn_group_forward_u8(rn_group* g, const uint8_t* bgr_nhwc, int n, 
         if (cnt == 0) continue;
         const uint8_t* src = bgr_nhwc + static_cast<size_t>(lo) * img_bytes;
         const size_t bytes = static_cast<size_t>(cnt) * img_bytes;
-        uploads.emplace_back([g, d, src, bytes, &up_rc] {
-            hipError_t e = hipSetDevice(g->devices[d]);
-            if (e == hipSuccess) e = hipMemcpyAsync(g->d_in[d], src, bytes, hipMemcpyHostToDevice, g->handles[d]->stream);
-            up_rc[d] = e;
-        });
+        // (no C++ exception may cross the C ABI, and a joinable std::thread must not be destroyed: if a thread cannot be
+        //  started, the ones that were are joined and the call fails with a status)
+        try {
+            uploads.emplace_back([g, d, src, bytes, &up_rc] {
+                hipError_t e = hipSetDevice(g->devices[d]);
+                if (e == hipSuccess) e = hipMemcpyAsync(g->d_in[d], src, bytes, hipMemcpyHostToDevice, g->handles[d]->stream);
+                up_rc[d] = e;
+            });
+        } catch (const std::exception& ex) {
+            for (auto& t : uploads) t.join();
+            rn_set_error("rn_group_forward_u8: cannot start the upload thread of device %d: %s", g->devices[d], ex.what());
+            return RN_E_STATE;
+        }
     }
     for (auto& t : uploads) t.join();
     for (int d = 0; d < g->ndev; ++d)

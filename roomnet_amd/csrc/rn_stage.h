@@ -228,7 +228,28 @@ struct StageArgs {
     const float* s0_ptab;         // [2][8] stage-0 folded BN: scale (inv / 9), shift
     int s0_S;                     // image side
     int s0_private;               // stage-0 fusion: keep the wave-private rings (round-2 form; A/B arm)
+    // column blocks of the row-blocked kernels (rn_stage4x / 5x / 6x): workgroup = image x band x block; block b owns output
+    // columns [cb_xo0[b], cb_xo0[b] + cb_wo[b]) and reads the input columns under them (+ halo).  n_cb == 1: whole rows.
+    int n_cb;
+    int cb_xo0[4], cb_wo[4];
 };
+
+// Column-block plan of a row-blocked kernel: the fewest blocks (<= 4) of equal width +-1 whose widths lie in [wo_min, wo_max].
+inline bool rn_colblock_plan(int out_side, int wo_min, int wo_max, int* n_cb, int* xo0, int* wo) {
+    for (int nb = 1; nb <= 4; ++nb) {
+        const int hi = (out_side + nb - 1) / nb, lo = out_side / nb;
+        if (hi > wo_max || lo < wo_min) continue;
+        int x = 0;
+        for (int b = 0; b < nb; ++b) {
+            wo[b] = lo + (b < out_side % nb ? 1 : 0);
+            xo0[b] = x;
+            x += wo[b];
+        }
+        *n_cb = nb;
+        return true;
+    }
+    return false;
+}
 
 // launch arguments of the cross-stage fused kernel (rn_stage23.hip): the last two steps of a depth-3 conv_block
 struct Stage23Args {

@@ -49,8 +49,7 @@ constexpr int X_NTAB = 5 * 32;                   // folded BN tables: sc2, sh2 |
 constexpr int X_RINGA_OFF = 1024;
 constexpr int X_RINGB_OFF = X_RINGA_OFF + X_NA * X_ROWA;
 constexpr int X_SKIP_OFF = X_RINGB_OFF + X_NB * X_ROWB;
-constexpr int X_WL_OFF = X_SKIP_OFF + 4 * X_NSK * X_SKROW;   // (experiment RN_Y_WL: two of the consumers' weight fragments, 2 x 1 KB)
-constexpr int X_LDS = X_WL_OFF + 2048;
+constexpr int X_LDS = X_SKIP_OFF + 4 * X_NSK * X_SKROW;
 constexpr int X_LAG = 11;                        // step t finishes output row t - X_LAG
 constexpr int X_KT = 9;                          // taps = K chunks of 32 (all channels of one tap)
 static_assert(X_LDS <= 160 * 1024, "LDS budget");
@@ -80,26 +79,10 @@ __device__ __forceinline__ f32x4 mfma16(i32x4 a, i32x4 b, f32x4 c) {
 
 template <int DT>
 __global__ __launch_bounds__(512, 2) void stage23x_kernel(const Stage23Args a) {
-// Register-pressure experiments (tools/build_variant.sh; one gpurun session, batch 256, stage-pair ms; NOTES.md): the kernel sits
-// at 256 VGPRs with two spilled dwords reloaded inside the consumer's loop (base 0.480-0.493).  WL + LATE_TAB (+ LIMOFF) compile
-// without any scratch access and are no faster (0.482-0.501): the reloads are not what bounds the kernel.  LATE_TAB alone
-// measured 0.472-0.475 and is the default.
-#ifndef RN_Y_AHEAD         // operand reads in flight ahead of their MFMA pair
-#define RN_Y_AHEAD 3
-#endif
-#ifndef RN_Y_WL            // consumer: two weight fragments read from LDS inside the chain instead of held in registers
-#define RN_Y_WL 0
-#endif
-#ifndef RN_Y_LATE_TAB      // consumer: BN tables read at the top of out_rest (behind the skip reads, in front of the eight
-#define RN_Y_LATE_TAB 1    // pooling / residual MFMAs) instead of a chain ahead (24 registers less across a chain)
-#endif
-#ifndef RN_Y_WAIT2         // chains: one counted LDS wait per pair of taps instead of one per tap (measured slower: 0.48-0.50 vs 0.475)
-#define RN_Y_WAIT2 0
-#endif
-#ifndef RN_Y_LIMOFF        // consumer: store mask from the store offset instead of the lane's pixel index
-#define RN_Y_LIMOFF 0
-#endif
-    constexpr int AHEAD = RN_Y_AHEAD;
+// Registers: the kernel sits at 256 VGPRs with six spilled dwords, two of them reloaded inside the consumer's loop.  A build that
+// keeps four of the consumers' weight fragments in LDS instead has no scratch access at all and is 3 % SLOWER (0.490 against
+// 0.475 ms, one session, round 4; two fragments: equal); the reloads are not what bounds the kernel (NOTES.md).
+    constexpr int AHEAD = 3;                              // operand reads in flight ahead of their MFMA pair
     extern __shared__ __attribute__((aligned(64))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -150,21 +133,8 @@ __global__ __launch_bounds__(512, 2) void stage23x_kernel(const Stage23Args a) {
     // two interleaved accumulation chains (the tile's two 16-cout halves) over the nine taps; the tap's operand is ONE
     // ds_read_b128 (16 pixels x 32 channels), issued AHEAD taps early and retired by a counted wait
     // `hook(IC<tap>)` runs behind the tap's MFMA pair: DMA issue and scalar bookkeeping ride in the MFMAs' shadow
-    unsigned wl_lds = 0;
-    auto chain = [&](auto S0C, auto ROWC, auto KC, const unsigned (&base)[3], const i32x4 (&wr)[2 * X_KT], f32x4 (&acc)[2], auto&& hook,
-                     auto WLC) __attribute__((always_inline)) {
+    auto chain = [&](auto S0C, auto ROWC, auto KC, const unsigned (&base)[3], const i32x4 (&wr)[2 * X_KT], f32x4 (&acc)[2], auto&& hook) __attribute__((always_inline)) {
         constexpr int S0 = decltype(S0C)::value, ROW = decltype(ROWC)::value, k = decltype(KC)::value;
-        constexpr bool WL = decltype(WLC)::value != 0;
-        i32x4 wl, wl2;
-#if defined(RN_X_PRIO) && RN_X_PRIO == 3
-        __builtin_amdgcn_s_setprio(1);
-#endif
-#ifdef RN_X_NOCHAIN      // (timing experiments only, tools/build_variant.sh: wrong results)
-        acc[0] = acc[1] = zero4;
-        asm volatile("" : "+v"(acc[0]), "+v"(acc[1]));
-        [&]<int... I>(std::integer_sequence<int, I...>) { (hook(IC<I>{}), ...); }(std::make_integer_sequence<int, X_KT>{});
-        return;
-#endif
         i32x4 fq[X_KT];
         auto rd = [&](auto TC, float dep) __attribute__((always_inline)) -> i32x4 {
             constexpr int tap = decltype(TC)::value, ky = tap / 3, kx = tap % 3;
@@ -177,43 +147,16 @@ __global__ __launch_bounds__(512, 2) void stage23x_kernel(const Stage23Args a) {
         [&]<int... I>(std::integer_sequence<int, I...>) {
             (([&] {
                  if constexpr (I + AHEAD < X_KT) fq[I + AHEAD] = rd(IC<(I + AHEAD < X_KT ? I + AHEAD : 0)>{}, I == 0 ? 0.f : acc[0][0]);
-#if RN_Y_WAIT2
-                 // one counted wait per PAIR of taps (even taps): it retires this tap's operand and the next one's, so the odd
-                 // taps need none -- a wave next to a busy matrix pipe issues ~one instruction per 10 cycles whatever its kind
-                 if constexpr ((I & 1) == 0) {
-                     constexpr int after = X_KT - 2 - I;                                 // reads issued behind tap I + 1's
-                     constexpr int newer2 = after < 0 ? 0 : (after < AHEAD - 1 ? after : AHEAD - 1);
-                     asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(fq[I]), "+v"(fq[I + 1 < X_KT ? I + 1 : I]) : "n"(newer2));
-                 }
-#else
+                 // one counted wait per tap (one per PAIR of taps measured slower, 0.48-0.50 against 0.475 ms: a wait that
+                 // stalls costs more than its issue slot)
                  constexpr int newer = (X_KT - 1 - I) < AHEAD ? (X_KT - 1 - I) : AHEAD;
                  asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(fq[I]) : "n"(newer));
-#endif
                  acc[0] = mfma16<DT>(fq[I], wr[2 * I], I == 0 ? zero4 : acc[0]);          // D'[pixel][cout], couts of half 0
-                 if constexpr (WL && I == X_KT - 1) {
-                     asm volatile("" : "+v"(wl));
-                     acc[1] = mfma16<DT>(fq[I], wl, acc[1]);
-                 } else if constexpr (WL && I == X_KT - 2) {
-                     asm volatile("" : "+v"(wl2));
-                     acc[1] = mfma16<DT>(fq[I], wl2, acc[1]);
-                 } else {
-                     acc[1] = mfma16<DT>(fq[I], wr[2 * I + 1], I == 0 ? zero4 : acc[1]);
-                 }
-                 if constexpr (WL && I == X_KT - 4) {
-                     auto& wlr = wl;
-                     asm volatile("ds_read_b128 %0, %1 offset:1024" : "=v"(wlr) : "v"(wl_lds));
-                 }
-                 if constexpr (WL && I == X_KT - 6) {
-                     auto& wlr = wl2;
-                     asm volatile("ds_read_b128 %0, %1" : "=v"(wlr) : "v"(wl_lds));
-                 }
+                 acc[1] = mfma16<DT>(fq[I], wr[2 * I + 1], I == 0 ? zero4 : acc[1]);
                  hook(IC<I>{});
              }()),
              ...);
         }(std::make_integer_sequence<int, X_KT>{});
-#if defined(RN_X_PRIO) && RN_X_PRIO == 3
-        __builtin_amdgcn_s_setprio(0);
-#endif
     };
     // ReLU6 -> fp16 pairs -> vertical pair sums; the pooling operand of the tile half = [pair sums two rows back | current]
     // Cut into six slices (per 16-cout half: pack rows 0-1, pack rows 2-3, pair sums + operand), so that the slices of tile k
@@ -292,14 +235,7 @@ __global__ __launch_bounds__(512, 2) void stage23x_kernel(const Stage23Args a) {
 
     if (wave < 4) {
         // =============================================================== producer: first stage, A ring -> B ring
-#if defined(RN_X_PRIO) && RN_X_PRIO == 2
-        __builtin_amdgcn_s_setprio(1);
-#endif
-#ifdef RN_Y_P3ONLY      // (timing experiment: wrong results)
-        const bool has4 = false;
-#else
         const bool has4 = wq < 2;                                   // tiles of this wave: 4 4 3 3
-#endif
         const int xw = xp_start(wq);
         i32x4 w2[2 * X_KT];
 #pragma unroll
@@ -373,10 +309,6 @@ __global__ __launch_bounds__(512, 2) void stage23x_kernel(const Stage23Args a) {
 
         auto out = [&](auto KC, auto PC, const i32x4 (&opk)[2], const i32x4 (&opn)[2], bool cross) __attribute__((always_inline)) {
             constexpr int k = decltype(KC)::value, P = decltype(PC)::value;
-#ifdef RN_X_NOOUT_P
-            asm volatile("" ::"v"(opk[0]), "v"(opk[1]), "v"(opn[0]), "v"(opn[1]));
-            return;
-#endif
             constexpr int off = ((P + 3) % X_NB) * X_ROWB;       // B row t-5
             f32x4 H[2];
 #pragma unroll
@@ -439,12 +371,12 @@ __global__ __launch_bounds__(512, 2) void stage23x_kernel(const Stage23Args a) {
             int vt[2][2];
             i32x4 op[4][2];
             op[3][0] = op[3][1] = i32x4{0, 0, 0, 0};
-            chain(IC<(P + 2) % 4>{}, IC<X_ROWA>{}, IC<0>{}, baseA, w2, accA, hook0, IC<0>{});      // conv row t-2: A rows t-2 .. t
-            chain(IC<(P + 2) % 4>{}, IC<X_ROWA>{}, IC<1>{}, baseA, w2, accB, with_finish(hook1, IC<PR>{}, accA, hp[0], q0[0], q1[0], op[0], vt), IC<0>{});
-            chain(IC<(P + 2) % 4>{}, IC<X_ROWA>{}, IC<2>{}, baseA, w2, accA, with_finish(hook2, IC<PR>{}, accB, hp[1], q0[1], q1[1], op[1], vt), IC<0>{});
+            chain(IC<(P + 2) % 4>{}, IC<X_ROWA>{}, IC<0>{}, baseA, w2, accA, hook0);      // conv row t-2: A rows t-2 .. t
+            chain(IC<(P + 2) % 4>{}, IC<X_ROWA>{}, IC<1>{}, baseA, w2, accB, with_finish(hook1, IC<PR>{}, accA, hp[0], q0[0], q1[0], op[0], vt));
+            chain(IC<(P + 2) % 4>{}, IC<X_ROWA>{}, IC<2>{}, baseA, w2, accA, with_finish(hook2, IC<PR>{}, accB, hp[1], q0[1], q1[1], op[1], vt));
             out(IC<0>{}, PC, op[0], op[1], true);
             if (has4) {
-                chain(IC<(P + 2) % 4>{}, IC<X_ROWA>{}, IC<3>{}, baseA, w2, accB, with_finish(no_hook, IC<PR>{}, accA, hp[2], q0[2], q1[2], op[2], vt), IC<0>{});
+                chain(IC<(P + 2) % 4>{}, IC<X_ROWA>{}, IC<3>{}, baseA, w2, accB, with_finish(no_hook, IC<PR>{}, accA, hp[2], q0[2], q1[2], op[2], vt));
                 out(IC<1>{}, PC, op[1], op[2], true);
                 finish(IC<PR>{}, accB, hp[3], q0[3], q1[3], op[3]);
                 out(IC<2>{}, PC, op[2], op[3], true);
@@ -454,9 +386,7 @@ __global__ __launch_bounds__(512, 2) void stage23x_kernel(const Stage23Args a) {
                 out(IC<1>{}, PC, op[1], op[2], true);
                 out(IC<2>{}, PC, op[2], op[3], true);         // op[3] = 0, and columns 13..15 of the third tile go to the dummy column
             }
-#ifndef RN_Y_NOWAIT_P       // (timing experiment only: wrong results)
             wait_vmcnt<0>();
-#endif
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             raw_barrier();
         };
@@ -476,17 +406,8 @@ __global__ __launch_bounds__(512, 2) void stage23x_kernel(const Stage23Args a) {
     }
 
     // =================================================================== consumer: second stage, B ring -> HBM
-#ifndef RN_X_PRIO
-#define RN_X_PRIO 1
-#endif
-#if RN_X_PRIO == 1
-    __builtin_amdgcn_s_setprio(1);
-#endif
-#ifdef RN_Y_C3ONLY      // (timing experiment: wrong results)
-    const bool has4 = false;
-#else
+    __builtin_amdgcn_s_setprio(1);                                  // (measured: consumers high 0.51 ms, none 0.55, producers high 0.55)
     const bool has4 = wq >= 2;                                      // tiles of this wave: 3 3 4 4
-#endif
     const int xw = xc_start(wq);
     const int xend = wq == 3 ? Wo : min(xc_start(wq + 1), Wo);      // this wave stores output columns [xw, xend)
     i32x4 w3[2 * X_KT];
@@ -507,7 +428,6 @@ __global__ __launch_bounds__(512, 2) void stage23x_kernel(const Stage23Args a) {
     const int voff0 = ((x0 + xw + px16) * 32 + 8 * g) * 2;
     const int ntile = has4 ? 4 : 3;
     auto lim = [&](int k) __attribute__((always_inline)) { return min(xend - xw - 16 * k, k == ntile - 1 ? 13 : 16); };
-    auto lim_off = [&](int k) __attribute__((always_inline)) { return 64 * (x0 + xw + lim(k)); };      // px16 < lim(k) <=> voff0 < lim_off(k)
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int xo = xw + 16 * k + px16;
@@ -558,13 +478,6 @@ __global__ __launch_bounds__(512, 2) void stage23x_kernel(const Stage23Args a) {
     wait_vmcnt<0>();                                      // the weight fragments have landed
 #pragma unroll
     for (int f = 0; f < 2 * X_KT; ++f) asm volatile("" : "+v"(w3[f]));
-#if RN_Y_WL
-    wl_lds = lds_addr(smem + X_WL_OFF) + static_cast<unsigned>(lane) * 16u;
-    {
-        const i32x4 last = w3[2 * X_KT - 1], last2 = w3[2 * X_KT - 3];
-        asm volatile("ds_write_b128 %0, %1\n\tds_write_b128 %0, %2 offset:1024\n\ts_waitcnt lgkmcnt(0)" ::"v"(wl_lds), "v"(last2), "v"(last) : "memory");
-    }
-#endif
     lds_barrier();
 
     // The LDS reads of a tile's epilogue (8 transposed reads of the skip rows, 6 table reads) are issued in FRONT of the next
@@ -576,9 +489,6 @@ __global__ __launch_bounds__(512, 2) void stage23x_kernel(const Stage23Args a) {
     };
     auto out_reads = [&](auto KC, OutRegs& R) __attribute__((always_inline)) {
         constexpr int k = decltype(KC)::value;
-#ifdef RN_X_NOOUT_C
-        return;
-#endif
         auto& tq = R.tq;
         // residual: R_lo / R_hi [cout][xo] = Skip^T [cout][32 source columns] * Wx on the matrix cores
         const unsigned alo = a_off[k] + cx.sk_lo, ahi = a_off[k] + cx.sk_hi;
@@ -590,32 +500,15 @@ __global__ __launch_bounds__(512, 2) void stage23x_kernel(const Stage23Args a) {
         asm volatile("ds_read_b64_tr_b16 %0, %1 offset:256" : "=v"(tq[1][0][1]) : "v"(ahi));
         asm volatile("ds_read_b64_tr_b16 %0, %1 offset:8" : "=v"(tq[1][1][0]) : "v"(ahi));
         asm volatile("ds_read_b64_tr_b16 %0, %1 offset:264" : "=v"(tq[1][1][1]) : "v"(ahi));
-#if !RN_Y_LATE_TAB
-        {
-            const unsigned ta = tabl_lds;
-            auto& t1 = R.tsc1;
-            auto& t2 = R.tsh1;
-            auto& t3 = R.tsc2;
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(t1[h]) : "v"(ta), "n"(16 * h));
-                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(t2[h]) : "v"(ta), "n"(128 + 16 * h));
-                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(t3[h]) : "v"(ta), "n"(256 + 16 * h));
-            }
-        }
-#endif
     };
     auto out_rest = [&](auto KC, OutRegs& R, const i32x4 (&opk)[2], const i32x4 (&opn)[2], bool cross) __attribute__((always_inline)) {
         constexpr int k = decltype(KC)::value;
-#ifdef RN_X_NOOUT_C
-        asm volatile("" ::"v"(opk[0]), "v"(opk[1]), "v"(opn[0]), "v"(opn[1]));
-        return;
-#endif
         auto& tq = R.tq;
         auto& tsc1 = R.tsc1;
         auto& tsh1 = R.tsh1;
         auto& tsc2 = R.tsc2;
-#if RN_Y_LATE_TAB
+        // BN tables of the lane's 8 couts: read here, behind the skip reads and in front of the eight pooling / residual MFMAs
+        // (a chain earlier they cost 24 registers across the chain)
         {
             const unsigned ta = tabl_lds;
             auto& t1 = R.tsc1;
@@ -628,7 +521,6 @@ __global__ __launch_bounds__(512, 2) void stage23x_kernel(const Stage23Args a) {
                 asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(t3[h]) : "v"(ta), "n"(256 + 16 * h));
             }
         }
-#endif
         f32x4 H[2];
 #pragma unroll
         for (int h = 0; h < 2; ++h) H[h] = mfma16<RN_DTYPE_F16>(opk[h], pm, zero4);
@@ -657,11 +549,7 @@ __global__ __launch_bounds__(512, 2) void stage23x_kernel(const Stage23Args a) {
         const i32x4 d = {static_cast<int>(pack2<DT>(y[0], y[1])), static_cast<int>(pack2<DT>(y[2], y[3])),
                          static_cast<int>(pack2<DT>(y[4], y[5])), static_cast<int>(pack2<DT>(y[6], y[7]))};
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(cx.row), 0, out_row_bytes, 0x00020000);
-#if RN_Y_LIMOFF
-        const int vo = (voff0 < lim_off(k) ? voff0 + 1024 * k : OOB) | cx.emit_mask;
-#else
         const int vo = (px16 < lim(k) ? voff0 + 1024 * k : OOB) | cx.emit_mask;
-#endif
         __builtin_amdgcn_raw_buffer_store_b128(d, rs, vo, 0, 0);
     };
     auto step = [&](auto PC, int t) __attribute__((always_inline)) {
@@ -699,17 +587,15 @@ __global__ __launch_bounds__(512, 2) void stage23x_kernel(const Stage23Args a) {
         auto hook_c2 = [&](auto IC_) __attribute__((always_inline)) {
             if constexpr (decltype(IC_)::value == 7) vl_pre = vlerp_of(yo0 + min(max(jo + 2, 0), nrows - 1));
         };
-        chain(IC<P>{}, IC<X_ROWB>{}, IC<0>{}, baseB, w3, accA, no_hook, IC<RN_Y_WL>{});           // conv row t-8: B rows t-8 .. t-6
-        chain(IC<P>{}, IC<X_ROWB>{}, IC<1>{}, baseB, w3, accB, with_finish(no_hook, IC<PR>{}, accA, hp[0], q0[0], q1[0], op[0], vt), IC<RN_Y_WL>{});
-#ifndef RN_Y_NOWAIT_C       // (timing experiment only: wrong results)
+        chain(IC<P>{}, IC<X_ROWB>{}, IC<0>{}, baseB, w3, accA, no_hook);           // conv row t-8: B rows t-8 .. t-6
+        chain(IC<P>{}, IC<X_ROWB>{}, IC<1>{}, baseB, w3, accB, with_finish(no_hook, IC<PR>{}, accA, hp[0], q0[0], q1[0], op[0], vt));
         wait_vmcnt<0>();                                       // a skip row fetched at the top of this step has landed
-#endif
         out_reads(IC<0>{}, R);
-        chain(IC<P>{}, IC<X_ROWB>{}, IC<2>{}, baseB, w3, accA, with_finish(hook_c2, IC<PR>{}, accB, hp[1], q0[1], q1[1], op[1], vt), IC<RN_Y_WL>{});
+        chain(IC<P>{}, IC<X_ROWB>{}, IC<2>{}, baseB, w3, accA, with_finish(hook_c2, IC<PR>{}, accB, hp[1], q0[1], q1[1], op[1], vt));
         out_rest(IC<0>{}, R, op[0], op[1], true);
         if (has4) {
             out_reads(IC<1>{}, R);
-            chain(IC<P>{}, IC<X_ROWB>{}, IC<3>{}, baseB, w3, accB, with_finish(no_hook, IC<PR>{}, accA, hp[2], q0[2], q1[2], op[2], vt), IC<RN_Y_WL>{});
+            chain(IC<P>{}, IC<X_ROWB>{}, IC<3>{}, baseB, w3, accB, with_finish(no_hook, IC<PR>{}, accA, hp[2], q0[2], q1[2], op[2], vt));
             out_rest(IC<1>{}, R, op[1], op[2], true);
             out_reads(IC<2>{}, R);
             finish(IC<PR>{}, accB, hp[3], q0[3], q1[3], op[3]);

@@ -13,8 +13,9 @@
 // The most matrix-dense launch of the pass held the lowest clock at the board's power cap (1.64 GHz, profiles/r3_clock.txt):
 // the 16x16x32 shape costs less energy per FLOP (profiles/r2_power_cap.txt), and one workgroup per CU x 256 images is one
 // round of the chip (the 2-wave workgroups of the row-streaming kernel ran 3.5 rounds).
-// One workgroup = one image x one band of output rows x the whole row (193 <= W <= 206: the 224 x 224 network; other sizes
-// keep the row-streaming kernel).
+// One workgroup = one image x one band of output rows x one COLUMN BLOCK of 95..101 pooled columns (194..206 input columns:
+// the whole row of the 224 x 224 network, two blocks at 420, three at 600; rn_colblock_plan).  Blocks do not overlap in the
+// output; the 4 halo columns of a block's input are read by both neighbours.
 #include "rn_fused.h"
 #include "rn_stage.h"
 
@@ -62,8 +63,11 @@ __global__ __launch_bounds__(512, 2) void stage4x_kernel(const StageArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int cq = wave & 3, ph = wave >> 2;              // cout quarter / pixel half: waves w and w + 4 share a SIMD (7 + 6 tiles)
     const int px16 = lane & 15, g = lane >> 4;
-    const int band = blockIdx.x, n = blockIdx.y;
-    const int W = a.W, Wo = a.Wo, Ho = a.Ho;
+    const int cb = blockIdx.x % a.n_cb, band = blockIdx.x / a.n_cb, n = blockIdx.y;
+    const int Win = a.W, Wo_full = a.Wo, Ho = a.Ho;
+    const int xo0 = a.cb_xo0[cb], Wo = a.cb_wo[cb];       // this block's pooled columns
+    const int x0 = 2 * xo0;                               // its first input column
+    const int W = min(2 * Wo + 4, Win - x0);              // input columns it reads
     const int yo0 = band * a.rows_per_band;
     const int nrows = min(Ho, yo0 + a.rows_per_band) - yo0;
     const int y0 = 2 * yo0;
@@ -98,8 +102,8 @@ __global__ __launch_bounds__(512, 2) void stage4x_kernel(const StageArgs a) {
 
     // ---- input rows by LDS-DMA: piece 0 = chunks tid (pixels 0..127); piece 1 = the remaining (W - 128) x 4 chunks, dealt
     // ceil(/8) to each wave, lane-masked (every wave keeps at least one active lane for W >= 193)
-    const char* const in_img = reinterpret_cast<const char*>(a.in + static_cast<int64_t>(n) * W * W * 32);
-    const int row_bytes = W * 64;
+    const char* const in_img = reinterpret_cast<const char*>(a.in + static_cast<int64_t>(n) * Win * Win * 32) + x0 * 64;
+    const int row_bytes = Win * 64;
     const unsigned goff0 = static_cast<unsigned>((tid >> 2) * 64 + (((tid & 3) ^ swz4x(tid >> 2)) << 4));
     const int tailn = ((W - 128) * 4 + 7) / 8;
     const int tail_cnt = min(W * 4 - (512 + wave * tailn), tailn);
@@ -155,7 +159,7 @@ __global__ __launch_bounds__(512, 2) void stage4x_kernel(const StageArgs a) {
     for (int u = 0; u < 4; ++u) {
         const int xo = xo_run + 16 * u + px16;
         const bool valid = 16 * u + px16 < nout_run && xo < Wo;
-        voff[u] = valid ? (xo * 64 + 16 * cq + 4 * g) * 2 : OOB;
+        voff[u] = valid ? ((xo0 + xo) * 64 + 16 * cq + 4 * g) * 2 : OOB;
     }
     // folded BN of the lane's 4 couts (16 cq + 4 g + i): y = S * sc + sh
     const f32x4 sc = *reinterpret_cast<const f32x4*>(a.ptab + 16 * cq + 4 * g);
@@ -170,8 +174,8 @@ __global__ __launch_bounds__(512, 2) void stage4x_kernel(const StageArgs a) {
 #pragma unroll
         for (int r3 = 0; r3 < 3; ++r3) acc[r3][k] = zero4;
     }
-    const int out_row_bytes = Wo * 128;
-    const char* const out_img = reinterpret_cast<const char*>(a.out + static_cast<int64_t>(n) * Ho * Wo * 64);
+    const int out_row_bytes = Wo_full * 128;
+    const char* const out_img = reinterpret_cast<const char*>(a.out + static_cast<int64_t>(n) * Ho * Wo_full * 64);
 
 #pragma unroll
     for (int j = 0; j < U_AHEAD; ++j) issue_row(j, j);
@@ -307,8 +311,15 @@ __global__ __launch_bounds__(512, 2) void stage4x_kernel(const StageArgs a) {
 
 }  // namespace
 
+// pooled columns per block: 2 wo + 4 input columns must lie in U_WMIN + 1 .. U_WMAX (the tail DMA piece needs > 192)
+bool rn_stage4x_plan(int out_side, int* n_cb, int* xo0, int* wo) {
+    return rn_colblock_plan(out_side, (U_WMIN + 1 - 4 + 1) / 2, (U_WMAX - 4) / 2, n_cb, xo0, wo);
+}
+
 bool rn_stage4x_supported(int cin, int cout, int pool_k, int pool_s, bool res, int in_side) {
-    return cin == 32 && cout == 64 && pool_k == 4 && pool_s == 2 && !res && in_side >= U_WMIN && in_side <= U_WMAX;
+    int ncb, xo0[4], wo[4];
+    return cin == 32 && cout == 64 && pool_k == 4 && pool_s == 2 && !res && in_side >= U_WMIN &&
+           rn_stage4x_plan((in_side - 6) / 2 + 1, &ncb, xo0, wo);
 }
 
 // B-operand fragments: frag[f = ky * 3 + kx][cout quarter q][lane][j] = W[tap f][channel 8 (lane / 16) + j][cout 16 q + lane % 16]
@@ -334,7 +345,7 @@ int rn_stage4x_launch(int dtype, hipStream_t s, const StageArgs& a, int n) {
             RN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             attr_devices.fetch_or(1ull << (dev & 63), std::memory_order_release);
         }
-        hipLaunchKernelGGL(kern, dim3(a.n_bands, n), dim3(512), U_LDS, s, a);
+        hipLaunchKernelGGL(kern, dim3(a.n_bands * a.n_cb, n), dim3(512), U_LDS, s, a);
         RN_CHECK_LAUNCH();
         return RN_OK;
     };

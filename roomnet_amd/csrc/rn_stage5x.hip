@@ -18,8 +18,9 @@
 //    transposed (ds_read_b64_tr_b16) and interpolated horizontally on the matrix cores (K = 64 source columns per tile pair);
 //    the lerp fraction is quantised like in the fused stage pair (res_quant_lerp) so that its two weights are one exact
 //    16-bit operand.
-// One workgroup = one image x one band of output rows x the whole row (W <= 110: the 224 x 224 network; other sizes keep the
-// row-streaming kernel).
+// One workgroup = one image x one band of output rows x one COLUMN BLOCK of 31..53 pooled columns (66..110 input columns:
+// the whole row of the 224 x 224 network, three blocks at 600; rn_stage5x_plan checks that every block's skip columns lie
+// inside the input columns it stages).
 #include "rn_fused.h"
 #include "rn_stage.h"
 
@@ -68,8 +69,11 @@ __global__ __launch_bounds__(512, 2) void stage5x_kernel(const StageArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int cq = wave & 3, ph = wave >> 2;              // cout quarter / pixel half: waves w and w + 4 share a SIMD (4 + 3 tiles)
     const int px16 = lane & 15, g = lane >> 4;
-    const int band = blockIdx.x, n = blockIdx.y;
-    const int W = a.W, Wo = a.Wo, Ho = a.Ho;
+    const int cb = blockIdx.x % a.n_cb, band = blockIdx.x / a.n_cb, n = blockIdx.y;
+    const int Win = a.W, Wo_full = a.Wo, Ho = a.Ho;
+    const int xo0 = a.cb_xo0[cb], Wo = a.cb_wo[cb];       // this block's pooled columns
+    const int x0 = 2 * xo0;                               // its first input column
+    const int W = min(2 * Wo + 6, Win - x0);              // input columns it stages (conv window + the residual's reach)
     const int yo0 = band * a.rows_per_band;
     const int nrows = min(Ho, yo0 + a.rows_per_band) - yo0;
     const int y0 = 2 * yo0;                               // first input row = first conv row of the band
@@ -107,8 +111,8 @@ __global__ __launch_bounds__(512, 2) void stage5x_kernel(const StageArgs a) {
 
     // ---- input rows by LDS-DMA: two pieces per wave and row (piece 0: chunks tid = pixels 0..63; piece 1: the remaining
     // (W - 64) x 8 chunks, W - 64 per wave, lane-masked)
-    const char* const in_img = reinterpret_cast<const char*>(a.in + static_cast<int64_t>(n) * W * W * 64);
-    const int row_bytes = W * 128;
+    const char* const in_img = reinterpret_cast<const char*>(a.in + static_cast<int64_t>(n) * Win * Win * 64) + x0 * 128;
+    const int row_bytes = Win * 128;
     const unsigned goff0 = static_cast<unsigned>((tid >> 3) * 128 + (((tid & 7) ^ swz8(tid >> 3)) << 4));
     const int tailn = W - 64;
     const unsigned long long tail_mask = tailn >= 64 ? ~0ull : ((1ull << tailn) - 1ull);
@@ -170,13 +174,14 @@ __global__ __launch_bounds__(512, 2) void stage5x_kernel(const StageArgs a) {
         const int q = px16 >> 2, pp = px16 & 3;
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
+            // (the bilinear tables are indexed by full-row output columns and hold full-row source columns: both block-relative here)
             const int xo_first = min(xo_run + 16 * u, Wo - 1);
-            const int xs_u = min(a.rlo[xo_first], W - 64);
+            const int xs_u = min(a.rlo[xo0 + xo_first] - x0, W - 64);
             const int xo = xo_run + 16 * u + px16;
             const bool valid = 16 * u + px16 < nout_run && xo < Wo;
-            voff[u] = valid ? (xo * 64 + 16 * cq + 4 * g) * 2 : OOB;
-            const int xq = min(xo, Wo - 1);
-            const int plo = a.rlo[xq], phi = a.rhi[xq];
+            voff[u] = valid ? ((xo0 + xo) * 64 + 16 * cq + 4 * g) * 2 : OOB;
+            const int xq = xo0 + min(xo, Wo - 1);
+            const int plo = a.rlo[xq] - x0, phi = a.rhi[xq] - x0;
             const float xlq = res_quant_lerp<DT>(a.rlerp[xq]);
 #pragma unroll
             for (int kh = 0; kh < 2; ++kh) {
@@ -215,8 +220,8 @@ __global__ __launch_bounds__(512, 2) void stage5x_kernel(const StageArgs a) {
 #pragma unroll
         for (int r3 = 0; r3 < 3; ++r3) acc[r3][k] = zero4;
     }
-    const int out_row_bytes = Wo * 128;
-    const char* const out_img = reinterpret_cast<const char*>(a.out + static_cast<int64_t>(n) * Ho * Wo * 64);
+    const int out_row_bytes = Wo_full * 128;
+    const char* const out_img = reinterpret_cast<const char*>(a.out + static_cast<int64_t>(n) * Ho * Wo_full * 64);
 
 #pragma unroll
     for (int j = 0; j < V_AHEAD; ++j) issue_row(j, j);
@@ -318,7 +323,7 @@ __global__ __launch_bounds__(512, 2) void stage5x_kernel(const StageArgs a) {
             const int ylo_v = static_cast<int>(src);
             const int ylo = __builtin_amdgcn_readfirstlane(ylo_v);
             const float yl = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(src - static_cast<float>(ylo_v))));
-            const int yhi = min(ylo + 1, W - 1);
+            const int yhi = min(ylo + 1, Win - 1);
             // ring slots of the two source rows (band-relative rows ylo - y0, yhi - y0; row s sits in slot_cur)
             int dlo = s - (ylo - y0), dhi = s - (yhi - y0);            // 0 .. 5 rows behind the newest
             dlo = min(max(dlo, 0), V_NS - 1);
@@ -399,8 +404,18 @@ __global__ __launch_bounds__(512, 2) void stage5x_kernel(const StageArgs a) {
 
 }  // namespace
 
+// pooled columns per block: 2 wo + 4 .. 2 wo + 6 staged input columns must lie in V_WMIN .. V_WMAX.  The residual reaches
+// (in_side - 2 out_side) < 5 columns / rows past the conv window's first column / row: inside the staged columns and the
+// 9-slot ring for every input the network can produce (in_side = 2 out_side + 4 or + 5).
+bool rn_stage5x_plan(int out_side, int* n_cb, int* xo0, int* wo) {
+    return rn_colblock_plan(out_side, (V_WMIN - 4 + 1) / 2, (V_WMAX - 4) / 2, n_cb, xo0, wo);
+}
+
 bool rn_stage5x_supported(int cin, int cout, int pool_k, int pool_s, bool res, int in_side, int skip_side) {
-    return cin == 64 && cout == 64 && pool_k == 4 && pool_s == 2 && res && in_side >= V_WMIN && in_side <= V_WMAX && skip_side == in_side;
+    int ncb, xo0[4], wo[4];
+    const int out_side = (in_side - 6) / 2 + 1;
+    return cin == 64 && cout == 64 && pool_k == 4 && pool_s == 2 && res && in_side >= V_WMIN && skip_side == in_side &&
+           in_side - 2 * out_side <= 5 && rn_stage5x_plan(out_side, &ncb, xo0, wo);
 }
 
 // B-operand fragments: frag[f = (ky * 3 + kx) * 2 + ch][cout quarter q][lane][j] = W[tap ky * 3 + kx][channel 32 ch + 8 (lane / 16) + j][cout 16 q + lane % 16]
@@ -427,7 +442,7 @@ int rn_stage5x_launch(int dtype, hipStream_t s, const StageArgs& a, int n) {
             RN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             attr_devices.fetch_or(1ull << (dev & 63), std::memory_order_release);
         }
-        hipLaunchKernelGGL(kern, dim3(a.n_bands, n), dim3(512), V_LDS, s, a);
+        hipLaunchKernelGGL(kern, dim3(a.n_bands * a.n_cb, n), dim3(512), V_LDS, s, a);
         RN_CHECK_LAUNCH();
         return RN_OK;
     };

@@ -9,7 +9,8 @@
 // input row feeds three MFMAs (kernel rows 0, 1, 2), so a step reads 6 fragments per tile for 18 MFMAs and the ring only
 // holds the newest row and the rows in flight.  Operands are NOT swapped here (D[cout][pixel]: a lane holds 4 consecutive
 // couts of one pixel = one 8-byte store): there is no pooling that would want the pixels in registers.
-// conv16_kernel (rn_conv16.hip) stays for the other sizes (W > 50).
+// Wider rows are cut into COLUMN BLOCKS of 33..48 output columns (rn_colblock_plan: one block at 224, three at 600):
+// workgroup = image x band x block.  conv16_kernel (rn_conv16.hip) stays as the RN_FLAG_PAIR_32X32 arm.
 #include "rn_fused.h"
 #include "rn_stage.h"
 
@@ -52,8 +53,10 @@ __global__ __launch_bounds__(512, 2) void stage6x_kernel(const StageArgs a) {
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // = cout group (16 couts)
     const int px16 = lane & 15, g = lane >> 4;
-    const int band = blockIdx.x, n = blockIdx.y;
-    const int W = a.W, Wo = a.Wo, Ho = a.Ho;
+    const int cb = blockIdx.x % a.n_cb, band = blockIdx.x / a.n_cb, n = blockIdx.y;
+    const int Win = a.W, Wo_full = a.Wo, Ho = a.Ho;
+    const int x0 = a.cb_xo0[cb], Wo = a.cb_wo[cb];        // this block's output columns = its first input column
+    const int W = Wo + 2;                                 // input columns it reads
     const int yo0 = band * a.rows_per_band;
     const int nrows = min(Ho, yo0 + a.rows_per_band) - yo0;
     const int nin = nrows + 2;
@@ -78,8 +81,8 @@ __global__ __launch_bounds__(512, 2) void stage6x_kernel(const StageArgs a) {
     }
 
     // ---- input rows by LDS-DMA: one lane-masked piece per wave and row (W x 8 chunks, W per wave)
-    const char* const in_img = reinterpret_cast<const char*>(a.in + static_cast<int64_t>(n) * W * W * 64);
-    const int row_bytes = W * 128;
+    const char* const in_img = reinterpret_cast<const char*>(a.in + static_cast<int64_t>(n) * Win * Win * 64) + x0 * 128;
+    const int row_bytes = Win * 128;
     const unsigned long long dma_mask = (1ull << W) - 1ull;
     unsigned goff;
     {
@@ -106,7 +109,7 @@ __global__ __launch_bounds__(512, 2) void stage6x_kernel(const StageArgs a) {
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         const int xo = 16 * k + px16;
-        voff[k] = xo < Wo ? (xo * 128 + 16 * wave + 4 * g) * 2 : OOB;
+        voff[k] = xo < Wo ? ((x0 + xo) * 128 + 16 * wave + 4 * g) * 2 : OOB;
     }
     const f32x4 sc = *reinterpret_cast<const f32x4*>(a.ptab + 16 * wave + 4 * g);
     const f32x4 sh = *reinterpret_cast<const f32x4*>(a.ptab + 128 + 16 * wave + 4 * g);
@@ -116,8 +119,8 @@ __global__ __launch_bounds__(512, 2) void stage6x_kernel(const StageArgs a) {
     for (int r3 = 0; r3 < 3; ++r3)
 #pragma unroll
         for (int k = 0; k < 3; ++k) acc[r3][k] = zero4;
-    const int out_row_bytes = Wo * 256;
-    const char* const out_img = reinterpret_cast<const char*>(a.out + static_cast<int64_t>(n) * Ho * Wo * 128);
+    const int out_row_bytes = Wo_full * 256;
+    const char* const out_img = reinterpret_cast<const char*>(a.out + static_cast<int64_t>(n) * Ho * Wo_full * 128);
 
 #pragma unroll
     for (int j = 0; j < S6_AHEAD; ++j) issue_row(j, j);
@@ -219,8 +222,13 @@ __global__ __launch_bounds__(512, 2) void stage6x_kernel(const StageArgs a) {
 
 }  // namespace
 
+bool rn_stage6x_plan(int out_side, int* n_cb, int* xo0, int* wo) {
+    return rn_colblock_plan(out_side, S6_WMIN - 2, S6_WMAX - 2, n_cb, xo0, wo);
+}
+
 bool rn_stage6x_supported(int cin, int cout, int pool_k, bool res, int in_side) {
-    return cin == 64 && cout == 128 && pool_k == 0 && !res && in_side >= S6_WMIN && in_side <= S6_WMAX;
+    int ncb, xo0[4], wo[4];
+    return cin == 64 && cout == 128 && pool_k == 0 && !res && in_side >= S6_WMIN && rn_stage6x_plan(in_side - 2, &ncb, xo0, wo);
 }
 
 // A-operand fragments: frag[f = (ky * 3 + kx) * 2 + ch][cout group q][lane][j] = W[tap][channel 32 ch + 8 (lane / 16) + j][cout 16 q + lane % 16]
@@ -240,7 +248,7 @@ void rn_stage6x_pack(const float* w_hwio, int dtype, unsigned short (*cvt_bf16)(
 
 int rn_stage6x_launch(int dtype, hipStream_t s, const StageArgs& a, int n) {
     auto launch = [&](auto kern) -> int {
-        hipLaunchKernelGGL(kern, dim3(a.n_bands, n), dim3(512), S6_LDS, s, a);
+        hipLaunchKernelGGL(kern, dim3(a.n_bands * a.n_cb, n), dim3(512), S6_LDS, s, a);
         RN_CHECK_LAUNCH();
         return RN_OK;
     };

@@ -57,10 +57,13 @@ struct RwCfg {
     // S0F: stage 0 (uint8 image -> conv 3->8 -> ReLU6 -> pool 3/1 -> BN) is computed by the SAME wave, row by row,
     // straight into its private ring: the 8-channel tensor between stages 0 and 1 never reaches HBM (see s0_feed)
     static constexpr bool S0F = S0F_;
-    // S0SH (with S0F, one column block): the stage-0 rows go to ONE ring shared by the workgroup -- wave w computes the 29
+    // S0SH (with S0F): the stage-0 rows go to ONE ring shared by the workgroup -- wave w computes the 29
     // stage-0 columns [29 w, 29 w + 29) (one 32-column tile instead of two: the second tile of the private form exists
-    // for 5 halo columns only and costs as much as the first) and reads its 34-column window once its neighbours are done
+    // for 5 halo columns only and costs as much as the first) and reads its 34-column window once its neighbours are done.
+    // The eight waves produce 232 stage-0 columns = the windows of 227 output columns: column blocks of this form are 227
+    // wide (the eighth tile stores 24 of its 29 columns), one at 224 x 224, two at 420, three at 600.
     static constexpr bool S0SH = S0SH_ != 0;
+    static constexpr int S0SH_BLKW = 227;
     static_assert(!S0SH || S0F, "shared stage-0 ring is a form of the stage-0 fusion");
     // S0SH_ == 2 (S0HW): NPT / 2 extra "helper" waves compute the stage-0 rows (two 29-column tiles each) and the NPT tile
     // waves run stage 1 only: 12 waves of <= 168 registers = three per SIMD instead of two, and the stage-0 row (a long
@@ -214,7 +217,9 @@ __global__ __launch_bounds__((RwCfg<DT, CIN, COUT, PK, PS, RES, NPT, KS, S0F, WI
     const int yc0 = PK ? yo0 * PS : yo0;
     const int nconv = PK ? (nout_rows - 1) * PS + 4 : nout_rows;
     const int nin = nconv + 2;
-    const int x0c = cb * NPT * TSTRIDE;
+    constexpr int BLKC = C::S0SH ? C::S0SH_BLKW : NPT * TSTRIDE;           // conv columns per column block
+    constexpr int BLKO = C::S0SH ? C::S0SH_BLKW : NPT * NOUT_T;            // output columns per column block
+    const int x0c = cb * BLKC;
     const int xo_blk0 = PK ? x0c / PS : x0c;
 
     // ---- folded BN tables -> LDS
@@ -549,7 +554,7 @@ __global__ __launch_bounds__((RwCfg<DT, CIN, COUT, PK, PS, RES, NPT, KS, S0F, WI
     const int xo = C::DPP2 ? (x0c + pt * TSTRIDE + pm) / PS : (PK ? (x0c + pt * TSTRIDE) / PS : x0c + pt * TSTRIDE) + r;
     // a window of the tile ends up on this lane (gapped / wide tiles: the window that starts at the lane's own, even, column)
     const bool lane_win = C::GAP ? ((r & 1) == 0 && (r & 15) <= 12) : (C::WIDE2 ? ((r & 1) == 0 && r <= 28) : r < NOUT_T);
-    const bool lane_out = lane_win && xo < a.Wo && (xo - xo_blk0) < NPT * NOUT_T;
+    const bool lane_out = lane_win && xo < a.Wo && (xo - xo_blk0) < BLKO;
     const float* const ptab_lane = ptab + ct * 32 + 4 * hh;                                // + 8*g (+ table*COUT)
     f32x4 sc1r[NG], sh1r[NG], sc2r[NG], sh2r[NG];
     if constexpr (C::PTAB_REGS) {
@@ -567,7 +572,7 @@ __global__ __launch_bounds__((RwCfg<DT, CIN, COUT, PK, PS, RES, NPT, KS, S0F, WI
     // staging: this lane's output pixel index inside the tile, number of valid pixels of the tile
     const int pr = r;
     const int xo_t0s = PK ? (x0c + pt * TSTRIDE) / PS : (x0c + pt * TSTRIDE);     // first output column of the tile
-    const int nvalid = max(0, min(NOUT_T, min(a.Wo, xo_blk0 + NPT * NOUT_T) - xo_t0s)); // wave-uniform
+    const int nvalid = max(0, min(NOUT_T, min(a.Wo, xo_blk0 + BLKO) - xo_t0s)); // wave-uniform
     // LDS byte addresses (as 32-bit LDS offsets, used by inline-asm DS ops):
     //   write: after the half-wave swap this lane holds 16-byte chunk (2k + hh) of pixel pr, stored at
     //          pixel*64 + ((chunk ^ swz) << 4); the k = 1 address is the k = 0 address ^ 32
@@ -1370,6 +1375,9 @@ bool rn_rw_supported(int cin, int cout, int pool_k, int pool_s, bool res, int ou
     return rw_plan(cin, cout, pool_k, pool_s, res, out_side, skip_side, false, plan);
 }
 
+// column blocks of the shared-ring form of the fused stages 0 + 1 (variant 0, 8 tiles) for `out_side` output columns
+int rn_rw_s0sh_colblocks(int out_side) { return (out_side + 226) / 227; }
+
 // 1: shared stage-0 ring, every wave computes its own stage-0 tile (0.216-0.22 ms at batch 256).
 // 2: + four stage-0 helper waves (12-wave workgroups, three waves per SIMD): bit-identical, but the stage-1 waves need ~200
 //    registers and get 168 -- 46 spilled -- 0.227-0.234 ms.  Kept as a build switch: the direction needs a stage-1 wave
@@ -1383,8 +1391,8 @@ int rn_rw_launch(const RwPlan& p, int dtype, hipStream_t s, const StageArgs& a, 
             if (a.s0_bgr) return launch_rw_dt<8, 32, 4, 1, false, 4, 1, true>(dtype, s, a, grid);
             return launch_rw_dt<8, 32, 4, 1, false, 4>(dtype, s, a, grid);
         case 0 * 16 + 8:
-            // one column block whose stage-0 columns (outputs + 5) all come from the eight 29-column tiles: shared ring
-            if (a.s0_bgr && a.n_colblocks == 1 && a.Wo + 5 <= 8 * 29 && !a.s0_private)
+            // shared stage-0 ring: column blocks of 227 output columns (the caller sized n_colblocks for that, rn_rw_s0sh_colblocks)
+            if (a.s0_bgr && !a.s0_private)
                 return launch_rw_dt<8, 32, 4, 1, false, 8, 1, true, false, RN_S0_MODE>(dtype, s, a, grid);
             if (a.s0_bgr) return launch_rw_dt<8, 32, 4, 1, false, 8, 1, true>(dtype, s, a, grid);
             return launch_rw_dt<8, 32, 4, 1, false, 8>(dtype, s, a, grid);

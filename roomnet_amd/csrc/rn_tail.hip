@@ -67,6 +67,31 @@ __device__ __forceinline__ void tail_stage(const unsigned short* src, unsigned s
         rx_hi = a.rhi[xq];
         rx_l = a.rlerp[xq];
     }
+    // every table the epilogue needs is fetched HERE, once, in front of the row loop (left at their point of use the loads sat
+    // behind the output stores -- the compiler may not move a load across a store it cannot prove disjoint -- and every
+    // emitted row paid several dependent global round trips: ~1 us each on a kernel that is nothing but latency)
+    f32x4 bn_mean[2], bn_inv[2], bn_beta[2];
+    [[maybe_unused]] f32x4 bn2_mean[2], bn2_inv[2], bn2_beta[2];
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        const int c0 = 4 * hh + 8 * g;
+        bn_mean[g] = *reinterpret_cast<const f32x4*>(st.mean + c0);
+        bn_inv[g] = *reinterpret_cast<const f32x4*>(st.inv + c0);
+        bn_beta[g] = *reinterpret_cast<const f32x4*>(st.beta + c0);
+        if constexpr (RES) {
+            bn2_mean[g] = *reinterpret_cast<const f32x4*>(a.mean2 + c0);
+            bn2_inv[g] = *reinterpret_cast<const f32x4*>(a.inv2 + c0);
+            bn2_beta[g] = *reinterpret_cast<const f32x4*>(a.beta2 + c0);
+        }
+    }
+    // vertical interpolation of the first pooled row; the next row's is fetched right behind each emitted row
+    [[maybe_unused]] float yl_n = 0.f;
+    [[maybe_unused]] int ylo_n = 0, yhi_n = 0;
+    if constexpr (RES) {
+        yl_n = a.rlerp[yo_a];
+        ylo_n = a.rlo[yo_a];
+        yhi_n = a.rhi[yo_a];
+    }
     float vring[RING][16];
 #pragma unroll
     for (int i = 0; i < RING; ++i)
@@ -114,17 +139,19 @@ __device__ __forceinline__ void tail_stage(const unsigned short* src, unsigned s
             const unsigned short* sk0 = nullptr;
             const unsigned short* sk1 = nullptr;
             if constexpr (RES) {
-                yl = a.rlerp[yo];
-                sk0 = skip + a.rlo[yo] * skip_side * 16;
-                sk1 = skip + a.rhi[yo] * skip_side * 16;
+                yl = yl_n;
+                sk0 = skip + ylo_n * skip_side * 16;
+                sk1 = skip + yhi_n * skip_side * 16;
+                const int yn = min(yo + 1, So - 1);
+                yl_n = a.rlerp[yn];
+                ylo_n = a.rlo[yn];
+                yhi_n = a.rhi[yn];
             }
             unsigned short* orow = st.out + ((static_cast<int64_t>(img) * So + yo) * So + xo) * 16;
 #pragma unroll
             for (int g = 0; g < 2; ++g) {
                 const int c0 = 4 * hh + 8 * g;
-                const f32x4 mean = *reinterpret_cast<const f32x4*>(st.mean + c0);
-                const f32x4 inv = *reinterpret_cast<const f32x4*>(st.inv + c0);
-                const f32x4 beta = *reinterpret_cast<const f32x4*>(st.beta + c0);
+                const f32x4 mean = bn_mean[g], inv = bn_inv[g], beta = bn_beta[g];
                 float y[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) y[j] = (tot[4 * g + j] * inv_area - mean[j]) * inv[j] + beta[j];
@@ -134,9 +161,7 @@ __device__ __forceinline__ void tail_stage(const unsigned short* src, unsigned s
                         const f32x4 tr = unpack4<DT>(*reinterpret_cast<const uint2*>(sk0 + rx_hi * 16 + c0));
                         const f32x4 bl = unpack4<DT>(*reinterpret_cast<const uint2*>(sk1 + rx_lo * 16 + c0));
                         const f32x4 br = unpack4<DT>(*reinterpret_cast<const uint2*>(sk1 + rx_hi * 16 + c0));
-                        const f32x4 mean2 = *reinterpret_cast<const f32x4*>(a.mean2 + c0);
-                        const f32x4 inv2 = *reinterpret_cast<const f32x4*>(a.inv2 + c0);
-                        const f32x4 beta2 = *reinterpret_cast<const f32x4*>(a.beta2 + c0);
+                        const f32x4 mean2 = bn2_mean[g], inv2 = bn2_inv[g], beta2 = bn2_beta[g];
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
                             const float top = tl[j] + (tr[j] - tl[j]) * rx_l;
@@ -188,6 +213,15 @@ __global__ __launch_bounds__(256) void tail_kernel(const TailArgs a) {
             }
         }
     }
+    // the dense layers' per-output constants of this thread: fetched now, used after the conv phases
+    float hd_bias[RN_MAX_DENSE], hd_inv[RN_MAX_DENSE], hd_shift[RN_MAX_DENSE];
+#pragma unroll
+    for (int d = 0; d < RN_MAX_DENSE; ++d) {
+        const bool on = d < a.head.n_dense && tid < a.head.nout[d];
+        hd_bias[d] = on && a.head.bias[d] ? a.head.bias[d][tid] : 0.f;
+        hd_inv[d] = on && a.head.inv[d] ? a.head.inv[d][tid] : 0.f;
+        hd_shift[d] = on && a.head.inv[d] ? a.head.shift[d][tid] : 0.f;
+    }
     __syncthreads();
     // ---- second and third step of the block: pooled rows dealt to the four waves
     {
@@ -206,19 +240,21 @@ __global__ __launch_bounds__(256) void tail_kernel(const TailArgs a) {
     for (int i = tid; i < nin0; i += 256) buf0[i] = from16<DT>(xb[i]);
     __syncthreads();
     const float* cur = buf0;
-    for (int d = 0; d < h.n_dense; ++d) {
+#pragma unroll
+    for (int d = 0; d < RN_MAX_DENSE; ++d) {       // (unrolled: the per-layer constants above stay in registers)
+        if (d >= h.n_dense) break;
         const int nin = h.nin[d], nout = h.nout[d];
         float* dst = small[d & 1];
         if (tid < nout) {
             float v = 0.f;
             const float* wd = w_off[d] >= 0 ? wl + w_off[d] : h.w[d];
             for (int k = 0; k < nin; ++k) v = fmaf(cur[k], wd[k * nout + tid], v);
-            if (h.bias[d]) v = __fadd_rn(v, h.bias[d][tid]);
+            if (h.bias[d]) v = __fadd_rn(v, hd_bias[d]);
             if (h.tap_mm[d]) h.tap_mm[d][static_cast<int64_t>(img) * nout + tid] = v;
             v = fminf(fmaxf(v, 0.f), 6.f);
             if (h.tap_relu[d]) h.tap_relu[d][static_cast<int64_t>(img) * nout + tid] = v;
             if (h.inv[d]) {
-                v = __fadd_rn(__fmul_rn(v, h.inv[d][tid]), h.shift[d][tid]);
+                v = __fadd_rn(__fmul_rn(v, hd_inv[d]), hd_shift[d]);
                 if (h.tap_bn[d]) h.tap_bn[d][static_cast<int64_t>(img) * nout + tid] = v;
             }
             dst[tid] = v;

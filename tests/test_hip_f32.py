@@ -28,9 +28,14 @@ def test_library_sees_a_gpu():
 
 
 def test_logits_probs_ids_vs_golden(engine, parity_images, golden_parity):
-    ids, probs = engine.forward_u8(parity_images)           # 40 images, chunks of max_batch
-    logits = engine.tap("d3.relu", 8)                        # last chunk
-    np.testing.assert_allclose(logits, golden_parity["logits_f64"][32:40], atol=TOL_LOGITS, rtol=0)
+    ids, probs, logits = [], [], []
+    for i in range(0, len(parity_images), 8):               # 40 images = five chunks of max_batch; logits tapped after each
+        a, b = engine.forward_u8(parity_images[i:i + 8])
+        ids.append(a)
+        probs.append(b)
+        logits.append(engine.tap("d3.relu", len(a)).copy())
+    ids, probs, logits = np.concatenate(ids), np.concatenate(probs), np.concatenate(logits)
+    np.testing.assert_allclose(logits, golden_parity["logits_f64"], atol=TOL_LOGITS, rtol=0)
     np.testing.assert_allclose(probs, golden_parity["probs_f64"], atol=TOL_PROBS, rtol=0)
     safe = golden_parity["top2_margin"] > MARGIN
     np.testing.assert_array_equal(ids[safe], golden_parity["ids"][safe])

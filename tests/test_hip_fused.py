@@ -88,8 +88,12 @@ def _same_up_to_sum_order(a, b, dtype, what, frac=1e-5, n_ulp=2):
         return
     ulp = 2.0 ** (-8 if dtype == "bf16" else -11)
     scale = float(np.abs(b).max())
-    err = float(np.abs(a.astype(np.float64) - b.astype(np.float64)).max())
-    assert n <= max(2, frac * a.size) and err <= n_ulp * ulp * scale, (what, dtype, n, a.size, err / (ulp * scale), np.argwhere(bad)[:4].tolist())
+    # bounded PER ELEMENT: n_ulp 16-bit ulps of the element itself (values below 1 % of the tensor's abs-max are measured
+    # against that floor: a folded-BN output near zero is a difference of two larger numbers)
+    d = np.abs(a.astype(np.float64) - b.astype(np.float64))
+    lim = n_ulp * ulp * np.maximum(np.abs(b.astype(np.float64)), 0.01 * scale)
+    worst = float((d / lim).max())
+    assert n <= max(2, frac * a.size) and worst <= 1.0, (what, dtype, n, a.size, worst, np.argwhere(bad)[:4].tolist())
 
 
 def _downstream_same(fused, plain, names, nb, dtype, probs_f, probs_p, ids_f, ids_p):
