@@ -225,11 +225,11 @@ def main():
     ap.add_argument("--event-steps", type=int, default=30, help="iterations of the per-step hipEvent timing pass (median reported)")
     ap.add_argument("--pair32", action="store_true", help="fused stage pair on the round-2 32x32x16 kernel (RN_FLAG_PAIR_32X32: comparison arm)")
     ap.add_argument("--no-parity-check", action="store_true", help="skip the golden check (timing experiments with garbage results)")
-    ap.add_argument("--handles", type=int, default=2, choices=(1, 2),
+    ap.add_argument("--handles", type=int, default=1, choices=(1, 2),
                     help="engine handles (each with its own activation tensors and stream) that take the steps in turn: with 2, the "
                          "small launches at the end of step k (stages 6, 7, tail: one latency-bound workgroup per image) overlap the "
                          "first launch of step k + 1.  Every step is still one complete pass over one resident batch")
-    ap.add_argument("--spinup-steps", type=int, default=240,
+    ap.add_argument("--spinup-steps", type=int, default=0,
                     help="untimed passes BEFORE the W warm-up steps (~0.3 s at batch 256, 224 x 224): the engine clock needs tens of ms "
                          "of load to leave its idle state, and W = 5 steps are 7 ms.  A fixed count, the same on every rank (a step "
                          "holds a collective when N > 1).  Reported as `spinup_steps`; 0 = none")
@@ -525,7 +525,7 @@ def main():
             "config": {"workload": "RoomNet forward (reference final_model weights), uint8 BGR %dx%dx3 in HBM -> "
                                    "probs+ids in HBM, batch %d per GPU, %s%s"
                                    % (args.side, args.side, B,
-                                      "float32 per-node correctness path (one launch per graph node; not a throughput path)" if f32
+                                      "float32 storage and arithmetic: conv stages 1-6 one v_mfma_f32_32x32x2_f32 launch each, the rest one launch per graph node" if f32
                                       else "%s storage / fp32 accumulate" % args.dtype,
                                       ", RCCL all-gather of probs+ids" if multi else ""),
                        "images_per_gpu": B, "global_batch": world * B, "im_side": args.side,
@@ -543,13 +543,12 @@ def main():
             dom_bytes = sum(sbytes[k] for k in dom_stages) * B
             dom_s = group_ms[dom] * 1e-3
             if f32:
-                # float32: the matrix-fp32 roofline bounds the path; this handle runs the per-node
-                # correctness kernels, so the figure is reported, not optimised
+                # float32: the matrix-fp32 roofline bounds the path
                 dom_flops = sum(sflops[k] for k in dom_stages) * B
                 out["roofline"] = {"bound": "mfma", "achieved": dom_flops / dom_s / 1e12, "peak": MFMA_PEAK_F32 / 1e12,
                                    "unit": "TFLOP/s", "frac": dom_flops / dom_s / MFMA_PEAK_F32, "traffic": None,
-                                   "kernel": "per-node float32 kernels of stage %d" % dom_stages[0], "kernel_ms": group_ms[dom],
-                                   "note": "correctness path only: one launch per graph node, VALU convolution"}
+                                   "kernel": "stage_f32m_kernel (v_mfma_f32_32x32x2_f32), stage %d" % dom_stages[0], "stages": dom_stages,
+                                   "kernel_ms": group_ms[dom], "algorithmic_flops_per_launch": dom_flops}
             else:
                 achieved = dom_bytes / dom_s
                 s0 = graph.stages[dom_stages[0]]

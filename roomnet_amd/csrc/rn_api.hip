@@ -354,12 +354,20 @@ int run_head(rn_handle* h, int n, float* d_probs, int64_t* d_ids) {
     return rn_launch_head(h->stream, flat.ptr, flat.dtype, n, a, d_probs, d_ids);
 }
 
-// Unfused float32 forward: one launch per graph node.
+// Float32 forward: one launch per graph node; without RN_FLAG_TAPS the conv stages rn_stage_f32m.hip covers run as one
+// matrix-core launch each.
 int forward_unfused(rn_handle* h, const float* d_rgb, int n, float* d_probs, int64_t* d_ids) {
     int rc;
     const float* cur = d_rgb;
     for (size_t i = 0; i < h->stages.size(); ++i) {
         StagePlan& s = h->stages[i];
+        if (rn_f32m_covers(h, static_cast<int>(i))) {
+            // the whole stage in one launch on the matrix cores; only its output node is written
+            if ((rc = rn_f32m_launch(h, static_cast<int>(i), cur, n)) != RN_OK) return rc;
+            cur = static_cast<const float*>(h->nodes[s.node_bn2 >= 0 ? s.node_bn2 : s.node_bn].ptr);
+            record(h, 2 + static_cast<int>(i));
+            continue;
+        }
         float* conv = static_cast<float*>(h->nodes[s.node_conv].ptr);
         if ((rc = rn_launch_conv3x3_relu6_f32(h->stream, cur, s.w_f32, conv, n, s.in_side, s.in_side, s.cin,
                                               s.cout)) != RN_OK)
@@ -485,6 +493,8 @@ extern "C" int rn_create(const rn_weights* w, int device, int dtype, int max_bat
         if ((rc = upload(h, lut, 256, &h->lut)) != RN_OK) return fail(rc);
     }
     if (fused_mode(h) && (rc = rn_fused_prepare(h, w)) != RN_OK) return fail(rc);
+    // float32 handles without per-node taps run their conv stages on the matrix cores (rn_stage_f32m.hip)
+    if (!fused_mode(h) && !(h->flags & RN_FLAG_TAPS) && (rc = rn_f32m_prepare(h, w)) != RN_OK) return fail(rc);
     if ((rc = alloc_buffers(h)) != RN_OK) return fail(rc);
     h->events.resize(3 + h->stages.size());
     for (auto& e : h->events)
@@ -519,6 +529,7 @@ extern "C" void rn_destroy(rn_handle* h) {
     }
     if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
     rn_fused_release(h);
+    rn_f32m_release(h);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
     delete h;
 }

@@ -229,6 +229,10 @@ constexpr int P16_RINGW = 14 * (P16_NT - 1) + 18;  // input columns a block read
 constexpr int P16_PIECES = 4;                      // DMA pieces of 192 lanes x 16 B per row (46 px x 16 chunks = 736 <= 768)
 constexpr int P16_ROWB = P16_PIECES * 64 * P16_NT * 16;
 constexpr int P16_KC = 36;
+#ifndef RN_P16_RD
+#define RN_P16_RD 6
+#endif
+constexpr int P16_RD = RN_P16_RD;                  // operand fragments in flight + 1
 constexpr int P16_LDS = C16_NSLOT * P16_ROWB;
 static_assert(P16_RINGW * 16 <= P16_PIECES * 64 * P16_NT, "a ring row fits its DMA pieces");
 
@@ -317,7 +321,10 @@ __global__ __launch_bounds__(64 * P16_NT, 2) void conv16p_kernel(const Conv16Arg
         raw_barrier();
         issue_row(s + C16_AHEAD, (P + C16_AHEAD) % C16_NSLOT);
         f32x4v acc[2];
-        i32x4 bq[2];
+        // operand reads run P16_RD - 1 chunks ahead of their MFMA behind counted waits (round 4: with one read in flight every
+        // MFMA stood behind an LDS round trip: 36 x ~100 cycles per row for 576 cycles of matrix work)
+        constexpr int RD = P16_RD;
+        i32x4 bq[RD];
         auto rd = [&](auto CC, i32x4& b) __attribute__((always_inline)) {
             constexpr int C = decltype(CC)::value;
             constexpr int tap = C / 4, q = C % 4, ky = tap / 3, kx = tap % 3;
@@ -325,17 +332,14 @@ __global__ __launch_bounds__(64 * P16_NT, 2) void conv16p_kernel(const Conv16Arg
             const unsigned ad = boff[kx][q];                 // (named outside the asm: implicit capture of an asm operand)
             asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(b) : "v"(ad), "n"(slot_off));
         };
-        rd(IC<0>{}, bq[0]);
+        [&]<int... C>(std::integer_sequence<int, C...>) { (rd(IC<C>{}, bq[C]), ...); }(std::make_integer_sequence<int, RD - 1>{});
         [&]<int... C>(std::integer_sequence<int, C...>) {
             (([&] {
                  const f32x4v zero = {0.f, 0.f, 0.f, 0.f};
-                 if constexpr (C + 1 < P16_KC) {
-                     rd(IC<(C + 1 < P16_KC ? C + 1 : 0)>{}, bq[(C + 1) & 1]);
-                     asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(bq[C & 1]));
-                 } else {
-                     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bq[C & 1]));
-                 }
-                 acc[C & 1] = mfma16<DT>(wr[C], bq[C & 1], C < 2 ? zero : acc[C & 1]);     // two chains: even / odd chunks
+                 if constexpr (C + RD - 1 < P16_KC) rd(IC<(C + RD - 1 < P16_KC ? C + RD - 1 : 0)>{}, bq[(C + RD - 1) % RD]);
+                 constexpr int newer = (P16_KC - 1 - C) < RD - 1 ? (P16_KC - 1 - C) : RD - 1;
+                 asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(bq[C % RD]) : "n"(newer));
+                 acc[C & 1] = mfma16<DT>(wr[C], bq[C % RD], C < 2 ? zero : acc[C & 1]);     // two chains: even / odd chunks
              }()),
              ...);
         }(std::make_integer_sequence<int, P16_KC>{});

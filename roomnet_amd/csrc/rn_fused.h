@@ -77,3 +77,9 @@ int rn_stage5x_launch(int dtype, hipStream_t s, const rnk::StageArgs& a, int n);
 void rn_stage23x_pack(const float* w_hwio, int dtype, unsigned short (*cvt_bf16)(float), unsigned short (*cvt_f16)(float),
                       std::vector<unsigned short>* out);
 int rn_stage23x_launch(int dtype, hipStream_t s, const rnk::Stage23Args& a, int n);
+
+// ---- float32 conv stages on the matrix cores (rn_stage_f32m.hip): the throughput path of RN_DTYPE_F32 handles without RN_FLAG_TAPS
+int rn_f32m_prepare(rn_handle* h, const rn_weights* w);
+void rn_f32m_release(rn_handle* h);
+bool rn_f32m_covers(const rn_handle* h, int stage);
+int rn_f32m_launch(rn_handle* h, int stage, const float* in, int n);      // writes the stage's output node

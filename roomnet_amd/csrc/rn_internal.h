@@ -110,6 +110,7 @@ struct rn_handle {
     hipStream_t copy_stream = nullptr;
     std::vector<void*> allocs;   // everything to hipFree on destroy
     void* fused = nullptr;       // plan of the fused 16-bit path (rn_fused.hip)
+    void* f32m = nullptr;        // plan of the float32 matrix-core stage kernels (rn_stage_f32m.hip)
     // profiling
     bool profiling = false;
     std::vector<hipEvent_t> events;   // [0]=start, [1]=after preprocess, [2+i]=after stage i, last=after head

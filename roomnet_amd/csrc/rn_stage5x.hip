@@ -167,6 +167,9 @@ __global__ __launch_bounds__(512, 2) void stage5x_kernel(const StageArgs a) {
 
     // ---- residual: tile pair u interpolates its 16 pooled columns from 64 source columns starting at xs_u (kept inside the
     // row); two K halves.  Transposed reads: lane 4 q + p' of a 16-lane group supplies pixel row q, couts 16 cq + 4 p' .. + 3.
+    // K element 8 g + 4 t2 + i of a half is source column 4 g + 16 t2 + i (not 8 g + 4 t2 + i): the two 16-lane groups of a
+    // half-wave then read pixels 4 apart, whose chunk swizzles differ -- conflict-free; 8 apart they share every bank (the
+    // 13.8 % LDS conflict rate of round 3; enumerated with the lane groups of MI355X_MICROARCH.md)
     unsigned a_tr[2][2][2];       // [pair][K half][block of 4 pixels]
     i32x4 wx[2][2];               // [pair][K half]
     int voff[2];
@@ -188,7 +191,7 @@ __global__ __launch_bounds__(512, 2) void stage5x_kernel(const StageArgs a) {
                 unsigned short wh[8];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    const int xin = xs_u + 32 * kh + 8 * g + j;
+                    const int xin = xs_u + 32 * kh + 4 * g + 16 * (j >> 2) + (j & 3);
                     float w = 0.f;
                     if (xin == plo) w += 1.0f - xlq;
                     if (xin == phi) w += xlq;
@@ -198,7 +201,7 @@ __global__ __launch_bounds__(512, 2) void stage5x_kernel(const StageArgs a) {
                 for (int d = 0; d < 4; ++d) wx[u][kh][d] = static_cast<int>(static_cast<unsigned>(wh[2 * d]) | (static_cast<unsigned>(wh[2 * d + 1]) << 16));
 #pragma unroll
                 for (int t2 = 0; t2 < 2; ++t2) {
-                    const int pix = xs_u + 32 * kh + 8 * g + 4 * t2 + q;
+                    const int pix = xs_u + 32 * kh + 4 * g + 16 * t2 + q;
                     const int chunk = 2 * cq + (pp >> 1);
                     a_tr[u][kh][t2] = ring_lds + static_cast<unsigned>(pix * 128 + ((chunk ^ swz8(pix)) << 4) + (pp & 1) * 8);
                 }

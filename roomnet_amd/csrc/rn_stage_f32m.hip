@@ -1,0 +1,426 @@
+// Float32 conv stages on the matrix cores: the throughput path of RN_DTYPE_F32 handles (reference network.py:28: the
+// graph's arithmetic type is float32; :183-203 one conv_block step).
+//
+//   in fp32 [N, H, W, CIN] -> conv3x3 VALID -> ReLU6 -> [avg-pool k/s] -> BN [-> + legacy-bilinear(skip) -> BN] = out fp32
+//
+// One launch per stage, every operation of the stage in fp32 exactly as the per-node kernels of rn_kernels_f32.hip state
+// them (un-contracted BN and residual expressions); only the ORDER of the convolution's K sum and of the pooling window sum
+// differs from the per-node path (within the 1e-4-of-abs-max per-node tolerance of BASELINE config 2; tests/test_hip_f32.py).
+// The per-node path stays what RN_FLAG_TAPS handles run: every graph node tappable.
+//
+// Kernel: the row-streaming implicit GEMM of stage_mfma_kernel (rn_fused.hip) with v_mfma_f32_32x32x2_f32 -- fp32 in, fp32
+// accumulate, bitwise an fmaf chain, 64 FLOP / clock / SIMD = 1/16 of the bf16 rate (MI355X_MICROARCH.md): the stage is bound by
+// the matrix pipe, not by memory (fp32 is priced against the 157 TFLOP/s matrix-fp32 roofline).
+//   * workgroup = image x band of output rows x block of columns x group of 32 couts; one wave = one tile of 32 conv columns;
+//   * the last three input rows live in an LDS ring (fp32 NHWC, 16-byte chunks XOR-swizzled inside a pixel); the B operand of
+//     FOUR MFMAs is one ds_read_b128: lane (pixel, h) reads channels 8 q + 4 h .. + 3 of a tap, MFMA i of the four contracts
+//     channels {8 q + i, 8 q + 4 + i};
+//   * weights sit in LDS in fragment order (host-packed): one lane-linear ds_read_b128 = the A operands of the same four MFMAs;
+//   * accumulator layout = pixel on the lane, 16 couts in registers: ReLU6 per register, horizontal pool by DPP wave shifts,
+//     vertical pool in a register ring, BN / residual / store per group of 4 consecutive couts (one 16-byte store).
+#include "rn_fused.h"
+#include "rn_stage.h"
+
+#include <atomic>
+#include <cstring>
+
+using namespace rnk;
+
+namespace {
+
+struct F32StageArgs {
+    const float* in;              // [N, H, W, CIN]
+    float* out;                   // [N, Ho, Wo, COUT]
+    const f32x4* wfrag;           // [9 CIN / 8][CT][64 lanes] x 4 floats
+    const float* bn_mean;
+    const float* bn_inv;
+    const float* bn_beta;
+    const float* skip;            // [N, Ss, Ss, COUT] (residual stages)
+    const float* bn2_mean;
+    const float* bn2_inv;
+    const float* bn2_beta;
+    const int32_t* rlo;
+    const int32_t* rhi;
+    const float* rlerp;
+    int H, W, Ho, Wo, Ss;
+    int rows_per_band, n_bands, n_colblocks, n_ctg, npt;
+};
+
+__device__ __forceinline__ f32x16 mfma_f32(float a, float b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
+
+// NSL = ring slots: 4 (three live rows + the one being filled behind the compute) or 3 (the fill waits behind a second barrier:
+// the 64-channel stages, whose weights take 72 KB of the LDS)
+template <int CIN, int COUT, int PK, int PS, bool RES, int NSL>
+__global__ __launch_bounds__(512) void stage_f32m_kernel(const F32StageArgs a) {
+    constexpr int CP = CIN / 4;                          // 16-byte chunks (4 floats) per pixel
+    constexpr int KQ = CIN / 8;                          // chunk pairs per tap = ds_read_b128 per tap and lane
+    constexpr int KC = 9 * KQ;                           // weight fragments (1 KB each) per 32-cout tile
+    constexpr int CT = (COUT + 31) / 32;
+    constexpr int NG = COUT >= 32 ? 4 : COUT / 8;
+    constexpr int TSTRIDE = tile_stride(PK, PS);
+    constexpr int NOUT_T = tile_nout(PK, PS);
+    constexpr int RING = PK ? PK - 1 : 0;
+    constexpr int PIXB = CIN * 4;
+    constexpr int LPT_MAX = 8;
+    static_assert(CIN % 8 == 0 && COUT % 8 == 0, "channels must be multiples of 8");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, hh = lane >> 5;
+    const int nthreads = blockDim.x;
+    const int npt = a.npt;
+
+    int bid = blockIdx.x;
+    const int ctg = bid % a.n_ctg;
+    bid /= a.n_ctg;
+    const int cb = bid % a.n_colblocks;
+    const int band = bid / a.n_colblocks;
+    const int n = blockIdx.y;
+
+    const int ringcols = (npt - 1) * TSTRIDE + 34;
+    const int rowbytes = ringcols * PIXB;
+    char* const wl = smem;                                  // weights [KC][64] x 16 B of this workgroup's cout tile
+    float* const tabs = reinterpret_cast<float*>(smem + KC * 1024);      // [6][32] per-channel tables of this cout tile
+    char* const ring = smem + KC * 1024 + 1024;             // NSL rows
+
+    const int yo0 = band * a.rows_per_band;
+    const int yo1 = min(a.Ho, yo0 + a.rows_per_band);
+    const int yc0 = PK ? yo0 * PS : yo0;
+    const int nconv = PK ? (yo1 - yo0 - 1) * PS + PK : (yo1 - yo0);
+    const int nin = nconv + 2;
+    const int x0c = cb * npt * TSTRIDE;
+    const int xo_blk0 = PK ? x0c / PS : x0c;
+
+    for (int i = tid; i < KC * 64; i += nthreads) reinterpret_cast<f32x4*>(wl)[i] = a.wfrag[((i >> 6) * CT + ctg) * 64 + (i & 63)];
+    // per-channel tables of the tile's couts -> LDS (in registers they cost up to 96 VGPRs per lane)
+    for (int i = tid; i < 6 * 32; i += nthreads) {
+        const int t = i / 32, c = ctg * 32 + i % 32;
+        const float* src = t == 0 ? a.bn_mean : t == 1 ? a.bn_inv : t == 2 ? a.bn_beta : t == 3 ? a.bn2_mean : t == 4 ? a.bn2_inv : a.bn2_beta;
+        tabs[i] = (c < COUT && (RES || t < 3)) ? src[c] : 0.f;
+    }
+
+    // ---- input-row loader: a thread owns up to LPT_MAX 16-byte chunks of a ring row
+    const int nchunks = ringcols * CP;
+    const float* const in_img = a.in + static_cast<int64_t>(n) * a.H * a.W * CIN;
+    int ld_goff[LPT_MAX], ld_loff[LPT_MAX];
+#pragma unroll
+    for (int i = 0; i < LPT_MAX; ++i) {
+        const int q = tid + i * nthreads;
+        const int p = q / CP, c4 = q % CP;
+        ld_loff[i] = q < nchunks ? (p * CP + (c4 ^ chunk_swz<CP>(p))) * 16 : -1;
+        ld_goff[i] = (q < nchunks ? min(x0c + p, a.W - 1) : 0) * CIN + c4 * 4;      // columns past the edge feed discarded lanes
+    }
+    f32x4 pre[LPT_MAX];
+    auto fetch_row = [&](int j) {
+        const float* row = in_img + static_cast<int64_t>(yc0 + j) * a.W * CIN;
+#pragma unroll
+        for (int i = 0; i < LPT_MAX; ++i)
+            if (ld_loff[i] >= 0) pre[i] = *reinterpret_cast<const f32x4*>(row + ld_goff[i]);
+    };
+    auto store_row = [&](int j) {
+        char* dst = ring + (j % NSL) * rowbytes;
+#pragma unroll
+        for (int i = 0; i < LPT_MAX; ++i)
+            if (ld_loff[i] >= 0) *reinterpret_cast<f32x4*>(dst + ld_loff[i]) = pre[i];
+    };
+    for (int j = 0; j < 3; ++j) {
+        fetch_row(j);
+        store_row(j);
+    }
+    __syncthreads();
+
+    const int xrel0 = wave * TSTRIDE + r;
+    int boff[3], bswz[3];
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+        boff[kx] = (xrel0 + kx) * PIXB;
+        bswz[kx] = chunk_swz<CP>(xrel0 + kx);
+    }
+    const int xc = x0c + xrel0;
+    const int xo = PK ? xc / PS : xc;
+    const bool lane_out = (PK ? (r % PS == 0 && r <= 32 - PK) : true) && xo < a.Wo && (xo - xo_blk0) < npt * NOUT_T;
+    const int cout_lane = ctg * 32 + 4 * hh;              // + 8 g + j
+
+    int rx_lo = 0, rx_hi = 0;
+    float rx_l = 0.f;
+    if constexpr (RES) {
+        const int xq = min(xo, a.Wo - 1);
+        rx_lo = a.rlo[xq];
+        rx_hi = a.rhi[xq];
+        rx_l = a.rlerp[xq];
+    }
+    float vring[RING > 0 ? RING : 1][16];
+#pragma unroll
+    for (int i = 0; i < (RING > 0 ? RING : 1); ++i)
+#pragma unroll
+        for (int g = 0; g < 16; ++g) vring[i][g] = 0.f;
+
+    const char* const wl_lane = wl + lane * 16;
+
+    for (int it = 0; it < nconv; ++it) {
+        const bool have_next = it + 3 < nin;
+        if (have_next) fetch_row(it + 3);
+
+        f32x16 acc;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) acc[g] = 0.f;
+        const char* rowp[3];
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) rowp[ky] = ring + ((it + ky) % NSL) * rowbytes;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int ky = tap / 3, kx = tap % 3;
+            const char* pb = rowp[ky] + boff[kx];
+#pragma unroll
+            for (int q = 0; q < KQ; ++q) {
+                const int c4 = 2 * q + hh;
+                const f32x4 b = *reinterpret_cast<const f32x4*>(pb + ((c4 ^ bswz[kx]) << 4));
+                const f32x4 wv = *reinterpret_cast<const f32x4*>(wl_lane + (tap * KQ + q) * 1024);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc = mfma_f32(wv[i], b[i], acc);
+            }
+        }
+
+        // ---------------- ReLU6 + horizontal pool sum (lanes) + vertical pool sum (register ring)
+        bool emit;
+        int yo;
+        if constexpr (PK > 0) {
+            emit = it >= PK - 1 && ((it - (PK - 1)) % PS) == 0;
+            yo = yo0 + (it - (PK - 1)) / PS;
+        } else {
+            emit = true;
+            yo = yo0 + it;
+        }
+        float tot[16];
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+            const float v = relu6f(acc[g]);
+            float hs;
+            if constexpr (PK == 4) {
+                const float t = v + lane_next(v);
+                hs = t + lane_next(lane_next(t));
+            } else {
+                hs = v;
+            }
+            float s = hs;
+            if constexpr (RING > 0) {
+                float t = vring[0][g];
+#pragma unroll
+                for (int i = 1; i < RING; ++i) t += vring[i][g];
+                s = t + s;
+#pragma unroll
+                for (int i = 0; i + 1 < RING; ++i) vring[i][g] = vring[i + 1][g];
+                vring[RING - 1][g] = hs;
+            }
+            tot[g] = s;
+        }
+        if (emit) {
+            constexpr float inv_area = PK ? 1.0f / static_cast<float>(PK * PK) : 1.0f;      // pool 4: exact (a power of two)
+            float yl = 0.f;
+            const float* sk0 = nullptr;
+            const float* sk1 = nullptr;
+            if constexpr (RES) {
+                yl = a.rlerp[yo];
+                const float* skn = a.skip + static_cast<int64_t>(n) * a.Ss * a.Ss * COUT;
+                sk0 = skn + static_cast<int64_t>(a.rlo[yo]) * a.Ss * COUT;
+                sk1 = skn + static_cast<int64_t>(a.rhi[yo]) * a.Ss * COUT;
+            }
+            float* orow = a.out + ((static_cast<int64_t>(n) * a.Ho + yo) * a.Wo + xo) * COUT;
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                const int c0 = cout_lane + 8 * g;
+                const float* tl0 = tabs + 4 * hh + 8 * g;
+                const f32x4 t_mean = *reinterpret_cast<const f32x4*>(tl0), t_inv = *reinterpret_cast<const f32x4*>(tl0 + 32),
+                            t_beta = *reinterpret_cast<const f32x4*>(tl0 + 64);
+                f32x4 y;
+                // (x - mean) * inv + beta, un-contracted like bn_f32_kernel
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    y[j] = __fadd_rn(__fmul_rn(__fsub_rn(__fmul_rn(tot[4 * g + j], inv_area), t_mean[j]), t_inv[j]), t_beta[j]);
+                if constexpr (RES) {
+                    if (lane_out) {
+                        const f32x4 t_mean2 = *reinterpret_cast<const f32x4*>(tl0 + 96), t_inv2 = *reinterpret_cast<const f32x4*>(tl0 + 128),
+                                    t_beta2 = *reinterpret_cast<const f32x4*>(tl0 + 160);
+                        const f32x4 tl = *reinterpret_cast<const f32x4*>(sk0 + rx_lo * COUT + c0);
+                        const f32x4 tr = *reinterpret_cast<const f32x4*>(sk0 + rx_hi * COUT + c0);
+                        const f32x4 bl = *reinterpret_cast<const f32x4*>(sk1 + rx_lo * COUT + c0);
+                        const f32x4 br = *reinterpret_cast<const f32x4*>(sk1 + rx_hi * COUT + c0);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            // resize_add_f32_kernel's expression, then the second BN
+                            const float top = __fadd_rn(tl[j], __fmul_rn(__fsub_rn(tr[j], tl[j]), rx_l));
+                            const float bot = __fadd_rn(bl[j], __fmul_rn(__fsub_rn(br[j], bl[j]), rx_l));
+                            const float rs = __fadd_rn(top, __fmul_rn(__fsub_rn(bot, top), yl));
+                            y[j] = __fadd_rn(__fmul_rn(__fsub_rn(__fadd_rn(y[j], rs), t_mean2[j]), t_inv2[j]), t_beta2[j]);
+                        }
+                    }
+                }
+                if (lane_out) *reinterpret_cast<f32x4*>(orow + c0) = y;
+            }
+        }
+
+        if constexpr (NSL == 3) __syncthreads();          // everybody is past row `it` before its slot is refilled
+        if (have_next) store_row(it + 3);
+        __syncthreads();
+    }
+}
+
+struct F32mStage {
+    bool on = false;
+    f32x4* wfrag = nullptr;
+    int variant = -1, npt = 1, n_colblocks = 1, n_ctg = 1, nsl = 4;
+    size_t lds = 0;
+};
+
+struct F32mState {
+    std::vector<F32mStage> st;
+};
+
+using F32LaunchFn = void (*)(const F32StageArgs&, dim3, dim3, size_t, hipStream_t);
+
+template <int CIN, int COUT, int PK, int PS, bool RES, int NSL>
+void launch_f32m(const F32StageArgs& a, dim3 grid, dim3 block, size_t lds, hipStream_t s) {
+    auto kern = stage_f32m_kernel<CIN, COUT, PK, PS, RES, NSL>;
+    static std::atomic<unsigned long long> attr_devices{0};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (!(attr_devices.load(std::memory_order_acquire) >> (dev & 63) & 1ull)) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_devices.fetch_or(1ull << (dev & 63), std::memory_order_release);
+    }
+    hipLaunchKernelGGL(kern, grid, block, lds, s, a);
+}
+
+struct F32Variant {
+    int cin, cout, pk, ps, res, nsl;
+    F32LaunchFn fn;
+};
+const F32Variant kF32Variants[] = {
+    {8, 32, 4, 1, 0, 4, launch_f32m<8, 32, 4, 1, false, 4>},      // stage 1
+    {32, 32, 4, 1, 0, 4, launch_f32m<32, 32, 4, 1, false, 4>},    // stage 2
+    {32, 32, 4, 1, 1, 4, launch_f32m<32, 32, 4, 1, true, 4>},     // stage 3
+    {32, 64, 4, 2, 0, 4, launch_f32m<32, 64, 4, 2, false, 4>},    // stage 4
+    {64, 64, 4, 2, 1, 3, launch_f32m<64, 64, 4, 2, true, 3>},     // stage 5
+    {64, 128, 0, 1, 0, 3, launch_f32m<64, 128, 0, 1, false, 3>},  // stage 6
+};
+
+}  // namespace
+
+void rn_f32m_release(rn_handle* h) {
+    delete static_cast<F32mState*>(h->f32m);
+    h->f32m = nullptr;
+}
+
+// Pack the weights of every stage the kernel covers: frag[tap * CIN / 8 + q][cout tile][lane][i] =
+// W[tap][channel 8 q + 4 (lane / 32) + i][cout 32 tile + lane % 32]
+int rn_f32m_prepare(rn_handle* h, const rn_weights* w) {
+    auto* fs = new F32mState();
+    fs->st.resize(h->stages.size());
+    h->f32m = fs;
+    for (size_t si = 0; si < h->stages.size(); ++si) {
+        const StagePlan& s = h->stages[si];
+        F32mStage& f = fs->st[si];
+        for (size_t v = 0; v < sizeof(kF32Variants) / sizeof(kF32Variants[0]); ++v) {
+            const F32Variant& k = kF32Variants[v];
+            if (k.cin == s.cin && k.cout == s.cout && k.pk == s.pool_k && (s.pool_k == 0 || k.ps == s.pool_s) &&
+                k.res == (s.skip_stage >= 0 ? 1 : 0))
+                f.variant = static_cast<int>(v);
+        }
+        if (f.variant < 0) continue;
+        if (s.skip_stage >= 0 && h->stages[s.skip_stage].node_bn2 >= 0) continue;      // skip source = a first BN output
+        const int kq = s.cin / 8, kc = 9 * kq, ct_n = (s.cout + 31) / 32;
+        f.nsl = kF32Variants[f.variant].nsl;
+        // pixel tiles (= waves) per workgroup: as many as fit the LDS next to the weights, at most 8
+        const int tstride = tile_stride(s.pool_k, s.pool_s), nout_t = tile_nout(s.pool_k, s.pool_s);
+        const int tiles = (s.out_side + nout_t - 1) / nout_t;
+        f.npt = std::min(tiles, 8);
+        for (;;) {
+            const int ringcols = (f.npt - 1) * tstride + 34;
+            f.lds = static_cast<size_t>(kc) * 1024 + 1024 + static_cast<size_t>(f.nsl) * ringcols * s.cin * 4;
+            const int chunks = ringcols * (s.cin / 4);
+            if ((f.lds <= 160 * 1024 && chunks <= 8 * 64 * f.npt) || f.npt == 1) break;
+            --f.npt;
+        }
+        if (f.lds > 160 * 1024) continue;
+        f.n_colblocks = (tiles + f.npt - 1) / f.npt;
+        f.n_ctg = ct_n;
+        std::vector<float> frag(static_cast<size_t>(kc) * ct_n * 64 * 4, 0.f);
+        const float* wsrc = w->stages[si].kernel;      // HWIO = [tap][cin][cout]
+        for (int tap = 0; tap < 9; ++tap)
+            for (int q = 0; q < kq; ++q)
+                for (int t = 0; t < ct_n; ++t)
+                    for (int l = 0; l < 64; ++l)
+                        for (int i = 0; i < 4; ++i) {
+                            const int c = 8 * q + 4 * (l >> 5) + i, co = 32 * t + (l & 31);
+                            if (co < s.cout)
+                                frag[((static_cast<size_t>(tap * kq + q) * ct_n + t) * 64 + l) * 4 + i] =
+                                    wsrc[(static_cast<size_t>(tap) * s.cin + c) * s.cout + co];
+                        }
+        void* d = nullptr;
+        if (hipMalloc(&d, frag.size() * 4) != hipSuccess) {
+            rn_set_error("hipMalloc(fp32 MFMA weights) failed");
+            return RN_E_NOMEM;
+        }
+        h->allocs.push_back(d);
+        RN_HIP(hipMemcpy(d, frag.data(), frag.size() * 4, hipMemcpyHostToDevice));
+        f.wfrag = static_cast<f32x4*>(d);
+        f.on = true;
+    }
+    return RN_OK;
+}
+
+bool rn_f32m_covers(const rn_handle* h, int stage) {
+    const F32mState* fs = static_cast<const F32mState*>(h->f32m);
+    return fs && stage >= 0 && stage < static_cast<int>(fs->st.size()) && fs->st[stage].on;
+}
+
+int rn_f32m_launch(rn_handle* h, int stage, const float* in, int n) {
+    const F32mState* fs = static_cast<const F32mState*>(h->f32m);
+    const F32mStage& f = fs->st[stage];
+    const StagePlan& s = h->stages[stage];
+    F32StageArgs a{};
+    a.in = in;
+    a.out = static_cast<float*>(h->nodes[s.node_bn2 >= 0 ? s.node_bn2 : s.node_bn].ptr);
+    a.wfrag = f.wfrag;
+    a.bn_mean = s.bn.mean;
+    a.bn_inv = s.bn.inv;
+    a.bn_beta = s.bn.beta;
+    if (s.skip_stage >= 0) {
+        a.skip = static_cast<const float*>(h->nodes[h->stages[s.skip_stage].node_bn].ptr);
+        a.bn2_mean = s.bn2.mean;
+        a.bn2_inv = s.bn2.inv;
+        a.bn2_beta = s.bn2.beta;
+        a.rlo = s.rt.lo;
+        a.rhi = s.rt.hi;
+        a.rlerp = s.rt.lerp;
+        a.Ss = s.skip_side;
+    }
+    a.H = a.W = s.in_side;
+    a.Ho = a.Wo = s.out_side;
+    a.npt = f.npt;
+    a.n_colblocks = f.n_colblocks;
+    a.n_ctg = f.n_ctg;
+    // bands: whole rounds of the chip (one workgroup per CU: the weights and the ring fill most of its LDS); a band costs its
+    // rows plus the rows its neighbour reads again
+    const long per_band = static_cast<long>(n) * f.n_colblocks * f.n_ctg;
+    const int rows_in = s.pool_k ? s.pool_s : 1, overlap = s.pool_k ? 5 : 2;
+    const int max_bands = std::max(1, s.out_side / 4);
+    int bands = 1;
+    long best = -1;
+    for (int b = 1; b <= 16 && b <= max_bands; ++b) {
+        const long rounds = (per_band * b + h->n_cu - 1) / h->n_cu;
+        const long cost = rounds * (rows_in * ((s.out_side + b - 1) / b) + overlap);
+        if (best < 0 || cost < best) {
+            best = cost;
+            bands = b;
+        }
+    }
+    if (per_band * bands < h->n_cu) bands = static_cast<int>(std::min<long>((h->n_cu + per_band - 1) / per_band, max_bands));
+    a.rows_per_band = (s.out_side + bands - 1) / bands;
+    a.n_bands = (s.out_side + a.rows_per_band - 1) / a.rows_per_band;
+    kF32Variants[f.variant].fn(a, dim3(a.n_bands * a.n_colblocks * a.n_ctg, n), dim3(64 * f.npt), f.lds, h->stream);
+    RN_CHECK_LAUNCH();
+    return RN_OK;
+}

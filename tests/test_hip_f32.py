@@ -160,3 +160,73 @@ def test_scratch_sharing_handle_matches_tap_handle(weights, parity_images, engin
             e2.tap("s3.conv", 4)
     finally:
         e2.close()
+
+
+# ---- float32 conv stages on the matrix cores (rn_stage_f32m.hip): what an RN_DTYPE_F32 handle runs WITHOUT RN_FLAG_TAPS
+# (the drop-in's default dtype; reference network.py:28).  Same tolerances as the per-node path above.
+STAGE_OUT = ["s0.bn", "s1.bn", "s2.bn", "s3.bn2", "s4.bn", "s5.bn2", "s6.bn", "s7.bn", "s8.bn", "s9.bn2"]
+
+
+@pytest.fixture(scope="module")
+def engine_mm(weights):
+    e = _capi.Engine(build_graph(6, 224), weights, device=0, dtype="f32", max_batch=8)
+    yield e
+    e.close()
+
+
+def test_matrix_core_f32_logits_probs_ids_vs_golden(engine_mm, parity_images, golden_parity):
+    ids, probs, logits = [], [], []
+    for i in range(0, len(parity_images), 8):
+        a, b = engine_mm.forward_u8(parity_images[i:i + 8])
+        ids.append(a)
+        probs.append(b)
+        logits.append(engine_mm.tap("d3.relu", len(a)).copy())
+    ids, probs, logits = np.concatenate(ids), np.concatenate(probs), np.concatenate(logits)
+    np.testing.assert_allclose(logits, golden_parity["logits_f64"], atol=TOL_LOGITS, rtol=0)
+    np.testing.assert_allclose(probs, golden_parity["probs_f64"], atol=TOL_PROBS, rtol=0)
+    safe = golden_parity["top2_margin"] > MARGIN
+    np.testing.assert_array_equal(ids[safe], golden_parity["ids"][safe])
+
+
+def test_matrix_core_f32_stage_outputs_vs_oracle(engine_mm, weights, parity_images):
+    """Every stage output (the tensors the fused stage launches write) within 1e-4 of the node's abs-max of the oracle, on images
+    that reach the 0- and the 6-clamp, at a batch that runs several bands per image (8 images on 256 CUs)."""
+    idx = [1, 14, 22, 30, 35]
+    ims = parity_images[idx]
+    ref = c_oracle.infer(weights, ims, taps=True)
+    ids, probs = engine_mm.forward_u8(ims)
+    for name in STAGE_OUT:
+        got = engine_mm.tap(name, len(idx))
+        want = np.asarray(ref["taps"][name])
+        assert got.shape == want.shape, name
+        tol = 1e-4 * max(float(np.abs(want).max()), 1e-3)
+        np.testing.assert_allclose(got, want, atol=tol, rtol=0, err_msg=name)
+    np.testing.assert_array_equal(ids, ref["ids"])
+
+
+def test_matrix_core_f32_equals_per_node_path_closely(engine, engine_mm, parity_images):
+    """The two float32 paths differ only in the order of the convolution's K sum and of the pooling window sum."""
+    ims = parity_images[[5, 19]]
+    ids_a, probs_a = engine.forward_u8(ims)
+    ids_b, probs_b = engine_mm.forward_u8(ims)
+    np.testing.assert_array_equal(ids_a, ids_b)
+    np.testing.assert_allclose(probs_a, probs_b, atol=2e-6, rtol=0)
+    for name in STAGE_OUT:
+        a, b = engine.tap(name, 2), engine_mm.tap(name, 2)
+        assert float(np.abs(a - b).max()) <= 2e-5 * max(float(np.abs(a).max()), 1e-3), name
+
+
+def test_matrix_core_f32_band_decomposition_does_not_change_bits(weights, parity_images):
+    """1 image (many bands per image) and 8 images (fewer bands) give the same bits: bands only re-partition rows."""
+    e1 = _capi.Engine(build_graph(6, 224), weights, device=0, dtype="f32", max_batch=1)
+    e8 = _capi.Engine(build_graph(6, 224), weights, device=0, dtype="f32", max_batch=8)
+    try:
+        ims = parity_images[[2, 9, 16, 23, 27, 31, 36, 39]]
+        ids8, probs8 = e8.forward_u8(ims)
+        for i in range(len(ims)):
+            ids1, probs1 = e1.forward_u8(ims[i:i + 1])
+            np.testing.assert_array_equal(probs1[0], probs8[i])
+            assert ids1[0] == ids8[i]
+    finally:
+        e1.close()
+        e8.close()
