@@ -14,7 +14,7 @@ mkdir -p "$OBJ"
 CFLAGS=("${FLAGS[@]/-shared/}")
 # (a failed background compile must fail the build: a bare `wait` returns 0 and the link would pick up a stale object)
 PIDS=()
-for f in rn_api rn_kernels_f32 rn_fused rn_imageops rn_group rn_tail rn_conv16 rn_stage_f32m; do
+for f in rn_api rn_kernels_f32 rn_fused rn_imageops rn_group rn_tail rn_conv16 rn_stage_f32m rn_backend; do
     rm -f "$OBJ/$f.o"
     "$HIPCC" "${CFLAGS[@]}" -c "$HERE/$f.hip" -o "$OBJ/$f.o" &
     PIDS+=($!)
@@ -41,7 +41,7 @@ rm -f "$OBJ/rn_stage6x.o"
 "$HIPCC" "${CFLAGS[@]}" ${RN_RW_FLAGS:--mllvm -amdgpu-mfma-vgpr-form} -c "$HERE/rn_stage6x.hip" -o "$OBJ/rn_stage6x.o" &
 PIDS+=($!)
 for p in "${PIDS[@]}"; do wait "$p"; done
-"$HIPCC" --offload-arch=gfx950 -shared -fPIC "$OBJ"/rn_api.o "$OBJ"/rn_kernels_f32.o "$OBJ"/rn_fused.o "$OBJ"/rn_imageops.o "$OBJ"/rn_group.o "$OBJ"/rn_tail.o "$OBJ"/rn_conv16.o "$OBJ"/rn_stage_rw.o "$OBJ"/rn_stage23.o "$OBJ"/rn_stage23x.o "$OBJ"/rn_stage5x.o "$OBJ"/rn_stage4x.o "$OBJ"/rn_stage6x.o "$OBJ"/rn_stage_f32m.o -ldl -lpthread \
+"$HIPCC" --offload-arch=gfx950 -shared -fPIC "$OBJ"/rn_api.o "$OBJ"/rn_kernels_f32.o "$OBJ"/rn_fused.o "$OBJ"/rn_imageops.o "$OBJ"/rn_group.o "$OBJ"/rn_tail.o "$OBJ"/rn_conv16.o "$OBJ"/rn_stage_rw.o "$OBJ"/rn_stage23.o "$OBJ"/rn_stage23x.o "$OBJ"/rn_stage5x.o "$OBJ"/rn_stage4x.o "$OBJ"/rn_stage6x.o "$OBJ"/rn_stage_f32m.o "$OBJ"/rn_backend.o -ldl -lpthread \
     ${RN_EXTRA_FLAGS:-} -o "$OUT/libroomnet_hip.so"
 echo "built $OUT/libroomnet_hip.so"
 # register report of the hot kernels: a spill in one of them costs ~25 % of its time (seen on the fused stage pair) and

@@ -1,0 +1,390 @@
+// The back end of the 16-bit path in ONE launch: stage 6 (64 -> 128, no pool) -> stage 7 (128 -> 16, pool 4/2) -> stages 8 + 9
+// (16 -> 16, pool 4/2, the second with the block's residual) -> flatten -> dense head -> softmax / argmax
+// (reference network.py:229-237, :44-45).  One workgroup per image; neither s6.bn nor s7.bn reaches HBM at default flags.
+//
+// Before (round 3): three launches -- stage6x_kernel 72 us, conv16p_kernel 30 us, tail_kernel 26 us at batch 256 -- each with one
+// workgroup (or two) per image: stage 7 was bound by re-reading stage 6's output from HBM (138 MB in 30 us = 4.6 TB/s), the
+// tail by launch and staging latency.
+//
+// Workgroup = 11 waves:
+//   waves 0-7   stage 6 exactly as rn_stage6x.hip (row-register blocking: wave = 16 couts x the row's three 16-pixel tiles, the
+//               newest input row feeds three live accumulator sets), but a finished conv row (ReLU6 + BN, 16-bit) goes into a
+//               four-row LDS ring ("mid") instead of HBM, in the 256-byte-pixel layout and chunk swizzle conv16p reads;
+//   waves 8-10  stage 7 exactly as conv16p_kernel (one wave = one 16-pixel tile x all 16 couts, 36 K-chunks in two chains, DPP
+//               pooling), three steps behind stage 6: operands from the mid ring, weight fragments from LDS (36 KB; in
+//               registers they are 144 per lane, and three waves per SIMD leave 168); its pooled rows go into an LDS image;
+//   waves 0-3   then run the tail (rn_tail_body.h) on that image.
+// One s_barrier per step; stage 7 adds a third wave to three of the four SIMDs whose matrix pipe stage 6 left 45 % idle.
+// Same arithmetic, operand values and summation order as the three launches: bit-identical (tests/test_hip_fused.py).
+#include "rn_tail_body.h"
+
+#include <atomic>
+#include <utility>
+
+using namespace rnk;
+
+namespace {
+
+constexpr int B_NS = 4, B_AHEAD = 3;             // stage-6 input ring: newest row + 3 in flight
+constexpr int B_ROW6 = 52 * 128;                 // bytes per input ring row (64 channels x 16 bit, 52 pixels)
+constexpr int B_WMIN = 35, B_WMAX = 50;          // stage-6 input side (rn_stage6x.hip)
+constexpr int B_NM = 4;                          // mid ring rows: three being read by stage 7 + the one being written
+constexpr int B_ROWM = 48 * 256;                 // bytes per mid row (128 channels x 16 bit, 48 pixels)
+constexpr int B_KC7 = 36;                        // stage-7 K chunks of 32 (9 taps x 4 channel quarters)
+constexpr int B_LAG = 5;                         // step s computes stage-7 conv row s - B_LAG
+constexpr int B_OFF_RING6 = 0;
+constexpr int B_OFF_MID = B_OFF_RING6 + B_NS * B_ROW6;
+constexpr int B_OFF_W7 = B_OFF_MID + B_NM * B_ROWM;
+constexpr int B_OFF_X7 = B_OFF_W7 + B_KC7 * 1024;            // stage-7 output image [So7][So7][16], So7 <= 22
+constexpr int B_OFF_XA = B_OFF_X7 + 16384;                    // tail: second step's output [16][16][16]
+constexpr int B_OFF_XB = B_OFF_XA + 16 * 16 * 16 * 2;         // third step's output [8][8][16]
+constexpr int B_OFF_BUF0 = B_OFF_XB + 8 * 8 * 16 * 2;
+constexpr int B_OFF_SMALL = B_OFF_BUF0 + 8 * 8 * 16 * 4;
+constexpr int B_OFF_WL = B_OFF_SMALL + 2 * 64 * 4;
+constexpr int B_OFF_TTAB = B_OFF_WL + T_W_LDS * 4;
+constexpr int B_LDS = B_OFF_TTAB + 144 * 4;
+static_assert(B_LDS <= 160 * 1024, "LDS budget");
+
+struct BackendArgs {
+    // stage 6
+    const unsigned short* in;     // [N, W, W, 64]
+    const i32x4* wfrag6;          // rn_stage6x_pack
+    const float* ptab6;           // folded BN: scale[128], shift[128]
+    unsigned short* out6;         // s6.bn [N, Wo, Wo, 128], or nullptr (default flags: not written)
+    int W, Wo;                    // stage-6 input / output side
+    // stage 7
+    const i32x4* wfrag7;          // rn_conv16p_pack: [36][64 lanes]
+    const float* ptab7;           // folded BN: scale[16] (inv / 16), shift[16]
+    unsigned short* out7;         // s7.bn [N, So7, So7, 16], or nullptr
+    int So7;
+    TailArgs tail;
+};
+
+__device__ __forceinline__ unsigned lds_addr(const void* p) {
+    return static_cast<unsigned>(reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) const char*)p));
+}
+__device__ __forceinline__ int swz8(int pix) { return pix & 7; }                   // stage-6 input ring (rn_stage6x.hip)
+__device__ __forceinline__ int swz16(int pix) { return (pix & 7) << 1; }           // mid ring (conv16p: 16 chunks per pixel)
+
+using i32x2 = __attribute__((ext_vector_type(2))) int;
+
+template <int DT>
+__device__ __forceinline__ f32x4 mfma16(i32x4 a, i32x4 b, f32x4 c) {
+    if constexpr (DT == RN_DTYPE_BF16)
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    else
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+
+template <int DT>
+__global__ __launch_bounds__(704) void backend_kernel(const BackendArgs a) {
+    extern __shared__ __attribute__((aligned(64))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int px16 = lane & 15, g = lane >> 4;
+    const int n = blockIdx.x;
+    const int W = a.W, Wo = a.Wo;
+    const int nin = Wo + 2;                         // stage-6 input rows = steps of its loop
+    const int nconv7 = Wo - 2;                      // stage-7 conv rows
+    const int nsteps = max(nin, nconv7 + B_LAG);
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    constexpr int OOB = 0x40000000;
+
+    char* const ring6 = smem + B_OFF_RING6;
+    char* const mid = smem + B_OFF_MID;
+    const unsigned mid_lds = lds_addr(mid);
+    // ---- prologue work shared by all waves: zero the input-ring pixels the row DMA never writes, stage the stage-7 weight
+    // fragments and the dense kernels in LDS
+    for (int i = tid; i < B_NS * (52 - B_WMIN) * 8; i += 704) {
+        const int slot = i / ((52 - B_WMIN) * 8), rest = i % ((52 - B_WMIN) * 8);
+        const int p = B_WMIN + rest / 8, c = rest % 8;
+        if (p >= W) *reinterpret_cast<i32x4*>(ring6 + slot * B_ROW6 + p * 128 + c * 16) = i32x4{0, 0, 0, 0};
+    }
+    for (int i = tid; i < B_KC7 * 64; i += 704) reinterpret_cast<i32x4*>(smem + B_OFF_W7)[i] = a.wfrag7[i];
+    int w_off[RN_MAX_DENSE];
+    tail_stage_dense(a.tail.head, reinterpret_cast<float*>(smem + B_OFF_WL), w_off, tid, 704);
+
+    if (wave < 8) {
+        // =============================================================== stage 6 (rn_stage6x.hip), output into the mid ring
+        const unsigned ring_lds = lds_addr(ring6);
+        i32x4 wf[18];
+#pragma unroll
+        for (int f = 0; f < 18; ++f) {
+            const i32x4* src = a.wfrag6 + (f * 8 + wave) * 64 + lane;
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(wf[f]) : "v"(src) : "memory");
+        }
+        const char* const in_img = reinterpret_cast<const char*>(a.in + static_cast<int64_t>(n) * W * W * 64);
+        const int row_bytes = W * 128;
+        const unsigned long long dma_mask = (1ull << W) - 1ull;
+        unsigned goff;
+        {
+            const int q = wave * W + min(lane, W - 1);
+            const int p = q >> 3, c = q & 7;
+            goff = static_cast<unsigned>(p * 128 + ((c ^ swz8(p)) << 4));
+        }
+        auto issue_row = [&](int y, int slot) __attribute__((always_inline)) {
+            const char* row = in_img + static_cast<int64_t>(min(y, nin - 1)) * row_bytes;
+            unsigned o = goff;
+            asm volatile("" : "+v"(o));
+            dma16_masked(row + o, ring6 + slot * B_ROW6 + wave * W * 16, dma_mask);
+        };
+        unsigned base[3][2];
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+            for (int ch = 0; ch < 2; ++ch) {
+                const int p = px16 + kx;
+                base[kx][ch] = ring_lds + static_cast<unsigned>(p * 128 + (((4 * ch + g) ^ swz8(p)) << 4));
+            }
+        // a lane holds couts 16 wave + 4 g .. + 3 of pixel 16 k + px16: 8 bytes = half (g & 1) of chunk 2 wave + g / 2 of the pixel
+        int voff[3];
+        unsigned moff[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int xo = 16 * k + px16;
+            voff[k] = (a.out6 != nullptr && xo < Wo) ? (xo * 128 + 16 * wave + 4 * g) * 2 : OOB;
+            moff[k] = mid_lds + static_cast<unsigned>(xo * 256 + (((2 * wave + (g >> 1)) ^ swz16(xo)) << 4) + (g & 1) * 8);
+        }
+        const f32x4 sc = *reinterpret_cast<const f32x4*>(a.ptab6 + 16 * wave + 4 * g);
+        const f32x4 sh = *reinterpret_cast<const f32x4*>(a.ptab6 + 128 + 16 * wave + 4 * g);
+        f32x4 acc[3][3];
+#pragma unroll
+        for (int r3 = 0; r3 < 3; ++r3)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) acc[r3][k] = zero4;
+        const int out_row_bytes = Wo * 256;
+        const char* const out_img = reinterpret_cast<const char*>(a.out6 ? a.out6 + static_cast<int64_t>(n) * Wo * Wo * 128 : nullptr);
+#pragma unroll
+        for (int j = 0; j < B_AHEAD; ++j) issue_row(j, j);
+        wait_vmcnt<0>();
+#pragma unroll
+        for (int f = 0; f < 18; ++f) asm volatile("" : "+v"(wf[f]));
+        lds_barrier();
+
+        int slot_cur = 0;
+        auto step = [&](auto RC, int s) __attribute__((always_inline)) {
+            constexpr int R = decltype(RC)::value;
+            constexpr int iN = R, iM = (R + 2) % 3, iO = (R + 1) % 3;
+            // (vmcnt: one DMA piece and three stores per step, as in stage6x_kernel)
+            wait_vmcnt<3 + 4 * (B_AHEAD - 1)>();
+            raw_barrier();
+            {
+                int sl = slot_cur + B_AHEAD;
+                sl = sl >= B_NS ? sl - B_NS : sl;
+                issue_row(s + B_AHEAD, sl);
+            }
+            const unsigned so = static_cast<unsigned>(slot_cur * B_ROW6);
+            unsigned bc[3][2];
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                for (int ch = 0; ch < 2; ++ch) bc[kx][ch] = base[kx][ch] + so;
+            const int j = s - 2;                                            // conv row completed by this step
+            const int jr = min(max(j, 0), Wo - 1);
+            const char* orow = out_img + static_cast<int64_t>(jr) * out_row_bytes;
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(orow), 0, out_row_bytes, 0x00020000);
+            const int emask = (j >= 0 && j < Wo) ? 0 : OOB;
+            const unsigned mslot = static_cast<unsigned>((jr & (B_NM - 1)) * B_ROWM);       // (rows j < 0 write row 0's slot early: harmless)
+            i32x4 fq[2][3];
+            auto reads = [&](auto BC) __attribute__((always_inline)) {
+                constexpr int b = decltype(BC)::value, k = b >> 1, ch = b & 1;
+                auto& dst = fq[b & 1];
+                auto& bcr = bc;
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst[kx]) : "v"(bcr[kx][ch]), "n"(k * 2048));
+            };
+            auto batch = [&](auto BC, auto NEXTC) __attribute__((always_inline)) {
+                constexpr int b = decltype(BC)::value, k = b >> 1, ch = b & 1;
+                constexpr bool NEXT = decltype(NEXTC)::value != 0;
+                if constexpr (NEXT) reads(IC<b + 1>{});
+                auto& cur = fq[b & 1];
+                [&]<int... KX>(std::integer_sequence<int, KX...>) {
+                    (([&] {
+                         asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(cur[KX]) : "n"((NEXT ? 3 : 0) + 2 - KX));
+                         acc[iN][k] = mfma16<DT>(wf[(0 * 3 + KX) * 2 + ch], cur[KX], (ch == 0 && KX == 0) ? zero4 : acc[iN][k]);
+                         acc[iM][k] = mfma16<DT>(wf[(1 * 3 + KX) * 2 + ch], cur[KX], acc[iM][k]);
+                         acc[iO][k] = mfma16<DT>(wf[(2 * 3 + KX) * 2 + ch], cur[KX], acc[iO][k]);
+                     }()),
+                     ...);
+                }(std::make_integer_sequence<int, 3>{});
+            };
+            auto emit = [&](auto KC) __attribute__((always_inline)) {
+                constexpr int k = decltype(KC)::value;
+                const f32x4 v = acc[iO][k];
+                float y[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) y[i] = __builtin_fmaf(relu6f(v[i]), sc[i], sh[i]);
+                const i32x2 d = {static_cast<int>(pack2<DT>(y[0], y[1])), static_cast<int>(pack2<DT>(y[2], y[3]))};
+                const unsigned ma = moff[k] + mslot;
+                asm volatile("ds_write_b64 %0, %1" ::"v"(ma), "v"(d) : "memory");
+                __builtin_amdgcn_raw_buffer_store_b64(d, rs, voff[k] | emask, 0, 0);
+            };
+            if (s < nin) {
+                reads(IC<0>{});
+                batch(IC<0>{}, IC<1>{});
+                batch(IC<1>{}, IC<1>{});
+                emit(IC<0>{});
+                batch(IC<2>{}, IC<1>{});
+                batch(IC<3>{}, IC<1>{});
+                emit(IC<1>{});
+                batch(IC<4>{}, IC<1>{});
+                batch(IC<5>{}, IC<0>{});
+                emit(IC<2>{});
+            }
+            slot_cur = slot_cur == B_NS - 1 ? 0 : slot_cur + 1;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        };
+        int s = 0;
+        for (; s + 2 < nsteps; s += 3) {
+            step(IC<0>{}, s);
+            step(IC<1>{}, s + 1);
+            step(IC<2>{}, s + 2);
+        }
+        const int rem = nsteps - s;
+        if (rem > 0) step(IC<0>{}, s);
+        if (rem > 1) step(IC<1>{}, s + 1);
+        wait_vmcnt<0>();
+    } else {
+        // =============================================================== stage 7 (conv16p_kernel), operands from the mid ring
+        const int t = wave - 8;                                  // pixel tile: conv columns 14 t .. 14 t + 15, pooled 7 t .. 7 t + 6
+        const int i16 = px16, kg = g;
+        const unsigned w7_lds = lds_addr(smem + B_OFF_W7) + static_cast<unsigned>(lane) * 16u;
+        unsigned boff[3][4];
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int p = min(14 * t + i16 + kx, 47);
+                boff[kx][q] = mid_lds + static_cast<unsigned>(p * 256 + (((4 * q + kg) ^ swz16(p)) << 4));
+            }
+        const f32x4 sc = *reinterpret_cast<const f32x4*>(a.ptab7 + 4 * kg);
+        const f32x4 sh = *reinterpret_cast<const f32x4*>(a.ptab7 + 16 + 4 * kg);
+        const int So7 = a.So7;
+        const int xo = 7 * t + (i16 >> 1);
+        const bool lane_out = (i16 & 1) == 0 && i16 <= 12 && xo < So7;
+        const int voff_lane = (lane_out && a.out7 != nullptr) ? (xo * 16 + 4 * kg) * 2 : OOB;
+        const int out_row_bytes = So7 * 16 * 2;
+        const char* out_row = reinterpret_cast<const char*>(a.out7 ? a.out7 + static_cast<int64_t>(n) * So7 * So7 * 16 : nullptr);
+        char* const x7 = smem + B_OFF_X7;
+        float hprev[4] = {0.f, 0.f, 0.f, 0.f}, q0[4] = {0.f, 0.f, 0.f, 0.f};
+        lds_barrier();                                           // (the prologue barrier of the stage-6 waves)
+        for (int s = 0; s < nsteps; ++s) {
+            raw_barrier();
+            const int j7 = s - B_LAG;
+            if (j7 >= 0 && j7 < nconv7) {
+                unsigned so[3];
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky) so[ky] = static_cast<unsigned>(((j7 + ky) & (B_NM - 1)) * B_ROWM);
+                f32x4 acc[2];
+                constexpr int RD = 4;                            // operand pairs in flight + 1
+                i32x4 bq[RD], aq[RD];
+                auto rd = [&](auto CC, i32x4& av, i32x4& bv) __attribute__((always_inline)) {
+                    constexpr int C = decltype(CC)::value;
+                    constexpr int tap = C / 4, q = C % 4, ky = tap / 3, kx = tap % 3;
+                    const unsigned ad = boff[kx][q] + so[ky], wa = w7_lds;
+                    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(av) : "v"(wa), "n"(C * 1024));
+                    asm volatile("ds_read_b128 %0, %1" : "=v"(bv) : "v"(ad));
+                };
+                [&]<int... C>(std::integer_sequence<int, C...>) { (rd(IC<C>{}, aq[C], bq[C]), ...); }(std::make_integer_sequence<int, RD - 1>{});
+                [&]<int... C>(std::integer_sequence<int, C...>) {
+                    (([&] {
+                         if constexpr (C + RD - 1 < B_KC7) rd(IC<(C + RD - 1 < B_KC7 ? C + RD - 1 : 0)>{}, aq[(C + RD - 1) % RD], bq[(C + RD - 1) % RD]);
+                         constexpr int newer = 2 * ((B_KC7 - 1 - C) < RD - 1 ? (B_KC7 - 1 - C) : RD - 1);
+                         asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(aq[C % RD]), "+v"(bq[C % RD]) : "n"(newer));
+                         acc[C & 1] = mfma16<DT>(aq[C % RD], bq[C % RD], C < 2 ? zero4 : acc[C & 1]);     // two chains: even / odd chunks
+                     }()),
+                     ...);
+                }(std::make_integer_sequence<int, B_KC7>{});
+                float v[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = relu6f(acc[0][j] + acc[1][j]);
+                if (j7 & 1) {
+                    float y[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float pq = hprev[j] + v[j];
+                        const float tt = q0[j] + pq;
+                        q0[j] = pq;
+                        const float u = tt + row_next<1>(tt);
+                        const float H = u + row_next<2>(u);
+                        y[j] = fmaf(H, sc[j], sh[j]);
+                    }
+                    if (j7 >= 3) {
+                        const int r = (j7 - 3) >> 1;                 // pooled row
+                        const i32x2 d = {static_cast<int>(pack2<DT>(y[0], y[1])), static_cast<int>(pack2<DT>(y[2], y[3]))};
+                        if (lane_out) *reinterpret_cast<i32x2*>(x7 + ((r * So7 + xo) * 16 + 4 * kg) * 2) = d;
+                        const __amdgpu_buffer_rsrc_t rs =
+                            __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(out_row) + static_cast<int64_t>(r) * out_row_bytes, 0, out_row_bytes, 0x00020000);
+                        __builtin_amdgcn_raw_buffer_store_b64(d, rs, voff_lane, 0, 0);
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) hprev[j] = v[j];
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+        wait_vmcnt<0>();
+    }
+    // =================================================================== tail on the first four waves
+    __syncthreads();
+    if (wave >= 4) return;
+    tail_phase<DT>(a.tail, reinterpret_cast<const unsigned short*>(smem + B_OFF_X7), reinterpret_cast<unsigned short*>(smem + B_OFF_XA),
+                   reinterpret_cast<unsigned short*>(smem + B_OFF_XB), reinterpret_cast<float*>(smem + B_OFF_BUF0),
+                   reinterpret_cast<float(*)[64]>(smem + B_OFF_SMALL), reinterpret_cast<const float*>(smem + B_OFF_WL), w_off, reinterpret_cast<float*>(smem + B_OFF_TTAB), n, tid);
+}
+
+}  // namespace
+
+// the fused back end covers: stage 6 as rn_stage6x (one column block), stage 7 as conv16p in one column block (<= 3 tiles), a
+// tail rn_tail_supported accepts
+bool rn_backend_supported(const rn_handle* h) {
+    const size_t ns = h->stages.size();
+    if (ns < 5 || !rn_tail_supported(h)) return false;
+    const StagePlan& s6 = h->stages[ns - 4];
+    const StagePlan& s7 = h->stages[ns - 3];
+    int ncb, xo0[4], wo[4];
+    if (!rn_stage6x_supported(s6.cin, s6.cout, s6.pool_k, s6.skip_stage >= 0, s6.in_side) || !rn_stage6x_plan(s6.out_side, &ncb, xo0, wo) ||
+        ncb != 1)
+        return false;
+    if (!rn_conv16p_supported(s7.cin, s7.cout, s7.pool_k, s7.pool_s, s7.skip_stage >= 0) || rn_conv16p_colblocks(s7.out_side) != 1) return false;
+    if (s7.in_side != s6.out_side || s7.out_side > 22 || s6.node_bn2 >= 0 || s7.node_bn2 >= 0) return false;
+    for (size_t k = ns - 2; k < ns; ++k)
+        if (h->stages[k].skip_stage == static_cast<int>(ns) - 4) return false;      // stage 6's output has no other consumer
+    return true;
+}
+
+int rn_backend_launch(rn_handle* h, const i32x4* wfrag6, const float* ptab6, const i32x4* wfrag7, const float* ptab7, const i32x4* wfrag_a,
+                      const i32x4* wfrag_b, const HeadArgs& head, bool write_taps, int n, float* d_probs, int64_t* d_ids) {
+    const size_t ns = h->stages.size();
+    const StagePlan& s5 = h->stages[ns - 5];
+    const StagePlan& s6 = h->stages[ns - 4];
+    const StagePlan& s7 = h->stages[ns - 3];
+    BackendArgs a{};
+    a.in = static_cast<const unsigned short*>(h->nodes[s5.node_bn2 >= 0 ? s5.node_bn2 : s5.node_bn].ptr);
+    a.wfrag6 = wfrag6;
+    a.ptab6 = ptab6;
+    a.out6 = write_taps ? static_cast<unsigned short*>(h->nodes[s6.node_bn].ptr) : nullptr;
+    a.W = s6.in_side;
+    a.Wo = s6.out_side;
+    a.wfrag7 = wfrag7;
+    a.ptab7 = ptab7;
+    a.out7 = write_taps ? static_cast<unsigned short*>(h->nodes[s7.node_bn].ptr) : nullptr;
+    a.So7 = s7.out_side;
+    rn_tail_fill_args(h, wfrag_a, wfrag_b, head, d_probs, d_ids, &a.tail);
+    auto launch = [&](auto kern) -> int {
+        static std::atomic<unsigned long long> attr_devices{0};
+        int dev = 0;
+        RN_HIP(hipGetDevice(&dev));
+        if (!(attr_devices.load(std::memory_order_acquire) >> (dev & 63) & 1ull)) {
+            RN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            attr_devices.fetch_or(1ull << (dev & 63), std::memory_order_release);
+        }
+        hipLaunchKernelGGL(kern, dim3(n), dim3(704), B_LDS, h->stream, a);
+        RN_CHECK_LAUNCH();
+        return RN_OK;
+    };
+    if (h->dtype == RN_DTYPE_BF16) return launch(backend_kernel<RN_DTYPE_BF16>);
+    return launch(backend_kernel<RN_DTYPE_F16>);
+}

@@ -613,6 +613,10 @@ struct FusedState {
     std::vector<int> launch_rep;
     bool fuse_s0 = false;        // stage 0 is computed inside stage 1's kernel (rn_stage_rw.hip, S0F)
     bool use_tail = false;       // last two stages + head in one launch (rn_tail.hip)
+    // the whole back end (stage 6 -> 7 -> 8 -> 9 -> head) in one launch, one workgroup per image (rn_backend.hip): taken when the
+    // batch fills at least half the chip; smaller batches keep the launches that cut an image into bands
+    bool use_backend = false;
+    bool last_backend = false;   // the last forward pass ran it: stages 6 and 7 were not written
     // cross-stage fused pair (rn_stage23.hip): stages pair_first, pair_first + 1 run as one launch
     int pair_first = -1;
     float* pair_ptab = nullptr;  // [5][32]: the first stage's scale, shift | the second stage's scale', shift', scale2
@@ -930,6 +934,11 @@ int rn_fused_prepare(rn_handle* h, const rn_weights* w) {
 #ifdef RN_X_NO_TAIL     // (A/B timing builds)
     fs->use_tail = false;
 #endif
+    {
+        const size_t ns = h->stages.size();
+        fs->use_backend = fs->use_tail && !(h->flags & RN_FLAG_PAIR_32X32) && ns >= 5 && rn_backend_supported(h) && fs->st[ns - 4].use_s6x &&
+                          fs->st[ns - 3].use_c16p;
+    }
     fs->launch_rep.resize(h->stages.size());
     for (size_t i = 0; i < h->stages.size(); ++i) fs->launch_rep[i] = static_cast<int>(i);
     if (fs->fuse_s0) fs->launch_rep[0] = 1;
@@ -942,12 +951,17 @@ int rn_fused_prepare(rn_handle* h, const rn_weights* w) {
 bool rn_fused_stage_elided(const rn_handle* h, int stage) {
     const FusedState* fs = static_cast<const FusedState*>(h->fused);
     if (!fs) return false;
+    const int ns = static_cast<int>(h->stages.size());
+    if (fs->last_backend && (stage == ns - 4 || stage == ns - 3)) return true;
     return (fs->fuse_s0 && stage == 0) || (fs->pair_first >= 0 && stage == fs->pair_first);
 }
 
 int rn_fused_launch_rep(const rn_handle* h, int stage) {
     const FusedState* fs = static_cast<const FusedState*>(h->fused);
-    return fs && stage >= 0 && stage < static_cast<int>(fs->launch_rep.size()) ? fs->launch_rep[stage] : stage;
+    if (!fs || stage < 0 || stage >= static_cast<int>(fs->launch_rep.size())) return stage;
+    const int ns = static_cast<int>(fs->launch_rep.size());
+    if (fs->last_backend && stage >= ns - 4) return ns - 1;      // (the last forward pass ran stage 6 .. head as one launch)
+    return fs->launch_rep[stage];
 }
 
 int rn_fused_forward(rn_handle* h, const uint8_t* d_bgr, const float* d_rgb, int n, float* d_probs,
@@ -1002,6 +1016,24 @@ int rn_fused_forward(rn_handle* h, const uint8_t* d_bgr, const float* d_rgb, int
         const StagePlan& s = h->stages[i];
         const FusedStage& f = fs->st[i];
         const StagePlan& prev = h->stages[i - 1];
+        if (fs->use_backend && i + 4 == h->stages.size() && 2 * n >= h->n_cu) {
+            // stage 6 .. head in one launch: reported under the last stage
+            const size_t ns = h->stages.size();
+            for (size_t k = i; k + 1 < ns; ++k) rn_record_event(h, 2 + static_cast<int>(k));
+            HeadArgs head;
+            rn_fill_head_args(h, &head);
+            fs->last_backend = true;
+            int rc = rn_backend_launch(h, fs->st[ns - 4].wfrag16, fs->st[ns - 4].ptab, fs->st[ns - 3].wfrag16, fs->st[ns - 3].ptab, fs->st[ns - 2].wfrag,
+                                       fs->st[ns - 1].wfrag, head, false, n, d_probs, d_ids);
+            if (rc != RN_OK) return rc;
+            rn_record_event(h, 2 + static_cast<int>(ns - 1));
+            rn_record_event(h, 2 + static_cast<int>(ns));
+#ifdef RN_CLOCK
+            rn_clock_end(h->stream);
+#endif
+            return RN_OK;
+        }
+        fs->last_backend = false;
         if (fs->use_tail && i + 2 == h->stages.size()) {
             // the last two stages, the flatten, the dense head, softmax and argmax in one launch: reported under the last
             // stage, the head's own slot reads ~0

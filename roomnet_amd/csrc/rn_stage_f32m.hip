@@ -50,7 +50,8 @@ __device__ __forceinline__ f32x16 mfma_f32(float a, float b, f32x16 c) { return 
 
 // NSL = ring slots: 4 (three live rows + the one being filled behind the compute) or 3 (the fill waits behind a second barrier:
 // the 64-channel stages, whose weights take 72 KB of the LDS)
-template <int CIN, int COUT, int PK, int PS, bool RES, int NSL>
+// LPT = 16-byte chunks of a ring row one thread fetches (the host sizes the workgroup so that ringcols * CIN / 4 <= LPT * threads)
+template <int CIN, int COUT, int PK, int PS, bool RES, int NSL, int LPT>
 __global__ __launch_bounds__(512) void stage_f32m_kernel(const F32StageArgs a) {
     constexpr int CP = CIN / 4;                          // 16-byte chunks (4 floats) per pixel
     constexpr int KQ = CIN / 8;                          // chunk pairs per tap = ds_read_b128 per tap and lane
@@ -61,7 +62,7 @@ __global__ __launch_bounds__(512) void stage_f32m_kernel(const F32StageArgs a) {
     constexpr int NOUT_T = tile_nout(PK, PS);
     constexpr int RING = PK ? PK - 1 : 0;
     constexpr int PIXB = CIN * 4;
-    constexpr int LPT_MAX = 8;
+    constexpr int LPT_MAX = LPT;
     static_assert(CIN % 8 == 0 && COUT % 8 == 0, "channels must be multiples of 8");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -280,9 +281,9 @@ struct F32mState {
 
 using F32LaunchFn = void (*)(const F32StageArgs&, dim3, dim3, size_t, hipStream_t);
 
-template <int CIN, int COUT, int PK, int PS, bool RES, int NSL>
+template <int CIN, int COUT, int PK, int PS, bool RES, int NSL, int LPT>
 void launch_f32m(const F32StageArgs& a, dim3 grid, dim3 block, size_t lds, hipStream_t s) {
-    auto kern = stage_f32m_kernel<CIN, COUT, PK, PS, RES, NSL>;
+    auto kern = stage_f32m_kernel<CIN, COUT, PK, PS, RES, NSL, LPT>;
     static std::atomic<unsigned long long> attr_devices{0};
     int dev = 0;
     (void)hipGetDevice(&dev);
@@ -294,16 +295,16 @@ void launch_f32m(const F32StageArgs& a, dim3 grid, dim3 block, size_t lds, hipSt
 }
 
 struct F32Variant {
-    int cin, cout, pk, ps, res, nsl;
+    int cin, cout, pk, ps, res, nsl, lpt;
     F32LaunchFn fn;
 };
 const F32Variant kF32Variants[] = {
-    {8, 32, 4, 1, 0, 4, launch_f32m<8, 32, 4, 1, false, 4>},      // stage 1
-    {32, 32, 4, 1, 0, 4, launch_f32m<32, 32, 4, 1, false, 4>},    // stage 2
-    {32, 32, 4, 1, 1, 4, launch_f32m<32, 32, 4, 1, true, 4>},     // stage 3
-    {32, 64, 4, 2, 0, 4, launch_f32m<32, 64, 4, 2, false, 4>},    // stage 4
-    {64, 64, 4, 2, 1, 3, launch_f32m<64, 64, 4, 2, true, 3>},     // stage 5
-    {64, 128, 0, 1, 0, 3, launch_f32m<64, 128, 0, 1, false, 3>},  // stage 6
+    {8, 32, 4, 1, 0, 4, 4, launch_f32m<8, 32, 4, 1, false, 4, 4>},        // stage 1
+    {32, 32, 4, 1, 0, 4, 4, launch_f32m<32, 32, 4, 1, false, 4, 4>},      // stage 2
+    {32, 32, 4, 1, 1, 4, 4, launch_f32m<32, 32, 4, 1, true, 4, 4>},       // stage 3
+    {32, 64, 4, 2, 0, 4, 4, launch_f32m<32, 64, 4, 2, false, 4, 4>},      // stage 4
+    {64, 64, 4, 2, 1, 3, 8, launch_f32m<64, 64, 4, 2, true, 3, 8>},       // stage 5
+    {64, 128, 0, 1, 0, 3, 10, launch_f32m<64, 128, 0, 1, false, 3, 10>},  // stage 6
 };
 
 }  // namespace
@@ -340,10 +341,13 @@ int rn_f32m_prepare(rn_handle* h, const rn_weights* w) {
             const int ringcols = (f.npt - 1) * tstride + 34;
             f.lds = static_cast<size_t>(kc) * 1024 + 1024 + static_cast<size_t>(f.nsl) * ringcols * s.cin * 4;
             const int chunks = ringcols * (s.cin / 4);
-            if ((f.lds <= 160 * 1024 && chunks <= 8 * 64 * f.npt) || f.npt == 1) break;
+            if ((f.lds <= 160 * 1024 && chunks <= kF32Variants[f.variant].lpt * 64 * f.npt) || f.npt == 1) break;
             --f.npt;
         }
-        if (f.lds > 160 * 1024) continue;
+        {
+            const int ringcols = (f.npt - 1) * tstride + 34;
+            if (f.lds > 160 * 1024 || ringcols * (s.cin / 4) > kF32Variants[f.variant].lpt * 64 * f.npt) continue;      // not coverable
+        }
         f.n_colblocks = (tiles + f.npt - 1) / f.npt;
         f.n_ctg = ct_n;
         std::vector<float> frag(static_cast<size_t>(kc) * ct_n * 64 * 4, 0.f);

@@ -154,8 +154,12 @@ def test_scratch_sharing_handle_matches_tap_handle(weights, parity_images, engin
         ims = parity_images[[5, 15, 25, 35]]
         ids2, probs2 = e2.forward_u8(ims)
         ids1, probs1 = engine.forward_u8(ims)
-        np.testing.assert_array_equal(probs1, probs2)
-        np.testing.assert_array_equal(e2.tap("s3.bn2", 4), engine.tap("s3.bn2", 4))
+        # (the handle without taps shares its scratch buffers AND runs its conv stages on the matrix cores: same values up to the
+        #  order of the convolution's K sum, test_matrix_core_f32_equals_per_node_path_closely)
+        np.testing.assert_array_equal(ids1, ids2)
+        np.testing.assert_allclose(probs1, probs2, atol=2e-6, rtol=0)
+        a, b = e2.tap("s3.bn2", 4), engine.tap("s3.bn2", 4)
+        assert float(np.abs(a - b).max()) <= 2e-5 * float(np.abs(b).max())
         with pytest.raises(_capi.RoomNetLibraryError):
             e2.tap("s3.conv", 4)
     finally:

@@ -182,15 +182,51 @@ def test_results_do_not_depend_on_the_batch_geometry(weights, parity_images, nb)
         pick = np.arange(nb) % len(parity_images)
         ids, probs = eng.forward_u8(parity_images[pick])
         s5 = eng.tap("s5.bn2", nb)
-        s7 = eng.tap("s7.bn", nb)
+        # from half a chip's worth of images on (128) the back end runs as ONE launch per image (rn_backend.hip): stages 6 and 7
+        # stay in LDS, stage 8 is the first tensor behind them that is written
+        late = "s8.bn" if nb >= 128 else "s7.bn"
+        if nb >= 128:
+            with pytest.raises(_capi.RoomNetLibraryError):
+                eng.tap("s7.bn", nb)
+        s7 = eng.tap(late, nb)
         for i in sorted({0, nb // 2, nb - 1}):
             ids1, probs1 = eng.forward_u8(parity_images[pick[i]:pick[i] + 1])
             np.testing.assert_array_equal(eng.tap("s5.bn2", 1)[0], s5[i])
-            np.testing.assert_array_equal(eng.tap("s7.bn", 1)[0], s7[i])
+            np.testing.assert_array_equal(eng.tap(late, 1)[0], s7[i])
             np.testing.assert_array_equal(probs1[0], probs[i])
             assert ids1[0] == ids[i]
     finally:
         eng.close()
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+def test_one_launch_back_end_is_bit_identical_to_the_stage_launches(weights, parity_images, dtype):
+    """Stage 6 -> 7 -> 8 -> 9 -> head as one launch per image (default handle, 160 images) against one launch per stage
+    (RN_FLAG_STAGE_LAUNCHES): same arithmetic, operand values and summation order -- every tensor behind it and the results agree
+    bit for bit; and against the oracle-pinned small-batch results."""
+    nb = 160
+    pick = (np.arange(nb) * 3) % len(parity_images)
+    ims = parity_images[pick]
+    fused = _capi.Engine(build_graph(6, 224), weights, device=0, dtype=dtype, max_batch=nb)
+    plain = _capi.Engine(build_graph(6, 224), weights, device=0, dtype=dtype, max_batch=nb, stage_launches=True)
+    small = _capi.Engine(build_graph(6, 224), weights, device=0, dtype=dtype, max_batch=8)
+    try:
+        ids_f, probs_f = fused.forward_u8(ims)
+        ids_p, probs_p = plain.forward_u8(ims)
+        assert fused.launch_groups()[-1] == [6, 7, 8, 9]
+        for name in ("s8.bn", "s9.bn2", "d3.relu"):
+            a, b = fused.tap(name, nb), plain.tap(name, nb)
+            if name == "s8.bn":                  # (the pair's fp32 summation order: see _same_up_to_sum_order)
+                _same_up_to_sum_order(a, b, dtype, name, frac=2e-3, n_ulp=4)
+        np.testing.assert_allclose(probs_f, probs_p, rtol=0, atol=2e-3)
+        np.testing.assert_array_equal(ids_f, ids_p)
+        ids8, probs8 = small.forward_u8(parity_images)
+        np.testing.assert_array_equal(probs_f, probs8[pick])         # default handle, small batch: three launches -- same bits
+        np.testing.assert_array_equal(ids_f, ids8[pick])
+    finally:
+        fused.close()
+        plain.close()
+        small.close()
 
 
 def test_against_f32_hip_path(engine, weights, parity_images):
@@ -238,7 +274,7 @@ def test_full_batch_256_properties(weights, parity_images, golden_parity, dtype)
     small = _capi.Engine(build_graph(6, 224), weights, device=0, dtype=dtype, max_batch=8)
     try:
         ids, probs = big.forward_u8(ims)
-        s7 = big.tap("s7.bn", 256)
+        s7 = big.tap("s8.bn", 256)              # (the first tensor behind the one-launch back end, rn_backend.hip)
         ids8, probs8 = small.forward_u8(parity_images)          # 40 images in chunks of 8
         np.testing.assert_array_equal(probs, probs8[pick])
         np.testing.assert_array_equal(ids, ids8[pick])
@@ -247,7 +283,7 @@ def test_full_batch_256_properties(weights, parity_images, golden_parity, dtype)
         perm = rng.permutation(256)
         ids_p, probs_p = big.forward_u8(ims[perm])
         np.testing.assert_array_equal(probs_p, probs[perm])
-        np.testing.assert_array_equal(big.tap("s7.bn", 256), s7[perm])
+        np.testing.assert_array_equal(big.tap("s8.bn", 256), s7[perm])
         ids_2, probs_2 = big.forward_u8(ims[perm])
         np.testing.assert_array_equal(probs_2, probs_p)
         # ragged tail: 255 and 1 images through the 256-image handle

@@ -5,7 +5,7 @@ set -euo pipefail
 ROOT="$(cd "$(dirname "${BASH_SOURCE[0]}")/.." && pwd)"
 SRC="$ROOT/roomnet_amd/csrc"; OBJ="$ROOT/build/obj"
 FLAGS=(--offload-arch=gfx950 -O3 -std=c++20 -fno-slp-vectorize -fPIC -fvisibility=hidden -I"$ROOT/include" -I"$SRC" -Wall -Wno-unused-function -DRN_BUILDING)
-ALL="rn_api rn_kernels_f32 rn_fused rn_imageops rn_group rn_tail rn_conv16 rn_stage_f32m rn_stage_rw rn_stage23 rn_stage23x rn_stage5x rn_stage4x rn_stage6x"
+ALL="rn_api rn_kernels_f32 rn_fused rn_imageops rn_group rn_tail rn_conv16 rn_stage_f32m rn_backend rn_stage_rw rn_stage23 rn_stage23x rn_stage5x rn_stage4x rn_stage6x"
 PIDS=()
 for f in "$@"; do
   extra=(); case $f in rn_stage_rw|rn_stage23|rn_stage23x|rn_stage5x|rn_stage4x|rn_stage6x) extra=(-mllvm -amdgpu-mfma-vgpr-form);; esac

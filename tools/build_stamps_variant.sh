@@ -10,7 +10,7 @@ OBJ="$ROOT/build/stamps_$NAME"; mkdir -p "$OBJ"
     -Wall -Wno-unused-function -Wno-unused-variable -Wno-unused-but-set-variable -DRN_BUILDING -DRN_STAMPS -mllvm -amdgpu-mfma-vgpr-form "$@" \
     -c "$SRC/$FILE.hip" -o "$OBJ/$FILE.o"
 OBJS=()
-for f in rn_api rn_kernels_f32 rn_fused rn_imageops rn_group rn_tail rn_conv16 rn_stage_rw rn_stage23 rn_stage23x rn_stage5x rn_stage4x rn_stage6x rn_stage_f32m; do
+for f in rn_api rn_kernels_f32 rn_fused rn_imageops rn_group rn_tail rn_conv16 rn_stage_rw rn_stage23 rn_stage23x rn_stage5x rn_stage4x rn_stage6x rn_stage_f32m rn_backend; do
   if [ "$f" = "$FILE" ]; then OBJS+=("$OBJ/$f.o"); else OBJS+=("$ROOT/build/stamps/$f.o"); fi
 done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC "${OBJS[@]}" -ldl -lpthread -o "$ROOT/roomnet_amd/lib/libroomnet_hip_stamps_$NAME.so"
