@@ -43,7 +43,11 @@ extern "C" {
 #define RN_E_RANGE (-5)     /* n exceeds max_batch, bad node id, buffer too small  */
 
 /* storage / MFMA input type of activations and conv weights.  float32 everywhere on
- * RN_DTYPE_F32 handles.  On the 16-bit handles: conv accumulation, ReLU6, BN, the vertical
+ * RN_DTYPE_F32 handles: without RN_FLAG_TAPS their conv stages 1-6 run as one launch each on the
+ * matrix cores (v_mfma_f32_32x32x2_f32: float32 in, float32 accumulate; rn_stage_f32m.hip), with
+ * RN_FLAG_TAPS as one launch per graph node (every node readable); the two differ only in the order
+ * of the convolution's K sum and of the pooling window sum (<= 2e-5 of a tensor's abs-max).
+ * On the 16-bit handles: conv accumulation, ReLU6, BN, the vertical
  * part of the residual interpolation, the dense head and the softmax are float32; what is
  * NOT float32 (all inside the tolerances of tests/test_hip_fused.py):
  *   - stage 0 feeds its MFMA fp16 inputs in BOTH 16-bit modes (bf16 cannot hold the 256
@@ -51,17 +55,17 @@ extern "C" {
  *   - avg-pool 4x4 stride 1 (stages 1-3): ReLU6 outputs are rounded to fp16, vertical pair
  *     sums are fp16 adds, and the window sums run on the matrix cores (fp16 x 0/1 band
  *     matrix, exact float32 accumulation); stride-2 pools are float32 VALU sums, except
- *     stages 4 and 5 at 224-class sizes (rn_stage4x.hip: 193-206 input columns,
- *     rn_stage5x.hip: 66-110), which pool like the stride-1 stages (fp16 ReLU6 outputs and
- *     pair sums, band-matrix MFMA);
+ *     stages 4 and 5 wherever the row-blocked kernels run (rn_stage4x.hip / rn_stage5x.hip: rows cut
+ *     into column blocks of 194-206 / 66-110 input columns -- 224, 420 and 600 inputs all qualify),
+ *     which pool like the stride-1 stages (fp16 ReLU6 outputs and pair sums, band-matrix MFMA);
  *   - every stage that pools fp16 values on the matrix cores (stages 1-3 always, 4 and 5 where
  *     the row-blocked kernels run) keeps its conv weights DIVIDED BY 6 (rounded to the 16-bit
  *     type after the division): relu6(6 x) / 6 = clamp(x, 0, 1) is then the free clamp of the
  *     fp16 conversion, and the folded BN scale carries the 6;
  *   - residual resize: the horizontal interpolation is an MFMA against the interpolation
- *     matrix in the storage type -- stage 3, and stage 5 at 224 x 224: one operand, lerp
+ *     matrix in the storage type -- stage 3, and stage 5 on the row-blocked kernel: one operand, lerp
  *     fraction rounded to 2^-8 (bf16) / 2^-11 (fp16) so that both weights are exact;
- *     stage 9, and stage 5 at other sizes: hi + lo split (~16-bit weights). */
+ *     stage 9, and stage 5 on the round-2 kernel (RN_FLAG_PAIR_32X32): hi + lo split (~16-bit weights). */
 #define RN_DTYPE_F32 0      /* reference arithmetic type (TensorFlow float32)      */
 #define RN_DTYPE_BF16 1
 #define RN_DTYPE_F16 2
@@ -73,7 +77,10 @@ extern "C" {
                                stage output "sK.bn"/"sK.bn2" materialised in HBM (per-stage
                                parity taps).  Default: stages are fused across their
                                boundaries where a kernel exists (the output of a stage
-                               that only feeds its fused successor is then never written) */
+                               that only feeds its fused successor is then never written:
+                               s0.bn, s2.bn; and, when a call carries at least half as many images
+                               as the device has CUs, s6.bn and s7.bn -- the back end then runs
+                               as one launch per image, rn_backend.hip; rn_tap refuses them) */
 #define RN_FLAG_GENERIC_KERNELS 4u /* 16-bit handles: every stage on the generic
                                stage_mfma_kernel (diagnostic cross-check of the tuned kernels) */
 #define RN_FLAG_PAIR_32X32 8u /* 16-bit handles: the round-2 kernels instead of the round-3 ones (comparison

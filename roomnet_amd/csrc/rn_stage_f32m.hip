@@ -163,6 +163,35 @@ __global__ __launch_bounds__(512) void stage_f32m_kernel(const F32StageArgs a) {
     for (int it = 0; it < nconv; ++it) {
         const bool have_next = it + 3 < nin;
         if (have_next) fetch_row(it + 3);
+        // which output row this conv row completes; a residual stage fetches the four skip neighbours of the lane's pixel NOW, in
+        // front of the row's MFMAs (at their point of use every emitted row waited for 16 dependent L2 round trips)
+        bool emit;
+        int yo;
+        if constexpr (PK > 0) {
+            emit = it >= PK - 1 && ((it - (PK - 1)) % PS) == 0;
+            yo = yo0 + (it - (PK - 1)) / PS;
+        } else {
+            emit = true;
+            yo = yo0 + it;
+        }
+        [[maybe_unused]] f32x4 sk_tl[NG], sk_tr[NG], sk_bl[NG], sk_br[NG];
+        [[maybe_unused]] float yl = 0.f;
+        if constexpr (RES) {
+            if (emit && lane_out) {
+                yl = a.rlerp[yo];
+                const float* skn = a.skip + static_cast<int64_t>(n) * a.Ss * a.Ss * COUT;
+                const float* sk0 = skn + static_cast<int64_t>(a.rlo[yo]) * a.Ss * COUT;
+                const float* sk1 = skn + static_cast<int64_t>(a.rhi[yo]) * a.Ss * COUT;
+#pragma unroll
+                for (int g = 0; g < NG; ++g) {
+                    const int c0 = cout_lane + 8 * g;
+                    sk_tl[g] = *reinterpret_cast<const f32x4*>(sk0 + rx_lo * COUT + c0);
+                    sk_tr[g] = *reinterpret_cast<const f32x4*>(sk0 + rx_hi * COUT + c0);
+                    sk_bl[g] = *reinterpret_cast<const f32x4*>(sk1 + rx_lo * COUT + c0);
+                    sk_br[g] = *reinterpret_cast<const f32x4*>(sk1 + rx_hi * COUT + c0);
+                }
+            }
+        }
 
         f32x16 acc;
 #pragma unroll
@@ -185,15 +214,6 @@ __global__ __launch_bounds__(512) void stage_f32m_kernel(const F32StageArgs a) {
         }
 
         // ---------------- ReLU6 + horizontal pool sum (lanes) + vertical pool sum (register ring)
-        bool emit;
-        int yo;
-        if constexpr (PK > 0) {
-            emit = it >= PK - 1 && ((it - (PK - 1)) % PS) == 0;
-            yo = yo0 + (it - (PK - 1)) / PS;
-        } else {
-            emit = true;
-            yo = yo0 + it;
-        }
         float tot[16];
 #pragma unroll
         for (int g = 0; g < 16; ++g) {
@@ -219,15 +239,6 @@ __global__ __launch_bounds__(512) void stage_f32m_kernel(const F32StageArgs a) {
         }
         if (emit) {
             constexpr float inv_area = PK ? 1.0f / static_cast<float>(PK * PK) : 1.0f;      // pool 4: exact (a power of two)
-            float yl = 0.f;
-            const float* sk0 = nullptr;
-            const float* sk1 = nullptr;
-            if constexpr (RES) {
-                yl = a.rlerp[yo];
-                const float* skn = a.skip + static_cast<int64_t>(n) * a.Ss * a.Ss * COUT;
-                sk0 = skn + static_cast<int64_t>(a.rlo[yo]) * a.Ss * COUT;
-                sk1 = skn + static_cast<int64_t>(a.rhi[yo]) * a.Ss * COUT;
-            }
             float* orow = a.out + ((static_cast<int64_t>(n) * a.Ho + yo) * a.Wo + xo) * COUT;
 #pragma unroll
             for (int g = 0; g < NG; ++g) {
@@ -244,10 +255,7 @@ __global__ __launch_bounds__(512) void stage_f32m_kernel(const F32StageArgs a) {
                     if (lane_out) {
                         const f32x4 t_mean2 = *reinterpret_cast<const f32x4*>(tl0 + 96), t_inv2 = *reinterpret_cast<const f32x4*>(tl0 + 128),
                                     t_beta2 = *reinterpret_cast<const f32x4*>(tl0 + 160);
-                        const f32x4 tl = *reinterpret_cast<const f32x4*>(sk0 + rx_lo * COUT + c0);
-                        const f32x4 tr = *reinterpret_cast<const f32x4*>(sk0 + rx_hi * COUT + c0);
-                        const f32x4 bl = *reinterpret_cast<const f32x4*>(sk1 + rx_lo * COUT + c0);
-                        const f32x4 br = *reinterpret_cast<const f32x4*>(sk1 + rx_hi * COUT + c0);
+                        const f32x4 tl = sk_tl[g], tr = sk_tr[g], bl = sk_bl[g], br = sk_br[g];
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
                             // resize_add_f32_kernel's expression, then the second BN

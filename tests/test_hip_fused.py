@@ -313,21 +313,21 @@ def test_randomized_batch_256_against_the_f32_hip_path(weights, record):
     try:
         ids, probs = big.forward_u8(ims)
         logits = big.tap("d3.relu", 256)
-        s7 = big.tap("s7.bn", 256)
+        s7 = big.tap("s8.bn", 256)              # (stages 6 and 7 stay in LDS at this batch: rn_backend.hip)
         s3 = big.tap("s3.bn2", 256)
         assert np.isfinite(logits).all() and np.isfinite(s7).all() and np.isfinite(s3).all()
         worst = worst_stage = 0.0
         for i in range(0, 256, 32):
             f32.forward_u8(ims[i:i + 32])
             ref_logits = f32.tap("d3.relu", 32)
-            ref_s7 = f32.tap("s7.bn", 32)
+            ref_s7 = f32.tap("s8.bn", 32)
             ref_s3 = f32.tap("s3.bn2", 32)
             worst = max(worst, float(np.abs(logits[i:i + 32] - ref_logits).max()))
             for got, want in ((s7[i:i + 32], ref_s7), (s3[i:i + 32], ref_s3)):
                 per_image = np.abs(got - want).reshape(32, -1).max(1) / max(float(np.abs(want).max()), 1e-6)
                 worst_stage = max(worst_stage, float(per_image.max()))
                 assert per_image.max() <= 2 * STAGE_TOL["bf16"], (i, per_image.argmax(), per_image.max())
-        record("random_256_images_224", "bf16_vs_float32_hip_path", {"max_abs_dlogit": worst, "max_stage_rel_err_s3_s7": worst_stage})
+        record("random_256_images_224", "bf16_vs_float32_hip_path", {"max_abs_dlogit": worst, "max_stage_rel_err_s3_s8": worst_stage})
         assert worst <= TOL_LOGITS, worst
         np.testing.assert_allclose(probs.sum(1), 1.0, atol=1e-5)
     finally:

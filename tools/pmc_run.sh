@@ -11,6 +11,6 @@ for p in 1 2; do
   rocprofv3 --pmc $C -d /tmp/pmc$p -o pmc --output-format csv -- python3 $R/bench.py --steps 2 --warmup 1 --spinup-steps 0 --no-cpu-baseline --profile-steps 1 > /tmp/pmc$p.log 2>&1
   f=$(ls /tmp/pmc$p/*/*counter_collection.csv 2>/dev/null | head -1); [ -z "$f" ] && f=$(ls /tmp/pmc$p/*counter_collection.csv | head -1)
   mkdir -p /tmp/pmcd$p/x; cp $f /tmp/pmcd$p/x/pmc_counter_collection.csv
-  grep -E "stage|head|tail|conv16|Counter_Name" $f > $R/gpurun_out/${tag}_sq$p.csv
+  grep -E "stage|head|tail|conv16|backend|Counter_Name" $f > $R/gpurun_out/${tag}_sq$p.csv
 done
 python3 $R/tools/pmc_summary.py /tmp/pmcd1 /tmp/pmcd2

@@ -7,8 +7,8 @@ for d in sys.argv[1:]:
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
     for r in csv.DictReader(open(f)):
         name = r['Kernel_Name']
-        if 'stage' not in name and 'head' not in name and 'tail' not in name and 'conv16' not in name: continue
-        key = name[max(name.find('stage'), name.find('tail_kernel'), name.find('conv16_kernel')):name.find('>') + 1] if '<' in name else name[:30]
+        if 'stage' not in name and 'head' not in name and 'tail' not in name and 'conv16' not in name and 'backend' not in name: continue
+        key = name[max(name.find('stage'), name.find('tail_kernel'), name.find('conv16_kernel'), name.find('backend_kernel')):name.find('>') + 1] if '<' in name else name[:30]
         agg[key][r['Counter_Name']].append(float(r['Counter_Value']))
         res[key]['vgpr'] = r['VGPR_Count']; res[key]['lds'] = r['LDS_Block_Size']; res[key]['wg'] = r['Workgroup_Size']; res[key]['grid'] = r['Grid_Size']
     for k, v in agg.items():

@@ -16,7 +16,7 @@ for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/p_$c && rocprofv3 --pmc $c -d /tmp/p_$c -o p --output-format csv -- python3 $R/bench.py --steps 3 --warmup 1 --spinup-steps 0 --no-cpu-baseline --profile-steps 1 > /tmp/p_$c.log 2>&1
   f=$(find /tmp/p_$c -name "*counter_collection.csv" | head -1)
   lc=$(echo $c | tr A-Z a-z)
-  grep -E "stage|head|tail|conv16|Counter_Name" "$f" > $O/${tag}_pmc_${lc}.csv
+  grep -E "stage|head|tail|conv16|backend|Counter_Name" "$f" > $O/${tag}_pmc_${lc}.csv
 done
 python3 $R/tools/hbm_traffic.py $O/${tag}_pmc_fetch_size.csv $O/${tag}_pmc_write_size.csv > $O/${tag}_hbm_traffic.json
 cp $O/${tag}_hbm_traffic.json $R/profiles/${tag}_hbm_traffic.json
