@@ -10,9 +10,14 @@
 //   waves 0-7   stage 6 exactly as rn_stage6x.hip (row-register blocking: wave = 16 couts x the row's three 16-pixel tiles, the
 //               newest input row feeds three live accumulator sets), but a finished conv row (ReLU6 + BN, 16-bit) goes into a
 //               four-row LDS ring ("mid") instead of HBM, in the 256-byte-pixel layout and chunk swizzle conv16p reads;
-//   waves 8-10  stage 7 exactly as conv16p_kernel (one wave = one 16-pixel tile x all 16 couts, 36 K-chunks in two chains, DPP
-//               pooling), three steps behind stage 6: operands from the mid ring, weight fragments from LDS (36 KB; in
-//               registers they are 144 per lane, and three waves per SIMD leave 168); its pooled rows go into an LDS image;
+//   waves 8-10  stage 7 with conv16p_kernel's arithmetic (16-pixel tiles x all 16 couts, 36 K-chunks, DPP pooling), split by KERNEL
+//               ROW: wave 8 + ky holds the 12 weight fragments of kernel row ky in registers (all 36 are 144 per lane: three waves
+//               per SIMD leave 168) and turns the NEWEST mid row r into the partial sums of conv row r - ky for the three tiles
+//               (36 MFMAs); the partials meet in LDS, and one step later wave 8 + t adds the three partials of tile t in the
+//               fixed order (P0 + P1) + P2 -- conv16p_kernel sums the same way -- pools them and writes the pooled row into an
+//               LDS image.  Only the newest mid row is ever read: two ring rows.  (First form: one wave per tile reading all
+//               36 weight fragments from LDS every row: 216 KB of LDS reads per step next to stage 6's 144 slowed the loop
+//               from 73 to 100 us.)
 //   waves 0-3   then run the tail (rn_tail_body.h) on that image.
 // One s_barrier per step; stage 7 adds a third wave to three of the four SIMDs whose matrix pipe stage 6 left 45 % idle.
 // Same arithmetic, operand values and summation order as the three launches: bit-identical (tests/test_hip_fused.py).
@@ -28,14 +33,15 @@ namespace {
 constexpr int B_NS = 4, B_AHEAD = 3;             // stage-6 input ring: newest row + 3 in flight
 constexpr int B_ROW6 = 52 * 128;                 // bytes per input ring row (64 channels x 16 bit, 52 pixels)
 constexpr int B_WMIN = 35, B_WMAX = 50;          // stage-6 input side (rn_stage6x.hip)
-constexpr int B_NM = 4;                          // mid ring rows: three being read by stage 7 + the one being written
+constexpr int B_NM = 2;                          // mid ring rows: the one stage 7 reads + the one being written
 constexpr int B_ROWM = 48 * 256;                 // bytes per mid row (128 channels x 16 bit, 48 pixels)
 constexpr int B_KC7 = 36;                        // stage-7 K chunks of 32 (9 taps x 4 channel quarters)
-constexpr int B_LAG = 5;                         // step s computes stage-7 conv row s - B_LAG
+constexpr int B_NP = 4;                          // partial-sum slots (conv rows in flight between their first partial and their sum)
+constexpr int B_LAG = 6;                         // step s finishes stage-7 conv row s - B_LAG
 constexpr int B_OFF_RING6 = 0;
 constexpr int B_OFF_MID = B_OFF_RING6 + B_NS * B_ROW6;
-constexpr int B_OFF_W7 = B_OFF_MID + B_NM * B_ROWM;
-constexpr int B_OFF_X7 = B_OFF_W7 + B_KC7 * 1024;            // stage-7 output image [So7][So7][16], So7 <= 22
+constexpr int B_OFF_PART = B_OFF_MID + B_NM * B_ROWM;         // partial sums [B_NP conv rows][3 kernel rows][3 tiles] x 1 KB (fp32 16x16)
+constexpr int B_OFF_X7 = B_OFF_PART + B_NP * 9 * 1024;        // stage-7 output image [So7][So7][16], So7 <= 22
 constexpr int B_OFF_XA = B_OFF_X7 + 16384;                    // tail: second step's output [16][16][16]
 constexpr int B_OFF_XB = B_OFF_XA + 16 * 16 * 16 * 2;         // third step's output [8][8][16]
 constexpr int B_OFF_BUF0 = B_OFF_XB + 8 * 8 * 16 * 2;
@@ -94,14 +100,12 @@ __global__ __launch_bounds__(704) void backend_kernel(const BackendArgs a) {
     char* const ring6 = smem + B_OFF_RING6;
     char* const mid = smem + B_OFF_MID;
     const unsigned mid_lds = lds_addr(mid);
-    // ---- prologue work shared by all waves: zero the input-ring pixels the row DMA never writes, stage the stage-7 weight
-    // fragments and the dense kernels in LDS
+    // ---- prologue work shared by all waves: zero the input-ring pixels the row DMA never writes, stage the dense kernels in LDS
     for (int i = tid; i < B_NS * (52 - B_WMIN) * 8; i += 704) {
         const int slot = i / ((52 - B_WMIN) * 8), rest = i % ((52 - B_WMIN) * 8);
         const int p = B_WMIN + rest / 8, c = rest % 8;
         if (p >= W) *reinterpret_cast<i32x4*>(ring6 + slot * B_ROW6 + p * 128 + c * 16) = i32x4{0, 0, 0, 0};
     }
-    for (int i = tid; i < B_KC7 * 64; i += 704) reinterpret_cast<i32x4*>(smem + B_OFF_W7)[i] = a.wfrag7[i];
     int w_off[RN_MAX_DENSE];
     tail_stage_dense(a.tail.head, reinterpret_cast<float*>(smem + B_OFF_WL), w_off, tid, 704);
 
@@ -246,18 +250,27 @@ __global__ __launch_bounds__(704) void backend_kernel(const BackendArgs a) {
         if (rem > 1) step(IC<1>{}, s + 1);
         wait_vmcnt<0>();
     } else {
-        // =============================================================== stage 7 (conv16p_kernel), operands from the mid ring
-        const int t = wave - 8;                                  // pixel tile: conv columns 14 t .. 14 t + 15, pooled 7 t .. 7 t + 6
+        // =============================================================== stage 7 (conv16p_kernel's arithmetic), split by kernel row
+        const int t = wave - 8;                                  // kernel row of the MFMA phase, pixel tile of the pooling phase
         const int i16 = px16, kg = g;
-        const unsigned w7_lds = lds_addr(smem + B_OFF_W7) + static_cast<unsigned>(lane) * 16u;
-        unsigned boff[3][4];
+        i32x4 w7[12];                                            // fragments of kernel row t: chunk c = kx * 4 + q
 #pragma unroll
-        for (int kx = 0; kx < 3; ++kx)
+        for (int c = 0; c < 12; ++c) {
+            const i32x4* src = a.wfrag7 + (t * 12 + c) * 64 + lane;
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(w7[c]) : "v"(src) : "memory");
+        }
+        unsigned boff[3][3][4];                                  // [tile][kx][channel quarter]
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int p = min(14 * t + i16 + kx, 47);
-                boff[kx][q] = mid_lds + static_cast<unsigned>(p * 256 + (((4 * q + kg) ^ swz16(p)) << 4));
-            }
+        for (int k = 0; k < 3; ++k)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int p = min(14 * k + i16 + kx, 47);
+                    boff[k][kx][q] = mid_lds + static_cast<unsigned>(p * 256 + (((4 * q + kg) ^ swz16(p)) << 4));
+                }
+        char* const part = smem + B_OFF_PART;
+        const unsigned part_lds = lds_addr(part) + static_cast<unsigned>(lane) * 16u;
         const f32x4 sc = *reinterpret_cast<const f32x4*>(a.ptab7 + 4 * kg);
         const f32x4 sh = *reinterpret_cast<const f32x4*>(a.ptab7 + 16 + 4 * kg);
         const int So7 = a.So7;
@@ -268,38 +281,25 @@ __global__ __launch_bounds__(704) void backend_kernel(const BackendArgs a) {
         const char* out_row = reinterpret_cast<const char*>(a.out7 ? a.out7 + static_cast<int64_t>(n) * So7 * So7 * 16 : nullptr);
         char* const x7 = smem + B_OFF_X7;
         float hprev[4] = {0.f, 0.f, 0.f, 0.f}, q0[4] = {0.f, 0.f, 0.f, 0.f};
+        wait_vmcnt<0>();
+#pragma unroll
+        for (int c = 0; c < 12; ++c) asm volatile("" : "+v"(w7[c]));
         lds_barrier();                                           // (the prologue barrier of the stage-6 waves)
         for (int s = 0; s < nsteps; ++s) {
             raw_barrier();
-            const int j7 = s - B_LAG;
-            if (j7 >= 0 && j7 < nconv7) {
-                unsigned so[3];
-#pragma unroll
-                for (int ky = 0; ky < 3; ++ky) so[ky] = static_cast<unsigned>(((j7 + ky) & (B_NM - 1)) * B_ROWM);
-                f32x4 acc[2];
-                constexpr int RD = 4;                            // operand pairs in flight + 1
-                i32x4 bq[RD], aq[RD];
-                auto rd = [&](auto CC, i32x4& av, i32x4& bv) __attribute__((always_inline)) {
-                    constexpr int C = decltype(CC)::value;
-                    constexpr int tap = C / 4, q = C % 4, ky = tap / 3, kx = tap % 3;
-                    const unsigned ad = boff[kx][q] + so[ky], wa = w7_lds;
-                    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(av) : "v"(wa), "n"(C * 1024));
-                    asm volatile("ds_read_b128 %0, %1" : "=v"(bv) : "v"(ad));
-                };
-                [&]<int... C>(std::integer_sequence<int, C...>) { (rd(IC<C>{}, aq[C], bq[C]), ...); }(std::make_integer_sequence<int, RD - 1>{});
-                [&]<int... C>(std::integer_sequence<int, C...>) {
-                    (([&] {
-                         if constexpr (C + RD - 1 < B_KC7) rd(IC<(C + RD - 1 < B_KC7 ? C + RD - 1 : 0)>{}, aq[(C + RD - 1) % RD], bq[(C + RD - 1) % RD]);
-                         constexpr int newer = 2 * ((B_KC7 - 1 - C) < RD - 1 ? (B_KC7 - 1 - C) : RD - 1);
-                         asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(aq[C % RD]), "+v"(bq[C % RD]) : "n"(newer));
-                         acc[C & 1] = mfma16<DT>(aq[C % RD], bq[C % RD], C < 2 ? zero4 : acc[C & 1]);     // two chains: even / odd chunks
-                     }()),
-                     ...);
-                }(std::make_integer_sequence<int, B_KC7>{});
+            // ---- pooling phase first (its reads are of partials written in earlier steps): conv row je is complete
+            const int je = s - B_LAG;
+            if (je >= 0 && je < nconv7) {
+                const unsigned pa = part_lds + static_cast<unsigned>(((je & (B_NP - 1)) * 9 + t) * 1024);
+                f32x4 p0, p1, p2;
+                asm volatile("ds_read_b128 %0, %1" : "=v"(p0) : "v"(pa));
+                asm volatile("ds_read_b128 %0, %1 offset:3072" : "=v"(p1) : "v"(pa));
+                asm volatile("ds_read_b128 %0, %1 offset:6144" : "=v"(p2) : "v"(pa));
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(p0), "+v"(p1), "+v"(p2));
                 float v[4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = relu6f(acc[0][j] + acc[1][j]);
-                if (j7 & 1) {
+                for (int j = 0; j < 4; ++j) v[j] = relu6f((p0[j] + p1[j]) + p2[j]);
+                if (je & 1) {
                     float y[4];
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
@@ -310,8 +310,8 @@ __global__ __launch_bounds__(704) void backend_kernel(const BackendArgs a) {
                         const float H = u + row_next<2>(u);
                         y[j] = fmaf(H, sc[j], sh[j]);
                     }
-                    if (j7 >= 3) {
-                        const int r = (j7 - 3) >> 1;                 // pooled row
+                    if (je >= 3) {
+                        const int r = (je - 3) >> 1;                 // pooled row
                         const i32x2 d = {static_cast<int>(pack2<DT>(y[0], y[1])), static_cast<int>(pack2<DT>(y[2], y[3]))};
                         if (lane_out) *reinterpret_cast<i32x2*>(x7 + ((r * So7 + xo) * 16 + 4 * kg) * 2) = d;
                         const __amdgpu_buffer_rsrc_t rs =
@@ -322,6 +322,39 @@ __global__ __launch_bounds__(704) void backend_kernel(const BackendArgs a) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) hprev[j] = v[j];
                 }
+            }
+            // ---- MFMA phase: the newest visible mid row r (stage 6 wrote it during the previous step) as kernel row t of conv
+            // row r - t, for the three tiles
+            const int r = s - 3;
+            const int jc = r - t;
+            if (r >= 0 && r < Wo && jc >= 0 && jc < nconv7) {
+                const unsigned so = static_cast<unsigned>((r & (B_NM - 1)) * B_ROWM);
+                const int pw_off = ((jc & (B_NP - 1)) * 9 + 3 * t) * 1024 + lane * 16;
+                auto tile = [&](auto KC) __attribute__((always_inline)) {
+                    constexpr int k = decltype(KC)::value;
+                    i32x4 bq[12];
+                    auto rdb = [&](auto CC) __attribute__((always_inline)) {
+                        constexpr int C = decltype(CC)::value;
+                        auto& dst = bq[C];                                  // (named outside the asm: implicit capture)
+                        const unsigned ad = boff[k][C / 4][C % 4] + so;
+                        asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(ad));
+                    };
+                    [&]<int... C>(std::integer_sequence<int, C...>) { (rdb(IC<C>{}), ...); }(std::make_integer_sequence<int, 12>{});
+                    f32x4 acc = zero4;
+                    auto mm = [&](auto CC) __attribute__((always_inline)) {
+                        constexpr int C = decltype(CC)::value;
+                        auto& src = bq[C];
+                        asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(src) : "n"(11 - C));
+                        acc = mfma16<DT>(w7[C], src, acc);                  // chunks of the kernel row in order: kx * 4 + q
+                    };
+                    [&]<int... C>(std::integer_sequence<int, C...>) { (mm(IC<C>{}), ...); }(std::make_integer_sequence<int, 12>{});
+                    // (a compiler-visible store: the matrix core's result registers need wait states before an LDS instruction may
+                    //  read them, and hipcc pads no hazards between its own instructions and the inside of an asm string)
+                    *reinterpret_cast<f32x4*>(part + pw_off + k * 1024) = acc;
+                };
+                tile(IC<0>{});
+                tile(IC<1>{});
+                tile(IC<2>{});
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }

@@ -320,7 +320,8 @@ __global__ __launch_bounds__(64 * P16_NT, 2) void conv16p_kernel(const Conv16Arg
         wait_vmcnt<2 * P16_PIECES>();
         raw_barrier();
         issue_row(s + C16_AHEAD, (P + C16_AHEAD) % C16_NSLOT);
-        f32x4v acc[2];
+        f32x4v acc[3];                                   // one chain per kernel row, summed (ky 0 + ky 1) + ky 2: the order the
+                                                         // one-launch back end (rn_backend.hip) adds its per-kernel-row partials in
         // operand reads run P16_RD - 1 chunks ahead of their MFMA behind counted waits (round 4: with one read in flight every
         // MFMA stood behind an LDS round trip: 36 x ~100 cycles per row for 576 cycles of matrix work)
         constexpr int RD = P16_RD;
@@ -339,14 +340,14 @@ __global__ __launch_bounds__(64 * P16_NT, 2) void conv16p_kernel(const Conv16Arg
                  if constexpr (C + RD - 1 < P16_KC) rd(IC<(C + RD - 1 < P16_KC ? C + RD - 1 : 0)>{}, bq[(C + RD - 1) % RD]);
                  constexpr int newer = (P16_KC - 1 - C) < RD - 1 ? (P16_KC - 1 - C) : RD - 1;
                  asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(bq[C % RD]) : "n"(newer));
-                 acc[C & 1] = mfma16<DT>(wr[C], bq[C % RD], C < 2 ? zero : acc[C & 1]);     // two chains: even / odd chunks
+                 acc[C / 12] = mfma16<DT>(wr[C], bq[C % RD], C % 12 == 0 ? zero : acc[C / 12]);
              }()),
              ...);
         }(std::make_integer_sequence<int, P16_KC>{});
         // ReLU6 -> vertical 4-row sums on the odd rows -> horizontal 4-column sums inside the 16-lane DPP row -> BN
         float v[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = relu6f(acc[0][j] + acc[1][j]);
+        for (int j = 0; j < 4; ++j) v[j] = relu6f((acc[0][j] + acc[1][j]) + acc[2][j]);
         int vo = OOB;
         float y[4] = {0.f, 0.f, 0.f, 0.f};
         if constexpr ((P & 1) == 1) {

@@ -575,6 +575,38 @@ def test_row_blocked_stage_kernels_match_the_round2_kernels_at_their_geometry_ed
             ref.close()
 
 
+@pytest.mark.parametrize("side", [212, 219, 225, 232])
+def test_one_launch_back_end_at_its_geometry_edges(weights, side):
+    """rn_backend.hip runs stage 6 -> head as one launch per image where stage 6's input is 35-50 columns wide (one column block) and
+    the call carries at least half a chip of images.  Other 224-class sides: 130 images through the default handle (back end
+    fused where it applies: checked through the launch grouping) against the same images in chunks of 8 (always the banded
+    launches): bit-identical results."""
+    from oracle import roomnet_ref as R
+    from roomnet_amd.synth import parity_batch
+    g = build_graph(6, side)
+    w = dict(weights)
+    w["dense/kernel"] = R.synth_dense_kernel_600(g.flat_len)
+    base = parity_batch(side, seed=3)
+    nb = 130
+    ims = base[(np.arange(nb) * 7) % len(base)]
+    big = _capi.Engine(g, w, device=0, dtype="bf16", max_batch=nb)
+    small = _capi.Engine(g, w, device=0, dtype="bf16", max_batch=8)
+    try:
+        ids, probs = big.forward_u8(ims)
+        fused = big.launch_groups()[-1] == [6, 7, 8, 9]
+        s6_in = g.stages[6].in_side
+        assert fused == (35 <= s6_in <= 50 and g.stages[7].out_side <= 21), (side, s6_in, big.launch_groups())
+        last = big.tap("s9.bn2", nb)
+        for i in range(0, nb, 8):
+            ids8, probs8 = small.forward_u8(ims[i:i + 8])
+            np.testing.assert_array_equal(probs[i:i + 8], probs8)
+            np.testing.assert_array_equal(ids[i:i + 8], ids8)
+            np.testing.assert_array_equal(last[i:i + 8], small.tap("s9.bn2", len(ids8)))
+    finally:
+        big.close()
+        small.close()
+
+
 def test_results_are_reproducible_run_to_run(engine, parity_images):
     """Every kernel synchronises its LDS rings with counted waits and bare barriers; a race shows as run-to-run noise
     (one was found that way in a stage-5 variant that never shipped).  Six passes over the same batch must agree bit for
