@@ -229,10 +229,8 @@ constexpr int P16_RINGW = 14 * (P16_NT - 1) + 18;  // input columns a block read
 constexpr int P16_PIECES = 4;                      // DMA pieces of 192 lanes x 16 B per row (46 px x 16 chunks = 736 <= 768)
 constexpr int P16_ROWB = P16_PIECES * 64 * P16_NT * 16;
 constexpr int P16_KC = 36;
-#ifndef RN_P16_RD
-#define RN_P16_RD 6
-#endif
-constexpr int P16_RD = RN_P16_RD;                  // operand fragments in flight + 1
+constexpr int P16_RD = 4;                          // operand fragments in flight + 1 (2 / 4 / 6 / 8 measured the same 30 us at batch
+                                                   // 256: the launch is bound by re-reading stage 6's output from HBM, 4.6 TB/s)
 constexpr int P16_LDS = C16_NSLOT * P16_ROWB;
 static_assert(P16_RINGW * 16 <= P16_PIECES * 64 * P16_NT, "a ring row fits its DMA pieces");
 
@@ -322,8 +320,7 @@ __global__ __launch_bounds__(64 * P16_NT, 2) void conv16p_kernel(const Conv16Arg
         issue_row(s + C16_AHEAD, (P + C16_AHEAD) % C16_NSLOT);
         f32x4v acc[3];                                   // one chain per kernel row, summed (ky 0 + ky 1) + ky 2: the order the
                                                          // one-launch back end (rn_backend.hip) adds its per-kernel-row partials in
-        // operand reads run P16_RD - 1 chunks ahead of their MFMA behind counted waits (round 4: with one read in flight every
-        // MFMA stood behind an LDS round trip: 36 x ~100 cycles per row for 576 cycles of matrix work)
+        // operand reads run P16_RD - 1 chunks ahead of their MFMA behind counted waits
         constexpr int RD = P16_RD;
         i32x4 bq[RD];
         auto rd = [&](auto CC, i32x4& b) __attribute__((always_inline)) {
