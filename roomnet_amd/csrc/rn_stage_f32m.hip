@@ -44,6 +44,7 @@ struct F32StageArgs {
     const float* rlerp;
     int H, W, Ho, Wo, Ss;
     int rows_per_band, n_bands, n_colblocks, n_ctg, npt;
+    int ringcols;                 // columns of a ring row: (npt - 1) tile strides + 34, but never more than the input row
 };
 
 __device__ __forceinline__ f32x16 mfma_f32(float a, float b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
@@ -51,7 +52,9 @@ __device__ __forceinline__ f32x16 mfma_f32(float a, float b, f32x16 c) { return 
 // NSL = ring slots: 4 (three live rows + the one being filled behind the compute) or 3 (the fill waits behind a second barrier:
 // the 64-channel stages, whose weights take 72 KB of the LDS)
 // LPT = 16-byte chunks of a ring row one thread fetches (the host sizes the workgroup so that ringcols * CIN / 4 <= LPT * threads)
-template <int CIN, int COUT, int PK, int PS, bool RES, int NSL, int LPT>
+// KS = waves per pixel tile: 2 = the tile's K sum is split by channel halves over two waves (the 64 -> 128 stage has two tiles per
+// row: two waves would leave half the CU's matrix pipes idle); the second wave's partial accumulators cross through LDS
+template <int CIN, int COUT, int PK, int PS, bool RES, int NSL, int LPT, int KS>
 __global__ __launch_bounds__(512) void stage_f32m_kernel(const F32StageArgs a) {
     constexpr int CP = CIN / 4;                          // 16-byte chunks (4 floats) per pixel
     constexpr int KQ = CIN / 8;                          // chunk pairs per tap = ds_read_b128 per tap and lane
@@ -68,7 +71,8 @@ __global__ __launch_bounds__(512) void stage_f32m_kernel(const F32StageArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave = wave_all / KS, kh = wave_all % KS;      // pixel tile / K half of this wave
     const int r = lane & 31, hh = lane >> 5;
     const int nthreads = blockDim.x;
     const int npt = a.npt;
@@ -80,11 +84,14 @@ __global__ __launch_bounds__(512) void stage_f32m_kernel(const F32StageArgs a) {
     const int band = bid / a.n_colblocks;
     const int n = blockIdx.y;
 
-    const int ringcols = (npt - 1) * TSTRIDE + 34;
+    // (a ring row never holds more columns than the input has: the last tile's lanes right of the image then read past the row
+    //  -- other rows' activations, or zero past the workgroup's LDS -- and only feed output columns that are not stored)
+    const int ringcols = a.ringcols;
     const int rowbytes = ringcols * PIXB;
     char* const wl = smem;                                  // weights [KC][64] x 16 B of this workgroup's cout tile
     float* const tabs = reinterpret_cast<float*>(smem + KC * 1024);      // [6][32] per-channel tables of this cout tile
     char* const ring = smem + KC * 1024 + 1024;             // NSL rows
+    [[maybe_unused]] char* const pbuf = ring + NSL * (a.ringcols * CIN * 4) + wave * 4096 + lane * 16;      // KS == 2: partial sums, 4 KB per tile
 
     const int yo0 = band * a.rows_per_band;
     const int yo1 = min(a.Ho, yo0 + a.rows_per_band);
@@ -205,6 +212,7 @@ __global__ __launch_bounds__(512) void stage_f32m_kernel(const F32StageArgs a) {
             const char* pb = rowp[ky] + boff[kx];
 #pragma unroll
             for (int q = 0; q < KQ; ++q) {
+                if (KS == 2 && (q & 1) != kh) continue;     // (wave-uniform: this wave's channel half)
                 const int c4 = 2 * q + hh;
                 const f32x4 b = *reinterpret_cast<const f32x4*>(pb + ((c4 ^ bswz[kx]) << 4));
                 const f32x4 wv = *reinterpret_cast<const f32x4*>(wl_lane + (tap * KQ + q) * 1024);
@@ -214,6 +222,22 @@ __global__ __launch_bounds__(512) void stage_f32m_kernel(const F32StageArgs a) {
         }
 
         // ---------------- ReLU6 + horizontal pool sum (lanes) + vertical pool sum (register ring)
+        if constexpr (KS == 2) {
+            // the second wave of the tile hands its partial sums over; the first adds them (fixed order) and runs the epilogue
+            if (kh == 1) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(pbuf + i * 1024) = f32x4{acc[4 * i], acc[4 * i + 1], acc[4 * i + 2], acc[4 * i + 3]};
+            }
+            __syncthreads();
+            if (kh == 0) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const f32x4 p = *reinterpret_cast<const f32x4*>(pbuf + i * 1024);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[4 * i + j] += p[j];
+                }
+            }
+        }
         float tot[16];
 #pragma unroll
         for (int g = 0; g < 16; ++g) {
@@ -237,7 +261,7 @@ __global__ __launch_bounds__(512) void stage_f32m_kernel(const F32StageArgs a) {
             }
             tot[g] = s;
         }
-        if (emit) {
+        if (emit && kh == 0) {
             constexpr float inv_area = PK ? 1.0f / static_cast<float>(PK * PK) : 1.0f;      // pool 4: exact (a power of two)
             float* orow = a.out + ((static_cast<int64_t>(n) * a.Ho + yo) * a.Wo + xo) * COUT;
 #pragma unroll
@@ -279,7 +303,7 @@ __global__ __launch_bounds__(512) void stage_f32m_kernel(const F32StageArgs a) {
 struct F32mStage {
     bool on = false;
     f32x4* wfrag = nullptr;
-    int variant = -1, npt = 1, n_colblocks = 1, n_ctg = 1, nsl = 4;
+    int variant = -1, npt = 1, n_colblocks = 1, n_ctg = 1, nsl = 4, ringcols = 34;
     size_t lds = 0;
 };
 
@@ -289,9 +313,9 @@ struct F32mState {
 
 using F32LaunchFn = void (*)(const F32StageArgs&, dim3, dim3, size_t, hipStream_t);
 
-template <int CIN, int COUT, int PK, int PS, bool RES, int NSL, int LPT>
+template <int CIN, int COUT, int PK, int PS, bool RES, int NSL, int LPT, int KS>
 void launch_f32m(const F32StageArgs& a, dim3 grid, dim3 block, size_t lds, hipStream_t s) {
-    auto kern = stage_f32m_kernel<CIN, COUT, PK, PS, RES, NSL, LPT>;
+    auto kern = stage_f32m_kernel<CIN, COUT, PK, PS, RES, NSL, LPT, KS>;
     static std::atomic<unsigned long long> attr_devices{0};
     int dev = 0;
     (void)hipGetDevice(&dev);
@@ -303,16 +327,16 @@ void launch_f32m(const F32StageArgs& a, dim3 grid, dim3 block, size_t lds, hipSt
 }
 
 struct F32Variant {
-    int cin, cout, pk, ps, res, nsl, lpt;
+    int cin, cout, pk, ps, res, nsl, lpt, ks;
     F32LaunchFn fn;
 };
 const F32Variant kF32Variants[] = {
-    {8, 32, 4, 1, 0, 4, 4, launch_f32m<8, 32, 4, 1, false, 4, 4>},        // stage 1
-    {32, 32, 4, 1, 0, 4, 4, launch_f32m<32, 32, 4, 1, false, 4, 4>},      // stage 2
-    {32, 32, 4, 1, 1, 4, 4, launch_f32m<32, 32, 4, 1, true, 4, 4>},       // stage 3
-    {32, 64, 4, 2, 0, 4, 4, launch_f32m<32, 64, 4, 2, false, 4, 4>},      // stage 4
-    {64, 64, 4, 2, 1, 3, 8, launch_f32m<64, 64, 4, 2, true, 3, 8>},       // stage 5
-    {64, 128, 0, 1, 0, 3, 10, launch_f32m<64, 128, 0, 1, false, 3, 10>},  // stage 6
+    {8, 32, 4, 1, 0, 4, 4, 1, launch_f32m<8, 32, 4, 1, false, 4, 4, 1>},        // stage 1
+    {32, 32, 4, 1, 0, 4, 4, 1, launch_f32m<32, 32, 4, 1, false, 4, 4, 1>},      // stage 2
+    {32, 32, 4, 1, 1, 4, 4, 1, launch_f32m<32, 32, 4, 1, true, 4, 4, 1>},       // stage 3
+    {32, 64, 4, 2, 0, 4, 4, 1, launch_f32m<32, 64, 4, 2, false, 4, 4, 1>},      // stage 4
+    {64, 64, 4, 2, 1, 3, 8, 1, launch_f32m<64, 64, 4, 2, true, 3, 8, 1>},       // stage 5
+    {64, 128, 0, 1, 0, 3, 8, 2, launch_f32m<64, 128, 0, 1, false, 3, 8, 2>},    // stage 6
 };
 
 }  // namespace
@@ -346,16 +370,15 @@ int rn_f32m_prepare(rn_handle* h, const rn_weights* w) {
         const int tiles = (s.out_side + nout_t - 1) / nout_t;
         f.npt = std::min(tiles, 8);
         for (;;) {
-            const int ringcols = (f.npt - 1) * tstride + 34;
-            f.lds = static_cast<size_t>(kc) * 1024 + 1024 + static_cast<size_t>(f.nsl) * ringcols * s.cin * 4;
-            const int chunks = ringcols * (s.cin / 4);
-            if ((f.lds <= 160 * 1024 && chunks <= kF32Variants[f.variant].lpt * 64 * f.npt) || f.npt == 1) break;
+            f.ringcols = std::min((f.npt - 1) * tstride + 34, s.in_side);
+            const int ks = kF32Variants[f.variant].ks;
+            f.lds = static_cast<size_t>(kc) * 1024 + 1024 + static_cast<size_t>(f.nsl) * f.ringcols * s.cin * 4 + (ks == 2 ? f.npt * 4096 : 0);
+            const int chunks = f.ringcols * (s.cin / 4);
+            if ((f.lds <= 160 * 1024 && chunks <= kF32Variants[f.variant].lpt * 64 * f.npt * ks && f.npt * ks <= 8) || f.npt == 1) break;
             --f.npt;
         }
-        {
-            const int ringcols = (f.npt - 1) * tstride + 34;
-            if (f.lds > 160 * 1024 || ringcols * (s.cin / 4) > kF32Variants[f.variant].lpt * 64 * f.npt) continue;      // not coverable
-        }
+        if (f.lds > 160 * 1024 || f.ringcols * (s.cin / 4) > kF32Variants[f.variant].lpt * 64 * f.npt * kF32Variants[f.variant].ks)
+            continue;      // not coverable
         f.n_colblocks = (tiles + f.npt - 1) / f.npt;
         f.n_ctg = ct_n;
         std::vector<float> frag(static_cast<size_t>(kc) * ct_n * 64 * 4, 0.f);
@@ -412,6 +435,7 @@ int rn_f32m_launch(rn_handle* h, int stage, const float* in, int n) {
     a.H = a.W = s.in_side;
     a.Ho = a.Wo = s.out_side;
     a.npt = f.npt;
+    a.ringcols = f.ringcols;
     a.n_colblocks = f.n_colblocks;
     a.n_ctg = f.n_ctg;
     // bands: whole rounds of the chip (one workgroup per CU: the weights and the ring fill most of its LDS); a band costs its
@@ -432,7 +456,7 @@ int rn_f32m_launch(rn_handle* h, int stage, const float* in, int n) {
     if (per_band * bands < h->n_cu) bands = static_cast<int>(std::min<long>((h->n_cu + per_band - 1) / per_band, max_bands));
     a.rows_per_band = (s.out_side + bands - 1) / bands;
     a.n_bands = (s.out_side + a.rows_per_band - 1) / a.rows_per_band;
-    kF32Variants[f.variant].fn(a, dim3(a.n_bands * a.n_colblocks * a.n_ctg, n), dim3(64 * f.npt), f.lds, h->stream);
+    kF32Variants[f.variant].fn(a, dim3(a.n_bands * a.n_colblocks * a.n_ctg, n), dim3(64 * f.npt * kF32Variants[f.variant].ks), f.lds, h->stream);
     RN_CHECK_LAUNCH();
     return RN_OK;
 }
