@@ -185,36 +185,39 @@ __global__ __launch_bounds__(512, 2) void stage4x_kernel(const StageArgs a) {
     lds_barrier();
 
     int slot_cur = 0;
+    // operand fragments double-buffered across tiles: tile k + 1's three reads go out before tile k's MFMAs (a tile's
+    // chain is only 9 MFMAs long: the LDS round trip at its head was a bubble as long as the chain itself) -- and across STEPS:
+    // the first tile's fragments of row s + 1 are read at the end of step s, in front of the barrier (round 4; the barrier of a
+    // step publishes the row AFTER the one the step computes).  Read behind the barrier they left both waves of every SIMD
+    // waiting for LDS at the same moment, ~350 cycles of a ~2 950-cycle step with an idle matrix pipe.
+    i32x4 fq[2][3];
+    auto reads_at = [&](auto KC, const unsigned (&bcr)[3]) __attribute__((always_inline)) {
+        constexpr int k = decltype(KC)::value;
+        auto& dst = fq[k & 1];
+#pragma unroll
+        for (int f = 0; f < 3; ++f) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst[f]) : "v"(bcr[f]), "n"(k * 1024));
+    };
+    {
+        // row 0 is published by the prologue's barrier only after every wave's pieces have landed: wait_vmcnt<0> above
+        unsigned bc0[3] = {base[0], base[1], base[2]};
+        reads_at(IC<0>{}, bc0);
+    }
     auto step = [&](auto RC, auto PARC, int s) __attribute__((always_inline)) {
         constexpr int R = decltype(RC)::value, PAR = decltype(PARC)::value;
         constexpr int iN = R, iM = (R + 2) % 3, iO = (R + 1) % 3;      // accumulators of conv rows s, s-1, s-2
-        // row s has landed.  VM_CNT counts the output stores too and retires in order: a step issues two DMA pieces at its
-        // top and, on odd rows, 3 (or 4: has7) stores at its end.  Younger than the DMA of row s (issued at step s - 3):
-        // even s: stores of s - 3, DMA of s - 2, DMA + stores of s - 1 = 3 + 2 + 2 + 3; odd s: DMA + stores of s - 2, DMA of
-        // s - 1 = 2 + 3 + 2.  (Counting the DMA pieces alone made every step wait for the previous step's stores.)
-        wait_vmcnt<PAR == 0 ? 10 : 7>();
+        // row s + 1 has landed (row s was published by the previous step's barrier).  VM_CNT counts the output stores too and
+        // retires in order: a step issues two DMA pieces behind its first MFMAs and, on odd rows, 3 (or 4: has7) stores at its
+        // end.  Younger than the DMA of row s + 1 (issued at step s - 2): even s: DMA + stores of step s - 1 = 2 + 3; odd s:
+        // stores of step s - 2, DMA of step s - 1 = 3 + 2 (one more with four stores: those waves wait for one piece more).
+        wait_vmcnt<5>();
         raw_barrier();
-        {
-            int sl = slot_cur + U_AHEAD;
-            sl = sl >= U_NS ? sl - U_NS : sl;
-            issue_row(s + U_AHEAD, sl);                                 // into the slot of row s-1: everybody is past it
-        }
         const unsigned so = static_cast<unsigned>(slot_cur * U_ROW);
         unsigned bc[3];
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx) bc[kx] = base[kx] + so;
         i32x4 op[U_NT + 1];
         op[U_NT - 1] = op[U_NT] = i32x4{0, 0, 0, 0};
-        // operand fragments double-buffered across tiles: tile k + 1's three reads go out before tile k's MFMAs (a tile's
-        // chain is only 9 MFMAs long: the LDS round trip at its head was a bubble as long as the chain itself)
-        i32x4 fq[2][3];
-        auto reads = [&](auto KC) __attribute__((always_inline)) {
-            constexpr int k = decltype(KC)::value;
-            auto& dst = fq[k & 1];
-            auto& bcr = bc;                                            // (named outside the asm: implicit capture)
-#pragma unroll
-            for (int f = 0; f < 3; ++f) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst[f]) : "v"(bcr[f]), "n"(k * 1024));
-        };
+        auto reads = [&](auto KC) __attribute__((always_inline)) { reads_at(KC, bc); };
         auto tile = [&](auto KC, auto NEXTC) __attribute__((always_inline)) {
             constexpr int k = decltype(KC)::value;
             constexpr bool NEXT = decltype(NEXTC)::value != 0;        // tile k + 1's reads are issued here (3 more in flight)
@@ -226,6 +229,12 @@ __global__ __launch_bounds__(512, 2) void stage4x_kernel(const StageArgs a) {
                      acc[iN][k] = mfma16<DT>(cur[F], wf[0 * 3 + F], F == 0 ? zero4 : acc[iN][k]);
                      acc[iM][k] = mfma16<DT>(cur[F], wf[1 * 3 + F], acc[iM][k]);
                      acc[iO][k] = mfma16<DT>(cur[F], wf[2 * 3 + F], acc[iO][k]);
+                     if constexpr (k == 0 && F == 0) {
+                         // the row DMA rides behind the step's first MFMAs: into the slot of row s - 1 (everybody is past it)
+                         int sl = slot_cur + U_AHEAD;
+                         sl = sl >= U_NS ? sl - U_NS : sl;
+                         issue_row(s + U_AHEAD, sl);
+                     }
                  }()),
                  ...);
             }(std::make_integer_sequence<int, 3>{});
@@ -244,7 +253,6 @@ __global__ __launch_bounds__(512, 2) void stage4x_kernel(const StageArgs a) {
                 pp2[k][1] = n1;
             }
         };
-        reads(IC<0>{});
         tile(IC<0>{}, IC<1>{});
         tile(IC<1>{}, IC<1>{});
         tile(IC<2>{}, IC<1>{});
@@ -281,6 +289,14 @@ __global__ __launch_bounds__(512, 2) void stage4x_kernel(const StageArgs a) {
         }
         slot_cur = slot_cur == U_NS - 1 ? 0 : slot_cur + 1;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        {
+            // first tile of the next row (published by this step's barrier)
+            const unsigned sn = static_cast<unsigned>(slot_cur * U_ROW);
+            unsigned bn[3];
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) bn[kx] = base[kx] + sn;
+            reads_at(IC<0>{}, bn);
+        }
     };
     int s = 0;
     for (; s + 5 < nin; s += 6) {
