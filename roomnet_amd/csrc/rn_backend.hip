@@ -381,8 +381,9 @@ bool rn_backend_supported(const rn_handle* h) {
     if (!rn_stage6x_supported(s6.cin, s6.cout, s6.pool_k, s6.skip_stage >= 0, s6.in_side) || !rn_stage6x_plan(s6.out_side, &ncb, xo0, wo) ||
         ncb != 1)
         return false;
-    if (!rn_conv16p_supported(s7.cin, s7.cout, s7.pool_k, s7.pool_s, s7.skip_stage >= 0) || rn_conv16p_colblocks(s7.out_side) != 1) return false;
-    if (s7.in_side != s6.out_side || s7.out_side > 22 || s6.node_bn2 >= 0 || s7.node_bn2 >= 0) return false;
+    // (stage 7 runs on three 16-pixel tiles = 21 pooled columns here)
+    if (!rn_conv16p_supported(s7.cin, s7.cout, s7.pool_k, s7.pool_s, s7.skip_stage >= 0) || s7.out_side > 21) return false;
+    if (s7.in_side != s6.out_side || s6.node_bn2 >= 0 || s7.node_bn2 >= 0) return false;
     for (size_t k = ns - 2; k < ns; ++k)
         if (h->stages[k].skip_stage == static_cast<int>(ns) - 4) return false;      // stage 6's output has no other consumer
     return true;

@@ -223,23 +223,29 @@ __global__ __launch_bounds__(256, 2) void conv16_kernel(const Conv16Args a) {
 // at the even columns 0 .. 12, 7 outputs per tile, tile stride 14 conv columns -- 44 conv columns (224 x 224) are
 // exactly 3 tiles.  Workgroup = image x band x block of 3 tiles (21 output columns), 3 waves sharing the input ring.
 constexpr int P16_CIN = 128, P16_COUT = 16;
-constexpr int P16_NT = 3;                          // pixel tiles = waves per workgroup
-constexpr int P16_BLKO = 7 * P16_NT;               // output columns per block
-constexpr int P16_RINGW = 14 * (P16_NT - 1) + 18;  // input columns a block reads (46)
-constexpr int P16_PIECES = 4;                      // DMA pieces of 192 lanes x 16 B per row (46 px x 16 chunks = 736 <= 768)
-constexpr int P16_ROWB = P16_PIECES * 64 * P16_NT * 16;
+// NT = pixel tiles = waves per workgroup: 3 (21 output columns: the whole row of the 224 x 224 network) or 5 (35: wider inputs run
+// in two column blocks instead of four -- the launch is bound by re-reading stage 6's output, and a block re-reads 4 halo
+// columns: 600 x 600 read 184 columns for 138 with three-tile blocks, 148 with five-tile ones)
+template <int NT>
+struct P16 {
+    static constexpr int BLKO = 7 * NT;               // output columns per block
+    static constexpr int RINGW = 14 * (NT - 1) + 18;  // input columns a block reads (46 / 74)
+    static constexpr int PIECES = 4;                  // DMA pieces of 64 NT lanes x 16 B per row (46 x 16 = 736 <= 768; 74 x 16 = 1184 <= 1280)
+    static constexpr int ROWB = PIECES * 64 * NT * 16;
+    static constexpr int LDS = C16_NSLOT * ROWB;
+    static_assert(RINGW * 16 <= PIECES * 64 * NT, "a ring row fits its DMA pieces");
+};
 constexpr int P16_KC = 36;
 constexpr int P16_RD = 4;                          // operand fragments in flight + 1 (2 / 4 / 6 / 8 measured the same 30 us at batch
                                                    // 256: the launch is bound by re-reading stage 6's output from HBM, 4.6 TB/s)
-constexpr int P16_LDS = C16_NSLOT * P16_ROWB;
-static_assert(P16_RINGW * 16 <= P16_PIECES * 64 * P16_NT, "a ring row fits its DMA pieces");
 
 // 16 chunks per 256-byte pixel = one whole bank row per pixel: chunk ^ ((pixel & 7) << 1) is conflict-free for every tap
 // column and channel quarter under ds_read_b128's lane grouping (enumerated; pixel & 15 and (pixel >> 1) & 15 are not)
 __device__ __forceinline__ int p16_swz(int pix) { return (pix & 7) << 1; }
 
-template <int DT>
-__global__ __launch_bounds__(64 * P16_NT, 2) void conv16p_kernel(const Conv16Args a) {
+template <int DT, int NT>
+__global__ __launch_bounds__(64 * NT, NT == 3 ? 2 : 1) void conv16p_kernel(const Conv16Args a) {
+    constexpr int P16_NT = NT, P16_BLKO = P16<NT>::BLKO, P16_RINGW = P16<NT>::RINGW, P16_PIECES = P16<NT>::PIECES, P16_ROWB = P16<NT>::ROWB;
     extern __shared__ __attribute__((aligned(64))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -327,8 +333,10 @@ __global__ __launch_bounds__(64 * P16_NT, 2) void conv16p_kernel(const Conv16Arg
             constexpr int C = decltype(CC)::value;
             constexpr int tap = C / 4, q = C % 4, ky = tap / 3, kx = tap % 3;
             constexpr int slot_off = ((P + ky) % C16_NSLOT) * P16_ROWB;
-            const unsigned ad = boff[kx][q];                 // (named outside the asm: implicit capture of an asm operand)
-            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(b) : "v"(ad), "n"(slot_off));
+            // (the instruction's offset field is 16 bits: the upper ring slots of the five-tile form lie beyond it)
+            constexpr int imm = slot_off <= 65535 ? slot_off : 0;
+            const unsigned ad = boff[kx][q] + static_cast<unsigned>(slot_off - imm);      // (named outside the asm: implicit capture)
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(b) : "v"(ad), "n"(imm));
         };
         [&]<int... C>(std::integer_sequence<int, C...>) { (rd(IC<C>{}, bq[C]), ...); }(std::make_integer_sequence<int, RD - 1>{});
         [&]<int... C>(std::integer_sequence<int, C...>) {
@@ -412,7 +420,13 @@ bool rn_conv16p_supported(int cin, int cout, int pool_k, int pool_s, bool res) {
     return cin == P16_CIN && cout == P16_COUT && pool_k == 4 && pool_s == 2 && !res;
 }
 
-int rn_conv16p_colblocks(int out_side) { return (out_side + P16_BLKO - 1) / P16_BLKO; }
+// tiles per workgroup for an output row of `out_side` columns, and the column blocks that gives
+static int conv16p_nt(int out_side) { return out_side <= P16<3>::BLKO ? 3 : 5; }
+int rn_conv16p_wgs_per_cu(int out_side) { return conv16p_nt(out_side) == 3 ? 2 : 1; }      // 72 KB / 123 KB of LDS per workgroup
+int rn_conv16p_colblocks(int out_side) {
+    const int blko = 7 * conv16p_nt(out_side);
+    return (out_side + blko - 1) / blko;
+}
 
 // A-operand fragments: frag[chunk c][lane][j] = W[k = 32 c + 8 (lane / 16) + j][cout = lane % 16]
 void rn_conv16p_pack(const float* w_hwio, int dtype, unsigned short (*cvt_bf16)(float), unsigned short (*cvt_f16)(float),
@@ -428,6 +442,7 @@ void rn_conv16p_pack(const float* w_hwio, int dtype, unsigned short (*cvt_bf16)(
 }
 
 int rn_conv16p_launch(int dtype, hipStream_t s, const Conv16Args& a, int n) {
+    const int nt = conv16p_nt(a.Wo);
     auto launch = [&](auto kern) -> int {
         static std::atomic<unsigned long long> attr_devices{0};     // 72 KB of dynamic LDS: per device and instantiation
         int dev = 0;
@@ -436,10 +451,14 @@ int rn_conv16p_launch(int dtype, hipStream_t s, const Conv16Args& a, int n) {
             RN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             attr_devices.fetch_or(1ull << (dev & 63), std::memory_order_release);
         }
-        hipLaunchKernelGGL(kern, dim3(a.n_bands * a.n_colblocks, n), dim3(64 * P16_NT), P16_LDS, s, a);
+        hipLaunchKernelGGL(kern, dim3(a.n_bands * a.n_colblocks, n), dim3(64 * nt), static_cast<size_t>(nt == 3 ? P16<3>::LDS : P16<5>::LDS), s, a);
         RN_CHECK_LAUNCH();
         return RN_OK;
     };
-    if (dtype == RN_DTYPE_BF16) return launch(conv16p_kernel<RN_DTYPE_BF16>);
-    return launch(conv16p_kernel<RN_DTYPE_F16>);
+    if (nt == 3) {
+        if (dtype == RN_DTYPE_BF16) return launch(conv16p_kernel<RN_DTYPE_BF16, 3>);
+        return launch(conv16p_kernel<RN_DTYPE_F16, 3>);
+    }
+    if (dtype == RN_DTYPE_BF16) return launch(conv16p_kernel<RN_DTYPE_BF16, 5>);
+    return launch(conv16p_kernel<RN_DTYPE_F16, 5>);
 }

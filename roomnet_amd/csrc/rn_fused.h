@@ -50,6 +50,7 @@ int rn_conv16_launch(int dtype, hipStream_t s, const rnk::Conv16Args& a, int n);
 // ... and the 128 -> 16 stage with avg-pool 4/2 (one wave = one 16-pixel tile x all 16 couts, no K split)
 bool rn_conv16p_supported(int cin, int cout, int pool_k, int pool_s, bool res);
 int rn_conv16p_colblocks(int out_side);
+int rn_conv16p_wgs_per_cu(int out_side);
 void rn_conv16p_pack(const float* w_hwio, int dtype, unsigned short (*cvt_bf16)(float), unsigned short (*cvt_f16)(float),
                      std::vector<unsigned short>* out);
 int rn_conv16p_launch(int dtype, hipStream_t s, const rnk::Conv16Args& a, int n);

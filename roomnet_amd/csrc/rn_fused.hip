@@ -1249,13 +1249,14 @@ int rn_fused_forward(rn_handle* h, const uint8_t* d_bgr, const float* d_rgb, int
             ca.Ho = ca.Wo = s.out_side;
             ca.n_colblocks = rn_conv16p_colblocks(s.out_side);
             const long per_band = static_cast<long>(n) * ca.n_colblocks;
-            const long slots = 2L * h->n_cu;                 // 3-wave workgroups with 72 KB of LDS: two per CU
+            const int per_cu = rn_conv16p_wgs_per_cu(s.out_side);    // 3-wave workgroups (72 KB of LDS): two per CU; 5-wave ones (123 KB): one
+            const long slots = static_cast<long>(per_cu) * h->n_cu;
             const int max_bands = (s.out_side + 3) / 4;
             int bands = 1;
             double best_cost = -1;
             for (int b = 1; b <= 8 && b <= max_bands; ++b) {
                 if (per_band * b < slots && b < max_bands) continue;          // fill the chip first
-                const double cost = rn_backfill_cost(per_band * b, slots, 2 * ((s.out_side + b - 1) / b) + 2, 2);
+                const double cost = rn_backfill_cost(per_band * b, slots, 2 * ((s.out_side + b - 1) / b) + 2, per_cu);
                 if (best_cost < 0 || cost < best_cost) {
                     best_cost = cost;
                     bands = b;

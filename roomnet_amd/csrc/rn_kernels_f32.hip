@@ -147,15 +147,16 @@ __global__ __launch_bounds__(256) void convert_to_f32_kernel(const void* __restr
 
 // One 64-thread block (one wavefront) per image: flatten, dense chain, softmax, argmax.
 constexpr int HEAD_MAX_FLAT = 4096;
-// Launched with 64 threads (one wavefront) when the flatten is short (224 input: 64 values), with 256 when it is long
-// (600 input: 3136 values): the first dense layer's K loop is then split over 256 / nout partitions whose partial sums
+// Launched with 64 threads (one wavefront) when the flatten is short (224 input: 64 values), with 1024 when it is long
+// (600 input: 3136 values; 256 until round 4: 40 us per launch at 64 images, one workgroup per image on a quarter of the
+// chip): the first dense layer's K loop is then split over threads / nout partitions whose partial sums
 // meet in LDS -- with one wavefront the 3136-step dependent fma chain of that layer alone took 1.06 ms per launch at
 // 64 x 600x600 (21 % of the forward pass, profiles/r2_600_kernel_stats.csv).  Layers with nin <= 64 run as before.
-__global__ __launch_bounds__(256) void head_kernel(const void* __restrict__ flat, int flat_dtype, HeadArgs a,
+__global__ __launch_bounds__(1024) void head_kernel(const void* __restrict__ flat, int flat_dtype, HeadArgs a,
                                                    float* __restrict__ probs, int64_t* __restrict__ ids) {
     __shared__ float buf0[HEAD_MAX_FLAT];
     __shared__ float small[2][64];
-    __shared__ float part[256];
+    __shared__ float part[1024];
     // dense kernels staged in LDS with coalesced, independent loads (all layers that fit): read from global
     // inside the k loop, the 64 + 32 + 16 + 8 dependent steps each paid an L2 round trip (40 us per launch)
     constexpr int HEAD_W_LDS = 3072;
@@ -325,7 +326,7 @@ int rn_launch_head(hipStream_t s, const void* flat, int flat_dtype, int n, const
             rn_set_error("dense layer %d wider than 64 is not supported by the head kernel", d);
             return RN_E_INVALID;
         }
-    const int threads = (a.nin[0] > 256 && a.nout[0] <= 64 && 256 % a.nout[0] == 0) ? 256 : 64;
+    const int threads = (a.nin[0] > 256 && a.nout[0] <= 64 && 1024 % a.nout[0] == 0) ? 1024 : 64;
     hipLaunchKernelGGL(head_kernel, dim3(n), dim3(threads), 0, s, flat, flat_dtype, a, probs, ids);
     RN_CHECK_LAUNCH();
     return RN_OK;
