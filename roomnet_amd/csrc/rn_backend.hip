@@ -32,10 +32,9 @@ namespace {
 
 constexpr int B_NS = 4, B_AHEAD = 3;             // stage-6 input ring: newest row + 3 in flight
 constexpr int B_ROW6 = 52 * 128;                 // bytes per input ring row (64 channels x 16 bit, 52 pixels)
-constexpr int B_WMIN = 35, B_WMAX = 50;          // stage-6 input side (rn_stage6x.hip)
+constexpr int B_WMIN = 35;                       // narrowest stage-6 input row (rn_stage6x.hip: 35 .. 50 columns)
 constexpr int B_NM = 2;                          // mid ring rows: the one stage 7 reads + the one being written
 constexpr int B_ROWM = 48 * 256;                 // bytes per mid row (128 channels x 16 bit, 48 pixels)
-constexpr int B_KC7 = 36;                        // stage-7 K chunks of 32 (9 taps x 4 channel quarters)
 constexpr int B_NP = 4;                          // partial-sum slots (conv rows in flight between their first partial and their sum)
 constexpr int B_LAG = 6;                         // step s finishes stage-7 conv row s - B_LAG
 constexpr int B_OFF_RING6 = 0;
@@ -56,12 +55,10 @@ struct BackendArgs {
     const unsigned short* in;     // [N, W, W, 64]
     const i32x4* wfrag6;          // rn_stage6x_pack
     const float* ptab6;           // folded BN: scale[128], shift[128]
-    unsigned short* out6;         // s6.bn [N, Wo, Wo, 128], or nullptr (default flags: not written)
     int W, Wo;                    // stage-6 input / output side
     // stage 7
     const i32x4* wfrag7;          // rn_conv16p_pack: [36][64 lanes]
     const float* ptab7;           // folded BN: scale[16] (inv / 16), shift[16]
-    unsigned short* out7;         // s7.bn [N, So7, So7, 16], or nullptr
     int So7;
     TailArgs tail;
 };
@@ -95,7 +92,6 @@ __global__ __launch_bounds__(704) void backend_kernel(const BackendArgs a) {
     const int nconv7 = Wo - 2;                      // stage-7 conv rows
     const int nsteps = max(nin, nconv7 + B_LAG);
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-    constexpr int OOB = 0x40000000;
 
     char* const ring6 = smem + B_OFF_RING6;
     char* const mid = smem + B_OFF_MID;
@@ -142,12 +138,10 @@ __global__ __launch_bounds__(704) void backend_kernel(const BackendArgs a) {
                 base[kx][ch] = ring_lds + static_cast<unsigned>(p * 128 + (((4 * ch + g) ^ swz8(p)) << 4));
             }
         // a lane holds couts 16 wave + 4 g .. + 3 of pixel 16 k + px16: 8 bytes = half (g & 1) of chunk 2 wave + g / 2 of the pixel
-        int voff[3];
         unsigned moff[3];
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
             const int xo = 16 * k + px16;
-            voff[k] = (a.out6 != nullptr && xo < Wo) ? (xo * 128 + 16 * wave + 4 * g) * 2 : OOB;
             moff[k] = mid_lds + static_cast<unsigned>(xo * 256 + (((2 * wave + (g >> 1)) ^ swz16(xo)) << 4) + (g & 1) * 8);
         }
         const f32x4 sc = *reinterpret_cast<const f32x4*>(a.ptab6 + 16 * wave + 4 * g);
@@ -157,8 +151,6 @@ __global__ __launch_bounds__(704) void backend_kernel(const BackendArgs a) {
         for (int r3 = 0; r3 < 3; ++r3)
 #pragma unroll
             for (int k = 0; k < 3; ++k) acc[r3][k] = zero4;
-        const int out_row_bytes = Wo * 256;
-        const char* const out_img = reinterpret_cast<const char*>(a.out6 ? a.out6 + static_cast<int64_t>(n) * Wo * Wo * 128 : nullptr);
 #pragma unroll
         for (int j = 0; j < B_AHEAD; ++j) issue_row(j, j);
         wait_vmcnt<0>();
@@ -170,8 +162,9 @@ __global__ __launch_bounds__(704) void backend_kernel(const BackendArgs a) {
         auto step = [&](auto RC, int s) __attribute__((always_inline)) {
             constexpr int R = decltype(RC)::value;
             constexpr int iN = R, iM = (R + 2) % 3, iO = (R + 1) % 3;
-            // (vmcnt: one DMA piece and three stores per step, as in stage6x_kernel)
-            wait_vmcnt<3 + 4 * (B_AHEAD - 1)>();
+            // (vmcnt: one DMA piece per step and nothing else -- no stores: the rows go to LDS -- so the pieces of rows s + 1 and
+            //  s + 2 are what may still be in flight behind row s's)
+            wait_vmcnt<B_AHEAD - 1>();
             raw_barrier();
             {
                 int sl = slot_cur + B_AHEAD;
@@ -186,9 +179,6 @@ __global__ __launch_bounds__(704) void backend_kernel(const BackendArgs a) {
                 for (int ch = 0; ch < 2; ++ch) bc[kx][ch] = base[kx][ch] + so;
             const int j = s - 2;                                            // conv row completed by this step
             const int jr = min(max(j, 0), Wo - 1);
-            const char* orow = out_img + static_cast<int64_t>(jr) * out_row_bytes;
-            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(orow), 0, out_row_bytes, 0x00020000);
-            const int emask = (j >= 0 && j < Wo) ? 0 : OOB;
             const unsigned mslot = static_cast<unsigned>((jr & (B_NM - 1)) * B_ROWM);       // (rows j < 0 write row 0's slot early: harmless)
             i32x4 fq[2][3];
             auto reads = [&](auto BC) __attribute__((always_inline)) {
@@ -222,7 +212,6 @@ __global__ __launch_bounds__(704) void backend_kernel(const BackendArgs a) {
                 const i32x2 d = {static_cast<int>(pack2<DT>(y[0], y[1])), static_cast<int>(pack2<DT>(y[2], y[3]))};
                 const unsigned ma = moff[k] + mslot;
                 asm volatile("ds_write_b64 %0, %1" ::"v"(ma), "v"(d) : "memory");
-                __builtin_amdgcn_raw_buffer_store_b64(d, rs, voff[k] | emask, 0, 0);
             };
             if (s < nin) {
                 reads(IC<0>{});
@@ -276,9 +265,6 @@ __global__ __launch_bounds__(704) void backend_kernel(const BackendArgs a) {
         const int So7 = a.So7;
         const int xo = 7 * t + (i16 >> 1);
         const bool lane_out = (i16 & 1) == 0 && i16 <= 12 && xo < So7;
-        const int voff_lane = (lane_out && a.out7 != nullptr) ? (xo * 16 + 4 * kg) * 2 : OOB;
-        const int out_row_bytes = So7 * 16 * 2;
-        const char* out_row = reinterpret_cast<const char*>(a.out7 ? a.out7 + static_cast<int64_t>(n) * So7 * So7 * 16 : nullptr);
         char* const x7 = smem + B_OFF_X7;
         float hprev[4] = {0.f, 0.f, 0.f, 0.f}, q0[4] = {0.f, 0.f, 0.f, 0.f};
         wait_vmcnt<0>();
@@ -314,9 +300,6 @@ __global__ __launch_bounds__(704) void backend_kernel(const BackendArgs a) {
                         const int r = (je - 3) >> 1;                 // pooled row
                         const i32x2 d = {static_cast<int>(pack2<DT>(y[0], y[1])), static_cast<int>(pack2<DT>(y[2], y[3]))};
                         if (lane_out) *reinterpret_cast<i32x2*>(x7 + ((r * So7 + xo) * 16 + 4 * kg) * 2) = d;
-                        const __amdgpu_buffer_rsrc_t rs =
-                            __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(out_row) + static_cast<int64_t>(r) * out_row_bytes, 0, out_row_bytes, 0x00020000);
-                        __builtin_amdgcn_raw_buffer_store_b64(d, rs, voff_lane, 0, 0);
                     }
                 } else {
 #pragma unroll
@@ -390,7 +373,7 @@ bool rn_backend_supported(const rn_handle* h) {
 }
 
 int rn_backend_launch(rn_handle* h, const i32x4* wfrag6, const float* ptab6, const i32x4* wfrag7, const float* ptab7, const i32x4* wfrag_a,
-                      const i32x4* wfrag_b, const HeadArgs& head, bool write_taps, int n, float* d_probs, int64_t* d_ids) {
+                      const i32x4* wfrag_b, const HeadArgs& head, int n, float* d_probs, int64_t* d_ids) {
     const size_t ns = h->stages.size();
     const StagePlan& s5 = h->stages[ns - 5];
     const StagePlan& s6 = h->stages[ns - 4];
@@ -399,12 +382,10 @@ int rn_backend_launch(rn_handle* h, const i32x4* wfrag6, const float* ptab6, con
     a.in = static_cast<const unsigned short*>(h->nodes[s5.node_bn2 >= 0 ? s5.node_bn2 : s5.node_bn].ptr);
     a.wfrag6 = wfrag6;
     a.ptab6 = ptab6;
-    a.out6 = write_taps ? static_cast<unsigned short*>(h->nodes[s6.node_bn].ptr) : nullptr;
     a.W = s6.in_side;
     a.Wo = s6.out_side;
     a.wfrag7 = wfrag7;
     a.ptab7 = ptab7;
-    a.out7 = write_taps ? static_cast<unsigned short*>(h->nodes[s7.node_bn].ptr) : nullptr;
     a.So7 = s7.out_side;
     rn_tail_fill_args(h, wfrag_a, wfrag_b, head, d_probs, d_ids, &a.tail);
     auto launch = [&](auto kern) -> int {

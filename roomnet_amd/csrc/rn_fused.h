@@ -88,5 +88,4 @@ int rn_f32m_launch(rn_handle* h, int stage, const float* in, int n);      // wri
 // ---- the back end in one launch: stage 6 -> 7 -> 8 -> 9 -> head (rn_backend.hip)
 bool rn_backend_supported(const rn_handle* h);
 int rn_backend_launch(rn_handle* h, const rnk::i32x4* wfrag6, const float* ptab6, const rnk::i32x4* wfrag7, const float* ptab7,
-                      const rnk::i32x4* wfrag_a, const rnk::i32x4* wfrag_b, const HeadArgs& head, bool write_taps, int n, float* d_probs,
-                      int64_t* d_ids);
+                      const rnk::i32x4* wfrag_a, const rnk::i32x4* wfrag_b, const HeadArgs& head, int n, float* d_probs, int64_t* d_ids);

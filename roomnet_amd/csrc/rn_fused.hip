@@ -1024,7 +1024,7 @@ int rn_fused_forward(rn_handle* h, const uint8_t* d_bgr, const float* d_rgb, int
             rn_fill_head_args(h, &head);
             fs->last_backend = true;
             int rc = rn_backend_launch(h, fs->st[ns - 4].wfrag16, fs->st[ns - 4].ptab, fs->st[ns - 3].wfrag16, fs->st[ns - 3].ptab, fs->st[ns - 2].wfrag,
-                                       fs->st[ns - 1].wfrag, head, false, n, d_probs, d_ids);
+                                       fs->st[ns - 1].wfrag, head, n, d_probs, d_ids);
             if (rc != RN_OK) return rc;
             rn_record_event(h, 2 + static_cast<int>(ns - 1));
             rn_record_event(h, 2 + static_cast<int>(ns));
