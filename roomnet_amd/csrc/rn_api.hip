@@ -368,6 +368,14 @@ int forward_unfused(rn_handle* h, const float* d_rgb, int n, float* d_probs, int
             record(h, 2 + static_cast<int>(i));
             continue;
         }
+        if (i == 0 && h->f32m && s.cin == 3 && s.cout == 8 && s.pool_k == 3 && s.pool_s == 1 && s.skip_stage < 0) {
+            // (handles without taps) stage 0 in one launch, bit-identical to its per-node launches
+            float* bn0 = static_cast<float*>(h->nodes[s.node_bn].ptr);
+            if ((rc = rn_launch_stage0_fused_f32(h->stream, cur, s.w_f32, bn0, n, s.in_side, s.bn)) != RN_OK) return rc;
+            cur = bn0;
+            record(h, 2 + static_cast<int>(i));
+            continue;
+        }
         float* conv = static_cast<float*>(h->nodes[s.node_conv].ptr);
         if ((rc = rn_launch_conv3x3_relu6_f32(h->stream, cur, s.w_f32, conv, n, s.in_side, s.in_side, s.cin,
                                               s.cout)) != RN_OK)

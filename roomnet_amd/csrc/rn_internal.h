@@ -122,6 +122,8 @@ struct rn_handle {
 int rn_launch_preprocess_u8(hipStream_t s, const uint8_t* bgr, float* rgb, const float* lut, int64_t npix);
 int rn_launch_conv3x3_relu6_f32(hipStream_t s, const float* in, const float* w, float* out, int n, int h,
                                 int wd, int cin, int cout);
+// stage 0 (3 -> 8, pool 3/1) as one launch (float32 handles without taps): same bits as the four per-node launches
+int rn_launch_stage0_fused_f32(hipStream_t s, const float* in, const float* w, float* out, int n, int side, const BnDev& bn);
 int rn_launch_avgpool_f32(hipStream_t s, const float* in, float* out, int n, int h, int w, int c, int k, int st);
 int rn_launch_bn_f32(hipStream_t s, const float* in, float* out, int64_t npix, int c, const BnDev& bn);
 int rn_launch_resize_add_f32(hipStream_t s, const float* x, const float* skip, float* out, int n, int side,

@@ -218,6 +218,8 @@ def test_matrix_core_f32_equals_per_node_path_closely(engine, engine_mm, parity_
     for name in STAGE_OUT:
         a, b = engine.tap(name, 2), engine_mm.tap(name, 2)
         assert float(np.abs(a - b).max()) <= 2e-5 * max(float(np.abs(a).max()), 1e-3), name
+    # stage 0 runs as one fused launch there (same operations in the same order as its four per-node launches): same bits
+    np.testing.assert_array_equal(engine.tap("s0.bn", 2), engine_mm.tap("s0.bn", 2))
 
 
 def test_matrix_core_f32_band_decomposition_does_not_change_bits(weights, parity_images):
