@@ -541,10 +541,10 @@ def test_conv16_stage_matches_the_generic_kernel_at_odd_sizes(weights, side):
             ref.close()
 
 
-@pytest.mark.parametrize("side", [205, 211, 212, 219, 225, 226, 240])
+@pytest.mark.parametrize("side", [205, 211, 212, 219, 225, 226, 240, 420, 600])
 def test_row_blocked_stage_kernels_match_the_round2_kernels_at_their_geometry_edges(weights, side):
-    """Stages 4, 5 and 6 run one workgroup per image with row-register blocking where their input is 193-206 / 66-110 /
-    35-50 columns wide (rn_stage4x/5x/6x.hip: sides 212-225 for all three, stages 5 and 6 alone a little beyond), and on the
+    """Stages 4, 5 and 6 run with row-register blocking where their rows can be cut into column blocks of 194-206 / 66-110 /
+    35-50 input columns (rn_stage4x/5x/6x.hip: one block at sides 212-225, two at 420, three at 600: the block seams), and on the
     round-2 kernels elsewhere.  `pair32=True` forces the round-2 kernels everywhere: the 32-channel block is bit-identical in
     both arms, so stage 4 sees identical inputs and may differ by the last 16-bit place (other accumulation order, fp16
     band-matrix pooling instead of fp32 sums); stages 5 and 6 inherit that.  1 and 3 images (one band / several bands)."""
