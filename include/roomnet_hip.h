@@ -50,8 +50,11 @@ extern "C" {
  * On the 16-bit handles: conv accumulation, ReLU6, BN, the vertical
  * part of the residual interpolation, the dense head and the softmax are float32; what is
  * NOT float32 (all inside the tolerances of tests/test_hip_fused.py):
- *   - stage 0 feeds its MFMA fp16 inputs in BOTH 16-bit modes (bf16 cannot hold the 256
- *     input levels);
+ *   - stage 0 runs on fp16 MFMAs in BOTH 16-bit modes and is exact up to the float32 summation
+ *     order: the operand is the uint8 pixel value itself, the pre-processing of network.py:129
+ *     is folded into the weights, and every folded weight is an fp16 hi + lo pair in two idle
+ *     rows of the 32 x 32 tile (rn_stage.h, s0_pixel_halves); only its OUTPUT is rounded to
+ *     the storage type;
  *   - avg-pool 4x4 stride 1 (stages 1-3): ReLU6 outputs are rounded to fp16, vertical pair
  *     sums are fp16 adds, and the window sums run on the matrix cores (fp16 x 0/1 band
  *     matrix, exact float32 accumulation); stride-2 pools are float32 VALU sums, except

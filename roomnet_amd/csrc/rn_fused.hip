@@ -47,36 +47,34 @@ namespace {
 //   * K is laid out as (ky, kx in 0..3, c in 0..3) = 48 (kx = 3 and c = 3 are zero weights), i.e.
 //     ONE 16-deep MFMA K-chunk per input row ky.  For v_mfma_f32_32x32x16 the B operand of lane
 //     (r, h) is then: h = 0: pixels r and r+1 (4 x 16-bit each), h = 1: pixel r+2 and zeros.
-//   * lane (r, h) loads ITS pixel x0 + r + 2h (3 bytes), maps it through the 256-entry table
-//     (LDS, 16-bit) and packs (R,G | B,0); the lower half-wave gets pixel r+1 from its
-//     neighbour lane with a DPP shift.  The fragments of the last 3 input rows stay in 12 VGPRs.
-//   * D[cout][pixel]: only rows 0..7 are real, so a lane owns 4 channels of one conv pixel in 4
-//     accumulator registers: ReLU6, 3-wide horizontal sum by DPP, 3-row vertical sum in a
-//     register ring, one fma for BN, one 8-byte store.  No LDS traffic besides the table.
+//   * lane (r, h) loads ITS pixel x0 + r + 2h (3 bytes) and packs the byte values as fp16 numbers
+//     (R,G | B,0) -- exact; the pre-processing table of network.py:129 is folded into the weights
+//     (s0_pixel_halves, rn_stage.h); the lower half-wave gets pixel r+1 from its neighbour lane
+//     with a DPP shift.  The fragments of the last 3 input rows stay in 12 VGPRs.
+//   * D[cout][pixel]: rows 0..7 hold the hi halves of the folded weights, rows 8..15 the lo halves,
+//     so a lane owns 4 channels of one conv pixel in 4 + 4 accumulator registers: add, ReLU6,
+//     3-wide horizontal sum by DPP, 3-row vertical sum in a register ring, one fma for BN, one
+//     8-byte store.  No LDS traffic.
 // A wave owns 32 conv columns (29 output columns, tiles overlap by 3) and walks down a band of
 // rows; a workgroup is up to 8 such waves side by side.
-// The MFMA inputs of this stage are ALWAYS fp16 (table and weights), whatever the storage type
-// of the activations: bf16's 8-bit significand cannot represent the 256 input levels (it costs
-// about one bit of image depth and the error is amplified ~10x by the following BN gains;
-// measured: stage-2 error 0.5 % -> 3.9 % of abs-max), fp16's 11 bits can.
+// The MFMA inputs of this stage are ALWAYS fp16, whatever the storage type of the activations:
+// fp16 holds the 256 input levels exactly and the weights as hi + lo pairs, so the stage computes
+// the fp32 convolution of the exact input (bf16's 8-bit significand cannot represent the levels).
 constexpr int S0_CO = 8;
 constexpr int S0_TSTRIDE = 29;      // output columns per 32-column tile: 32 - (3 - 1) - 1
 constexpr int S0_AHEAD = 8;         // input rows prefetched (one dword per lane and row in registers)
 
 struct Stage0Args {
     const uint8_t* bgr;             // [N, S, S, 3]
-    const unsigned short* lut16;    // 256 entries, storage dtype
-    const i32x4* wfrag;             // [3 (ky)][64 lanes] A fragments, 8 x 16-bit
-    const float* ptab;              // [2][8] folded BN: scale (inv / 9), shift
+    const i32x4* wfrag;             // [3 (ky)][64 lanes] A fragments, 8 x fp16: cout rows 0..7 hi, 8..15 lo
+    const float* ptab;              // [2][8] folded BN: scale (inv / 9 / 2^8), shift
     unsigned short* out;            // [N, So, So, 8]
     int S, So;
     int rows_per_band, n_bands, n_colblocks, npt;
-    int lut_arith;                  // the 256 table entries equal fp16(fma(x, 2/255, -1)): compute instead of looking up
 };
 
 template <int DT>
 __global__ __launch_bounds__(512) void stage0_kernel(const Stage0Args a) {
-    __shared__ unsigned short s_lut[256];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -84,7 +82,6 @@ __global__ __launch_bounds__(512) void stage0_kernel(const Stage0Args a) {
     const int cb = blockIdx.x % a.n_colblocks;
     const int band = blockIdx.x / a.n_colblocks;
     const int n = blockIdx.y;
-    for (int i = tid; i < 256; i += blockDim.x) s_lut[i] = a.lut16[i];
 
     const int yo0 = band * a.rows_per_band;
     const int yo1 = min(a.So, yo0 + a.rows_per_band);
@@ -118,7 +115,6 @@ __global__ __launch_bounds__(512) void stage0_kernel(const Stage0Args a) {
     };
 #pragma unroll
     for (int i = 0; i < S0_AHEAD; ++i) pw[i] = load_px(i);
-    __syncthreads();
 
     i32x4 bfr[3];                                      // B fragments of the 3 live input rows
     float h1[4], h2[4];                                // horizontal sums of the two previous conv rows
@@ -131,20 +127,7 @@ __global__ __launch_bounds__(512) void stage0_kernel(const Stage0Args a) {
     auto next_frag = [&](int jrow) -> i32x4 {
         const unsigned w = pw[0] >> sh0;                       // bytes: B, G, R
         int d0, d1;
-        if (a.lut_arith) {
-            // ((x / 255.) * 2) - 1 of network.py:129 as one fp32 fma, verified on the host to round to the same
-            // fp16 as the float64 expression for all 256 inputs: no LDS look-ups (random 2-byte reads from a
-            // 512-byte table ran at 63 % bank conflicts)
-            const float fb = fmaf(static_cast<float>(w & 0xff), 2.0f / 255.0f, -1.0f);
-            const float fg = fmaf(static_cast<float>((w >> 8) & 0xff), 2.0f / 255.0f, -1.0f);
-            const float fr = fmaf(static_cast<float>((w >> 16) & 0xff), 2.0f / 255.0f, -1.0f);
-            d0 = static_cast<int>(pack2<RN_DTYPE_F16>(fr, fg));
-            d1 = static_cast<int>(pack2<RN_DTYPE_F16>(fb, 0.f));
-        } else {
-            const unsigned cr = s_lut[(w >> 16) & 0xff], cg = s_lut[(w >> 8) & 0xff], cbl = s_lut[w & 0xff];
-            d0 = static_cast<int>(cr | (cg << 16));
-            d1 = static_cast<int>(cbl);
-        }
+        s0_pixel_halves(w, d0, d1);
 #pragma unroll
         for (int i = 0; i + 1 < S0_AHEAD; ++i) pw[i] = pw[i + 1];
         pw[S0_AHEAD - 1] = load_px(jrow + S0_AHEAD);
@@ -169,7 +152,7 @@ __global__ __launch_bounds__(512) void stage0_kernel(const Stage0Args a) {
         float y[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const float v = relu6f(acc[j]);
+            const float v = s0_relu6(acc, j);
             const float v1 = lane_next(v);
             const float hs = (v + v1) + lane_next(v1);
             y[j] = fmaf((h2[j] + h1[j]) + hs, scale[j], shift[j]);
@@ -483,6 +466,24 @@ unsigned short f32_to_f16(float f) {
     return static_cast<unsigned short>(sign | out);
 }
 
+float f16_to_f32(unsigned short h) {
+    const uint32_t sign = static_cast<uint32_t>(h & 0x8000u) << 16;
+    const int e = (h >> 10) & 0x1f;
+    const uint32_t m = h & 0x3ffu;
+    float mag;
+    if (e == 0)
+        mag = std::ldexp(static_cast<float>(m), -24);                    // zero / subnormal
+    else if (e == 31)
+        mag = m ? std::nanf("") : INFINITY;
+    else
+        mag = std::ldexp(static_cast<float>(m | 0x400u), e - 25);
+    uint32_t u;
+    std::memcpy(&u, &mag, 4);
+    u |= sign;
+    std::memcpy(&mag, &u, 4);
+    return mag;
+}
+
 // Cost of running `wgs` equal workgroups of `rows` row steps each with `slots` of them resident at a time, for the
 // variants with several small workgroups per CU (they are back-filled as slots free up, so a launch does not run in
 // whole rounds of the chip).  Fitted to band-count sweeps on the GPU (NOTES.md, rounds 1-2, "Band counts"):
@@ -624,8 +625,6 @@ struct FusedState {
     i32x4* pair_wfrag_a = nullptr;
     i32x4* pair_wfrag_b = nullptr;
     // stage 0
-    unsigned short* s0_lut16 = nullptr;
-    int s0_lut_arith = 0;
     i32x4* s0_wfrag = nullptr;
     float* s0_ptab = nullptr;
 };
@@ -650,26 +649,35 @@ int rn_fused_prepare(rn_handle* h, const rn_weights* w) {
         return RN_E_INVALID;
     }
     {
-        // stage-0 tables: 16-bit pre-processing table, A fragments with K = (ky, kx<4, c<4), folded BN
-        auto cvt = [&](float v) { return f32_to_f16(v); };   // stage-0 MFMA inputs are always fp16
-        std::vector<unsigned short> lut(256);
-        for (int v = 0; v < 256; ++v)
-            lut[v] = cvt(static_cast<float>(((static_cast<double>(v) / 255.) * 2) - 1));
+        // stage-0 tables (s0_pixel_halves, rn_stage.h): A fragments with K = (ky, kx<4, c<4) of the folded weights
+        // 2^8 (2 w / 255) as fp16 hi (cout rows 0..7) + lo (rows 8..15) pairs with the constant -2^8 sum(w) in the fourth
+        // channel slot of (ky, kx) = (0, 0); folded BN
         std::vector<unsigned short> frag(3 * 64 * 8, 0);
         const float* w0 = w->stages[0].kernel;       // [ky][kx][c][cout]
         for (int ky = 0; ky < 3; ++ky)
             for (int l = 0; l < 64; ++l)
                 for (int j = 0; j < 8; ++j) {
-                    const int kk = 8 * (l >> 5) + j, kx = kk / 4, c = kk % 4, co = l & 31;
-                    float v = 0.f;
-                    if (kx < 3 && c < 3 && co < S0_CO) v = w0[((ky * 3 + kx) * 3 + c) * S0_CO + co];
-                    frag[(ky * 64 + l) * 8 + j] = cvt(v);
+                    const int kk = 8 * (l >> 5) + j, kx = kk / 4, c = kk % 4, row = l & 31, co = row & 7, part = row >> 3;
+                    if (part >= 2) continue;
+                    double v;
+                    if (kx < 3 && c < 3) {
+                        v = static_cast<double>(w0[((ky * 3 + kx) * 3 + c) * S0_CO + co]) * (2.0 / 255.0) * S0_WSCALE;
+                    } else if (ky == 0 && kx == 0 && c == 3) {      // the constant slot: B = 1.0
+                        v = 0.0;
+                        for (int t = 0; t < 27; ++t) v -= static_cast<double>(w0[t * S0_CO + co]);
+                        v *= S0_WSCALE;
+                    } else {
+                        continue;
+                    }
+                    const unsigned short hi = f32_to_f16(static_cast<float>(v));
+                    const unsigned short lo = f32_to_f16(static_cast<float>(v - static_cast<double>(f16_to_f32(hi))));
+                    frag[(ky * 64 + l) * 8 + j] = part == 0 ? hi : lo;
                 }
         const rn_conv_stage& ws = w->stages[0];
         std::vector<float> tab(16);
         for (int c = 0; c < S0_CO; ++c) {
             const float inv = (1.0f / sqrtf(ws.variance[c] + w->bn_epsilon)) * ws.gamma[c];
-            tab[c] = inv / 9.0f;
+            tab[c] = inv / 9.0f / S0_WSCALE;
             tab[8 + c] = ws.beta[c] - ws.mean[c] * inv;
         }
         void* d = nullptr;
@@ -684,11 +692,6 @@ int rn_fused_prepare(rn_handle* h, const rn_weights* w) {
             return RN_OK;
         };
         int rc;
-        if ((rc = up(lut.data(), lut.size() * 2, &d)) != RN_OK) return rc;
-        fs->s0_lut16 = static_cast<unsigned short*>(d);
-        fs->s0_lut_arith = 1;
-        for (int v = 0; v < 256; ++v)
-            if (cvt(fmaf(static_cast<float>(v), 2.0f / 255.0f, -1.0f)) != lut[v]) fs->s0_lut_arith = 0;
         if ((rc = up(frag.data(), frag.size() * 2, &d)) != RN_OK) return rc;
         fs->s0_wfrag = static_cast<i32x4*>(d);
         if ((rc = up(tab.data(), tab.size() * 4, &d)) != RN_OK) return rc;
@@ -925,7 +928,7 @@ int rn_fused_prepare(rn_handle* h, const rn_weights* w) {
         const StagePlan& s1 = h->stages[1];
         bool feeds_others = false;
         for (size_t k = 2; k < h->stages.size(); ++k) feeds_others |= h->stages[k].skip_stage == 0;
-        fs->fuse_s0 = fs->st[1].use_rw && fs->st[1].rw.variant == 0 && s1.skip_stage < 0 && fs->s0_lut_arith && !feeds_others;
+        fs->fuse_s0 = fs->st[1].use_rw && fs->st[1].rw.variant == 0 && s1.skip_stage < 0 && !feeds_others;
 #ifdef RN_X_NO_S0F      // (A/B timing builds)
         fs->fuse_s0 = false;
 #endif
@@ -986,8 +989,6 @@ int rn_fused_forward(rn_handle* h, const uint8_t* d_bgr, const float* d_rgb, int
         const StagePlan& s = h->stages[0];
         Stage0Args a0{};
         a0.bgr = d_bgr;
-        a0.lut16 = fs->s0_lut16;
-        a0.lut_arith = fs->s0_lut_arith;
         a0.wfrag = fs->s0_wfrag;
         a0.ptab = fs->s0_ptab;
         a0.out = static_cast<unsigned short*>(h->nodes[s.node_bn].ptr);

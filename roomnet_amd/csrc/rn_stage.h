@@ -139,6 +139,38 @@ __device__ __forceinline__ float mul_rounded(float a, float b) {
 
 __device__ __forceinline__ float relu6f(float v) { return __builtin_amdgcn_fmed3f(v, 0.f, 6.f); }
 
+// ---- stage-0 operands (stage0_kernel in rn_fused.hip and the stage-0 fusion of stage_rw_kernel use the same sequence)
+// Stage 0 is the one stage whose input is EXACT in 16 bits: the uint8 pixel values themselves.  The pre-processing
+// ((x / 255.) * 2) - 1 of network.py:129 is folded into the weights and a per-cout constant,
+//     conv(x') = sum w (2 x / 255 - 1) = sum (2 w / 255) x - sum w,
+// the B operand is fp16(x) (an integer <= 255: exact), and each folded weight enters the MFMA as a PAIR of fp16 numbers
+// hi + lo (hi = fp16(v), lo = fp16(v - hi): 22 significand bits) in two cout rows of the A operand -- rows 8..31 of the
+// 32 x 32 tile were idle (the stage has 8 couts), so the pair costs no matrix instruction: row c holds hi, row 8 + c lo,
+// and the lane adds its two accumulator registers.  The constant - sum w rides in the idle fourth channel slot of the
+// (ky = 0, kx = 0) pixel: that B element is 1.0, its A elements are the constant's hi / lo halves.  Everything is scaled
+// by 2^8 (hi stays a normal fp16 number for |w| >= 1.5e-5; the power of two is exact and comes off in the BN scale),
+// ReLU6 clamps at 6 x 2^8.
+// With it the stage computes the fp32 convolution of the exact input up to the fp32 accumulation order; before, the
+// fp16-rounded input levels and weights were the largest single error of the 16-bit path (tools/scratch/dbg_logit_err.py).
+constexpr float S0_WSCALE = 256.0f;
+__device__ __forceinline__ void s0_pixel_halves(unsigned bgr, int& d0, int& d1) {
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    // 0x6400 | x is the fp16 number 1024 + x: bytes (R, 0x64, G, 0x64) and (B, 0x64, 0x00, 0x3c), then - 1024 from the pixel
+    // halves: (R, G) and (B, 1.0)
+    const unsigned m0 = __builtin_amdgcn_perm(0x3c006400u, bgr, 0x05010502u);
+    const unsigned m1 = __builtin_amdgcn_perm(0x3c006400u, bgr, 0x07060500u);
+    const h2 a = __builtin_bit_cast(h2, m0) - h2{static_cast<_Float16>(1024.f), static_cast<_Float16>(1024.f)};
+    const h2 b = __builtin_bit_cast(h2, m1) - h2{static_cast<_Float16>(1024.f), static_cast<_Float16>(0.f)};
+    d0 = __builtin_bit_cast(int, a);
+    d1 = __builtin_bit_cast(int, b);
+}
+// conv value of cout 4 h + j of the lane's pixel (hi row + lo row: one packed add per two couts), ReLU6 in the scaled domain
+__device__ __forceinline__ float s0_relu6(const f32x16& acc, int j) {
+    const int p = j & ~1;
+    const f32x2 sum = f32x2{acc[p], acc[p + 1]} + f32x2{acc[4 + p], acc[5 + p]};
+    return __builtin_amdgcn_fmed3f(sum[j & 1], 0.f, 6.f * S0_WSCALE);
+}
+
 #ifdef RN_CLOCK
 // Diagnostic build (-DRN_CLOCK, tools/build_clock.sh; never shipped): the in-kernel clock of a launch is
 // delta(s_memtime) / delta(s_memrealtime) x 100 MHz (MI355X_MICROARCH.md, DVFS give-back item 6), stamped once at the entry
@@ -225,7 +257,7 @@ struct StageArgs {
     // stage-0 fusion (8-channel rw variant only; s0_bgr == nullptr: the stage reads `in` as usual)
     const uint8_t* s0_bgr;        // [N, S, S, 3] uint8 image batch
     const i32x4* s0_wfrag;        // [3 (ky)][64 lanes] stage-0 A fragments (fp16, K = (kx < 4, c < 4))
-    const float* s0_ptab;         // [2][8] stage-0 folded BN: scale (inv / 9), shift
+    const float* s0_ptab;         // [2][8] stage-0 folded BN: scale (inv / 9 / 2^8), shift
     int s0_S;                     // image side
     int s0_private;               // stage-0 fusion: keep the wave-private rings (round-2 form; A/B arm)
     // column blocks of the row-blocked kernels (rn_stage4x / 5x / 6x): workgroup = image x band x block; block b owns output

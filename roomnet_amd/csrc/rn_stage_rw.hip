@@ -389,14 +389,10 @@ __global__ __launch_bounds__((RwCfg<DT, CIN, COUT, PK, PS, RES, NPT, KS, S0F, WI
             const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int u = 0; u < C::S0_TILES; ++u) {
-                // ((x / 255.) * 2) - 1 of network.py:129 as one fp32 fma (the host checked that it rounds to the same
-                // fp16 as the float64 expression for all 256 inputs, rn_fused_prepare)
+                // the byte values as fp16 numbers, exact; ((x / 255.) * 2) - 1 of network.py:129 lives in the weights
                 const unsigned w = s0_pw[u][Q] >> s0_sh[u];              // bytes: B, G, R
-                const float fb = fmaf(static_cast<float>(w & 0xff), 2.0f / 255.0f, -1.0f);
-                const float fg = fmaf(static_cast<float>((w >> 8) & 0xff), 2.0f / 255.0f, -1.0f);
-                const float fr = fmaf(static_cast<float>((w >> 16) & 0xff), 2.0f / 255.0f, -1.0f);
-                const int d0 = static_cast<int>(pack2<RN_DTYPE_F16>(fr, fg));
-                const int d1 = static_cast<int>(pack2<RN_DTYPE_F16>(fb, 0.f));
+                int d0, d1;
+                s0_pixel_halves(w, d0, d1);
                 s0_pw[u][Q] = s0_load(u, i + S0_AHEAD);
                 i32x4 f;
                 f[0] = d0;
@@ -411,7 +407,7 @@ __global__ __launch_bounds__((RwCfg<DT, CIN, COUT, PK, PS, RES, NPT, KS, S0F, WI
                     float y[4];
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        const float v = relu6f(acc[j]);
+                        const float v = s0_relu6(acc, j);
                         const float v1 = lane_next(v);
                         const float hs = (v + v1) + lane_next(v1);
                         y[j] = fmaf((s0_h2[u][j] + s0_h1[u][j]) + hs, s0_scale[j], s0_shift[j]);
@@ -444,11 +440,8 @@ __global__ __launch_bounds__((RwCfg<DT, CIN, COUT, PK, PS, RES, NPT, KS, S0F, WI
 #pragma unroll
             for (int u = 0; u < C::S0_TILES; ++u) {
                 const unsigned w = s0_pw[u][Q] >> s0_sh[u];              // bytes: B, G, R
-                const float fb = fmaf(static_cast<float>(w & 0xff), 2.0f / 255.0f, -1.0f);
-                const float fg = fmaf(static_cast<float>((w >> 8) & 0xff), 2.0f / 255.0f, -1.0f);
-                const float fr = fmaf(static_cast<float>((w >> 16) & 0xff), 2.0f / 255.0f, -1.0f);
-                const int d0 = static_cast<int>(pack2<RN_DTYPE_F16>(fr, fg));
-                const int d1 = static_cast<int>(pack2<RN_DTYPE_F16>(fb, 0.f));
+                int d0, d1;
+                s0_pixel_halves(w, d0, d1);
                 s0_pw[u][Q] = s0_load(u, i + S0_AHEAD);
                 i32x4 f;
                 f[0] = d0;
@@ -471,7 +464,7 @@ __global__ __launch_bounds__((RwCfg<DT, CIN, COUT, PK, PS, RES, NPT, KS, S0F, WI
                 if constexpr (k < 2) {
 #pragma unroll
                     for (int j = 2 * k; j < 2 * k + 2; ++j) {
-                        const float v = relu6f(s0_acc[u][j]);
+                        const float v = s0_relu6(s0_acc[u], j);
                         const float v1 = lane_next(v);
                         const float hs = (v + v1) + lane_next(v1);
                         s0_y[u][j] = fmaf((s0_h2[u][j] + s0_h1[u][j]) + hs, s0_scale[j], s0_shift[j]);

@@ -1,11 +1,9 @@
 #!/bin/bash
-# GPU box, round 4 session 16: five-tile conv16p + 1024-thread head at 420 / 600: tests + 600 bench
-cd $GRAFT_REPO_ROOT
+# exact stage 0: parity and speed
 mkdir -p gpurun_out/r4
-python -m pytest tests/test_hip_fused.py tests/test_roomnet_api.py -m gpu -q 2>&1 | tail -6 | tee gpurun_out/r4/s16_pytest.txt
-for rep in 1 2; do
-python bench.py --side 600 --batch 64 --dtype f16 --steps 100 --warmup 10 --no-cpu-baseline 2>/dev/null | tail -1 | python -c "
+python tools/scratch/dbg_logit_err.py > gpurun_out/r4/dbg_logit2.txt 2>&1
+grep -E "worst|s0.bn|s1.bn|s3.bn2|s8.bn|d3.relu" gpurun_out/r4/dbg_logit2.txt
+python -m pytest tests -m gpu -x -q 2>&1 | tail -15 > gpurun_out/r4/s16_pytest.txt; tail -5 gpurun_out/r4/s16_pytest.txt
+for i in 1 2; do python bench.py --steps 400 --warmup 20 --no-cold-pass 2>/dev/null | python3 -c "
 import sys,json
-d=json.loads(sys.stdin.readline())
-print('600 base %.0f img/s  cold %.0f  ' % (d['value'], d.get('cold_images_per_sec', 0)) + ' '.join('%.3f'%x for x in d['path']['stage_ms']) + ' head %.3f' % d['path']['head_ms'] + '  parity %s' % (d['parity'].get('ids_wrong'),))"
-done 2>&1 | tee gpurun_out/r4/s16_600.txt
+d=json.loads(sys.stdin.readlines()[-1]); print(round(d['value']), d['path']['launch_ms'])"; done
