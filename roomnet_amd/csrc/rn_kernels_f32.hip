@@ -142,52 +142,64 @@ __global__ __launch_bounds__(256) void resize_add_f32_kernel(const float* __rest
 // Stage 0 of a float32 handle without taps in ONE launch: conv3x3 (3 -> 8) -> ReLU6 -> avg-pool 3/1 -> BN, the four per-node
 // kernels' arithmetic in their order (fmaf chain over ky, kx, c; window sum over ky, kx, then / 9; un-contracted BN): same bits.
 // 27 MACs per conv output are not matrix-core work (K = 27, 8 couts); what the per-node path pays for is its three round
-// trips through HBM (6.5 MB per image; this kernel: input 0.6 MB + output 1.55 MB).  One workgroup = a 16 x 16 output tile.
+// trips through HBM (6.5 MB per image; this kernel: input 0.6 MB + output 1.55 MB).  One workgroup = a 30 x 14 output tile =
+// 32 x 16 conv pixels (two full passes of the 256 threads); the 216 weights are wave-uniform scalar operands of the fmas (as
+// LDS broadcasts they were 216 ds_reads per conv pixel next to its 27 input reads: the kernel was bound by LDS issue).
 __global__ __launch_bounds__(256) void stage0_fused_f32_kernel(const float* __restrict__ in, const float* __restrict__ w,
                                                                float* __restrict__ out, int S, const float* __restrict__ mean,
                                                                const float* __restrict__ inv, const float* __restrict__ beta) {
-    constexpr int T = 16, CT = T + 2, IT = T + 4, CO = 8;
-    __shared__ float tin[IT * IT * 3];
-    __shared__ float tconv[CT * CT * CO];
-    __shared__ float tw[27 * CO];
-    const int n = blockIdx.z, ox0 = blockIdx.x * T, oy0 = blockIdx.y * T;
+    constexpr int TX = 30, TY = 14, CX = TX + 2, CY = TY + 2, IX = TX + 4, IY = TY + 4, CO = 8;
+    static_assert(CX * CY == 512, "two passes of 256 threads");
+    __shared__ float tin[IY * IX * 3];
+    __shared__ float tconv[CY * CX * CO];
+    const int n = blockIdx.z, ox0 = blockIdx.x * TX, oy0 = blockIdx.y * TY;
     const int So = S - 4;                                      // conv S - 2, pool 3/1: S - 4
     const float* img = in + static_cast<int64_t>(n) * S * S * 3;
-    for (int i = threadIdx.x; i < IT * IT * 3; i += 256) {
-        const int c = i % 3, p = i / 3, ix = p % IT, iy = p / IT;
+    for (int i = threadIdx.x; i < IY * IX * 3; i += 256) {
+        const int c = i % 3, p = i / 3, ix = p % IX, iy = p / IX;
         const int gy = min(oy0 + iy, S - 1), gx = min(ox0 + ix, S - 1);      // (clamped columns / rows only feed outputs that are not stored)
         tin[i] = img[(static_cast<int64_t>(gy) * S + gx) * 3 + c];
     }
-    for (int i = threadIdx.x; i < 27 * CO; i += 256) tw[i] = w[i];
     __syncthreads();
-    for (int p = threadIdx.x; p < CT * CT; p += 256) {
-        const int cx = p % CT, cy = p / CT;
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        const int p = threadIdx.x + 256 * pass;
+        const int cx = p % CX, cy = p / CX;
         float acc[CO];
 #pragma unroll
         for (int o = 0; o < CO; ++o) acc[o] = 0.f;
+#pragma unroll
         for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
             for (int kx = 0; kx < 3; ++kx)
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
-                    const float v = tin[((cy + ky) * IT + cx + kx) * 3 + c];
+                    const float v = tin[((cy + ky) * IX + cx + kx) * 3 + c];
 #pragma unroll
-                    for (int o = 0; o < CO; ++o) acc[o] = fmaf(v, tw[((ky * 3 + kx) * 3 + c) * CO + o], acc[o]);
+                    for (int o = 0; o < CO; ++o) acc[o] = fmaf(v, w[((ky * 3 + kx) * 3 + c) * CO + o], acc[o]);
                 }
 #pragma unroll
         for (int o = 0; o < CO; ++o) tconv[p * CO + o] = relu6f(acc[o]);
     }
     __syncthreads();
-    const int tx = threadIdx.x % T, ty = threadIdx.x / T;
-    const int ox = ox0 + tx, oy = oy0 + ty;
-    if (ox >= So || oy >= So) return;
-    float* op = out + ((static_cast<int64_t>(n) * So + oy) * So + ox) * CO;
+    for (int q = threadIdx.x; q < TX * TY; q += 256) {
+        const int tx = q % TX, ty = q / TX;
+        const int ox = ox0 + tx, oy = oy0 + ty;
+        if (ox >= So || oy >= So) continue;
+        float* op = out + ((static_cast<int64_t>(n) * So + oy) * So + ox) * CO;
+        float y[CO];
 #pragma unroll
-    for (int o = 0; o < CO; ++o) {
-        float acc = 0.f;
-        for (int ky = 0; ky < 3; ++ky)
-            for (int kx = 0; kx < 3; ++kx) acc += tconv[((ty + ky) * CT + tx + kx) * CO + o];
-        const float pooled = acc / 9.0f;
-        op[o] = __fadd_rn(__fmul_rn(__fsub_rn(pooled, mean[o]), inv[o]), beta[o]);
+        for (int o = 0; o < CO; ++o) {
+            float acc = 0.f;
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) acc += tconv[((ty + ky) * CX + tx + kx) * CO + o];
+            const float pooled = acc / 9.0f;
+            y[o] = __fadd_rn(__fmul_rn(__fsub_rn(pooled, mean[o]), inv[o]), beta[o]);
+        }
+        *reinterpret_cast<float4*>(op) = make_float4(y[0], y[1], y[2], y[3]);
+        *reinterpret_cast<float4*>(op + 4) = make_float4(y[4], y[5], y[6], y[7]);
     }
 }
 
@@ -346,7 +358,7 @@ int rn_launch_avgpool_f32(hipStream_t s, const float* in, float* out, int n, int
 
 int rn_launch_stage0_fused_f32(hipStream_t s, const float* in, const float* w, float* out, int n, int side, const BnDev& bn) {
     const int so = side - 4;
-    hipLaunchKernelGGL(stage0_fused_f32_kernel, dim3((so + 15) / 16, (so + 15) / 16, n), dim3(256), 0, s, in, w, out, side, bn.mean, bn.inv, bn.beta);
+    hipLaunchKernelGGL(stage0_fused_f32_kernel, dim3((so + 29) / 30, (so + 13) / 14, n), dim3(256), 0, s, in, w, out, side, bn.mean, bn.inv, bn.beta);
     RN_CHECK_LAUNCH();
     return RN_OK;
 }

@@ -39,6 +39,11 @@ using namespace rnk;
 
 namespace {
 
+// Cache policy (aux operand of the buffer store / LDS-DMA; 2 = nt): the output rows and the residual's second read of an A row are
+// streamed -- neither is read again by this launch -- so that the L2 keeps the A rows between their first read (the conv operand)
+// and their second (the skip row, 0-10 row steps later).  FETCH_SIZE of the launch 1 315 -> 928 MB per 256 images (757 = every A row
+// once); the rate does not move (the pass is not bound by HBM; gpurun_out/r4/s17_nt.txt).
+constexpr int RN_NT_OUT = 2, RN_NT_SKIP = 2;
 constexpr int X_NA = 4, X_NB = 4, X_NSK = 3;     // ring depths: A rows, B rows, private skip rows
 constexpr int X_WMAX = 215;                      // widest A row (column blocks: 193..215, rn_stage23_plan; the tail DMA piece needs W > 192)
 constexpr int X_ROWA = X_WMAX * 64;              // bytes per A ring row (32 channels x 16 bit per pixel)
@@ -206,7 +211,7 @@ __global__ __launch_bounds__(512, 2) void stage23x_kernel(const Stage23Args a) {
         const char* row = in_img + static_cast<int64_t>(y) * static_cast<int64_t>(Win * 64);
         unsigned off = sk_goff0;
         asm volatile("" : "+v"(off));
-        dma16(row + i * 1024 + off, skw + slot * X_SKROW + i * 1024);
+        __builtin_amdgcn_global_load_lds(row + i * 1024 + off, (lds_void_ptr)(skw + slot * X_SKROW + i * 1024), 16, 0, RN_NT_SKIP);
     };
     auto issue_skip_row = [&](int y, int slot) __attribute__((always_inline)) {
         issue_skip_piece(IC<0>{}, y, slot);
@@ -550,7 +555,7 @@ __global__ __launch_bounds__(512, 2) void stage23x_kernel(const Stage23Args a) {
                          static_cast<int>(pack2<DT>(y[4], y[5])), static_cast<int>(pack2<DT>(y[6], y[7]))};
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(cx.row), 0, out_row_bytes, 0x00020000);
         const int vo = (px16 < lim(k) ? voff0 + 1024 * k : OOB) | cx.emit_mask;
-        __builtin_amdgcn_raw_buffer_store_b128(d, rs, vo, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(d, rs, vo, 0, RN_NT_OUT);
     };
     auto step = [&](auto PC, int t) __attribute__((always_inline)) {
         constexpr int P = decltype(PC)::value;
