@@ -10,7 +10,9 @@ tail -12 gpurun_out/r4/final_profile_round.txt | cut -c1-200
 bash tools/profile_600.sh r4_600 > gpurun_out/r4/final_profile_600.txt 2>&1
 tail -12 gpurun_out/r4/final_profile_600.txt | cut -c1-200
 cd $GRAFT_REPO_ROOT
-python bench.py --dtype f32 --steps 20 --warmup 3 2>/dev/null | tail -1 > gpurun_out/r4_c_bench_f32.json
+bash tools/profile_f32.sh r4_f32 > gpurun_out/r4/final_profile_f32.txt 2>&1
+tail -30 gpurun_out/r4/final_profile_f32.txt | cut -c1-200
+cp gpurun_out/r4_f32_line.json gpurun_out/r4_c_bench_f32.json
 python bench.py --dtype f16 --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/r4_c_bench_f16.json
 python bench.py --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/r4_c_bench_driver_cmd.json
 python -c "
