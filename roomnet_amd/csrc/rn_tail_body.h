@@ -175,10 +175,12 @@ __device__ __forceinline__ void tail_phase(const TailArgs& a, const unsigned sho
         const float* srcs[9] = {a.a.mean, a.a.inv, a.a.beta, a.b.mean, a.b.inv, a.b.beta, a.mean2, a.inv2, a.beta2};
         ttab[tid] = srcs[t][c];
     }
-    // the dense layers' per-output constants of this thread: fetched now, used after the conv phases
-    float hd_bias[RN_MAX_DENSE], hd_inv[RN_MAX_DENSE], hd_shift[RN_MAX_DENSE];
+    // the dense layers' per-output constants of this thread: fetched now, used after the conv phases (the first HD_REG layers:
+    // 3 registers each, live across both conv phases of a kernel that has 168 per lane; deeper heads fetch theirs at the layer)
+    constexpr int HD_REG = 4;
+    float hd_bias[HD_REG], hd_inv[HD_REG], hd_shift[HD_REG];
 #pragma unroll
-    for (int d = 0; d < RN_MAX_DENSE; ++d) {
+    for (int d = 0; d < HD_REG; ++d) {
         const bool on = d < a.head.n_dense && tid < a.head.nout[d];
         hd_bias[d] = on && a.head.bias[d] ? a.head.bias[d][tid] : 0.f;
         hd_inv[d] = on && a.head.inv[d] ? a.head.inv[d][tid] : 0.f;
@@ -211,12 +213,12 @@ __device__ __forceinline__ void tail_phase(const TailArgs& a, const unsigned sho
             float v = 0.f;
             const float* wd = w_off[d] >= 0 ? wl + w_off[d] : h.w[d];
             for (int k = 0; k < nin; ++k) v = fmaf(cur[k], wd[k * nout + tid], v);
-            if (h.bias[d]) v = __fadd_rn(v, hd_bias[d]);
+            if (h.bias[d]) v = __fadd_rn(v, d < HD_REG ? hd_bias[d] : h.bias[d][tid]);
             if (h.tap_mm[d]) h.tap_mm[d][static_cast<int64_t>(img) * nout + tid] = v;
             v = fminf(fmaxf(v, 0.f), 6.f);
             if (h.tap_relu[d]) h.tap_relu[d][static_cast<int64_t>(img) * nout + tid] = v;
             if (h.inv[d]) {
-                v = __fadd_rn(__fmul_rn(v, hd_inv[d]), hd_shift[d]);
+                v = __fadd_rn(__fmul_rn(v, d < HD_REG ? hd_inv[d] : h.inv[d][tid]), d < HD_REG ? hd_shift[d] : h.shift[d][tid]);
                 if (h.tap_bn[d]) h.tap_bn[d][static_cast<int64_t>(img) * nout + tid] = v;
             }
             dst[tid] = v;
