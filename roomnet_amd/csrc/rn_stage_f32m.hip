@@ -123,9 +123,10 @@ __global__ __launch_bounds__(512) void stage_f32m_kernel(const F32StageArgs a) {
     f32x4 pre[LPT_MAX];
     auto fetch_row = [&](int j) {
         const float* row = in_img + static_cast<int64_t>(yc0 + j) * a.W * CIN;
+        // (unconditional: a thread without a chunk re-reads pixel 0 of the row; as predicated loads every one of them sat in a
+        //  basic block of its own behind an s_waitcnt vmcnt(0) that also drained the epilogue's stores)
 #pragma unroll
-        for (int i = 0; i < LPT_MAX; ++i)
-            if (ld_loff[i] >= 0) pre[i] = *reinterpret_cast<const f32x4*>(row + ld_goff[i]);
+        for (int i = 0; i < LPT_MAX; ++i) pre[i] = *reinterpret_cast<const f32x4*>(row + ld_goff[i]);
     };
     auto store_row = [&](int j) {
         char* dst = ring + (j % NSL) * rowbytes;

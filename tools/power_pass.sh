@@ -3,7 +3,7 @@
 # imply: tools/power_pass.sh > gpurun_out/r3/power.txt   (rocm-smi sampled once per second; the bench line's img/s)
 cd $GRAFT_REPO_ROOT
 smi() { rocm-smi --showclocks --showpower 2>&1 | grep -E "sclk|Package Power" | sed -e 's/.*sclk clock level: [0-9S]*: //' -e 's/.*Power (W): /W /' | tr '\n' ' '; echo; }
-for arm in "--dtype bf16" "--dtype f16" "--dtype bf16 --pair32"; do
+for arm in "--dtype bf16" "--dtype f16" "--dtype bf16 --pair32" "--dtype f32 --steps 600"; do
   echo "--- bench.py --steps 6000 $arm"
   T=$(mktemp)
   (while true; do echo "   [smi] $(smi)"; sleep 1; done) > $T &
