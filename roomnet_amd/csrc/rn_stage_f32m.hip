@@ -147,6 +147,20 @@ __global__ __launch_bounds__(512) void stage_f32m_kernel(const F32StageArgs a) {
         boff[kx] = (xrel0 + kx) * PIXB;
         bswz[kx] = chunk_swz<CP>(xrel0 + kx);
     }
+    // byte offset of the lane's B chunk inside a ring row, per kernel column and chunk pair of this wave (lane constants: computed
+    // per group in the row loop they were two VALU instructions each -- and VALU instructions do not hide behind the fp32 MFMA,
+    // tools/ubench/mfma_f32_valu.hip)
+    constexpr bool BQ_PRE = KQ / KS <= 4;      // (the 64-channel one-wave-per-tile stage has no 24 registers to spare)
+    [[maybe_unused]] int bq[3][BQ_PRE ? KQ / KS : 1];
+    if constexpr (BQ_PRE) {
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+            for (int qi = 0; qi < KQ / KS; ++qi) {
+                const int q = KS == 2 ? 2 * qi + kh : qi;
+                bq[kx][qi] = boff[kx] + (((2 * q + hh) ^ bswz[kx]) << 4);
+            }
+    }
     const int xc = x0c + xrel0;
     const int xo = PK ? xc / PS : xc;
     const bool lane_out = (PK ? (r % PS == 0 && r <= 32 - PK) : true) && xo < a.Wo && (xo - xo_blk0) < npt * NOUT_T;
@@ -168,7 +182,13 @@ __global__ __launch_bounds__(512) void stage_f32m_kernel(const F32StageArgs a) {
 
     const char* const wl_lane = wl + lane * 16;
 
-    for (int it = 0; it < nconv; ++it) {
+    // one row step; PH = it mod 3 for the pooled stages without residual (RING_ROT: the row loop is unrolled by three): the three
+    // rows of the vertical pooling ring are vring[PH] (oldest), vring[(PH + 1) % 3], vring[(PH + 2) % 3] -- the new row replaces
+    // the oldest in place instead of shifting the ring (32 v_mov per row).  The residual stages keep the shifting form: unrolled
+    // they spill.
+    constexpr bool RING_ROT = RING == 3 && !RES;
+    auto step = [&](auto PHC, int it) __attribute__((always_inline)) {
+        [[maybe_unused]] constexpr int PH = decltype(PHC)::value;
         const bool have_next = it + 3 < nin;
         if (have_next) fetch_row(it + 3);
         // which output row this conv row completes; a residual stage fetches the four skip neighbours of the lane's pixel NOW, in
@@ -201,21 +221,17 @@ __global__ __launch_bounds__(512) void stage_f32m_kernel(const F32StageArgs a) {
             }
         }
 
-        f32x16 acc;
-#pragma unroll
-        for (int g = 0; g < 16; ++g) acc[g] = 0.f;
+        f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};      // (the first MFMA's inline-zero C operand)
         const char* rowp[3];
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky) rowp[ky] = ring + ((it + ky) % NSL) * rowbytes;
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             const int ky = tap / 3, kx = tap % 3;
-            const char* pb = rowp[ky] + boff[kx];
 #pragma unroll
-            for (int q = 0; q < KQ; ++q) {
-                if (KS == 2 && (q & 1) != kh) continue;     // (wave-uniform: this wave's channel half)
-                const int c4 = 2 * q + hh;
-                const f32x4 b = *reinterpret_cast<const f32x4*>(pb + ((c4 ^ bswz[kx]) << 4));
+            for (int qi = 0; qi < KQ / KS; ++qi) {
+                const int q = KS == 2 ? 2 * qi + kh : qi;   // (wave-uniform: this wave's channel half)
+                const f32x4 b = *reinterpret_cast<const f32x4*>(rowp[ky] + (BQ_PRE ? bq[kx][BQ_PRE ? qi : 0] : boff[kx] + (((2 * q + hh) ^ bswz[kx]) << 4)));
                 const f32x4 wv = *reinterpret_cast<const f32x4*>(wl_lane + (tap * KQ + q) * 1024);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) acc = mfma_f32(wv[i], b[i], acc);
@@ -251,7 +267,14 @@ __global__ __launch_bounds__(512) void stage_f32m_kernel(const F32StageArgs a) {
                 hs = v;
             }
             float s = hs;
-            if constexpr (RING > 0) {
+            if constexpr (RING_ROT) {
+                static_assert(!RING_ROT || RING == 3, "pool 4");
+                float t = vring[PH % 3][g];                  // oldest first, as in the shifting form
+#pragma unroll
+                for (int i = 1; i < 3; ++i) t += vring[(PH + i) % 3][g];
+                s = t + s;
+                vring[PH % 3][g] = hs;
+            } else if constexpr (RING > 0) {
                 float t = vring[0][g];
 #pragma unroll
                 for (int i = 1; i < RING; ++i) t += vring[i][g];
@@ -298,6 +321,15 @@ __global__ __launch_bounds__(512) void stage_f32m_kernel(const F32StageArgs a) {
         if constexpr (NSL == 3) __syncthreads();          // everybody is past row `it` before its slot is refilled
         if (have_next) store_row(it + 3);
         __syncthreads();
+    };
+    if constexpr (RING_ROT) {
+        for (int it = 0; it < nconv; it += 3) {
+            step(IC<0>{}, it);
+            if (it + 1 < nconv) step(IC<1>{}, it + 1);
+            if (it + 2 < nconv) step(IC<2>{}, it + 2);
+        }
+    } else {
+        for (int it = 0; it < nconv; ++it) step(IC<0>{}, it);
     }
 }
 
