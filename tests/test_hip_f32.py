@@ -236,3 +236,27 @@ def test_matrix_core_f32_band_decomposition_does_not_change_bits(weights, parity
     finally:
         e1.close()
         e8.close()
+
+
+@pytest.mark.parametrize("side", [300, 600])
+def test_matrix_core_f32_at_other_input_sides(weights, side):
+    """The matrix-core float32 stages in column blocks / with other band counts (600 x 600 is the reference's default im_side,
+    network.py:21): same numbers as the per-node path up to the order of the K sum and of the pooling window sum."""
+    from roomnet_amd.synth import parity_batch
+    g = build_graph(6, side)
+    w = dict(weights)
+    w["dense/kernel"] = R.synth_dense_kernel_600(g.flat_len)
+    ims = parity_batch(side, seed=1)[[14, 22, 37]]
+    mm = _capi.Engine(g, w, device=0, dtype="f32", max_batch=3)
+    pn = _capi.Engine(g, w, device=0, dtype="f32", max_batch=3, taps=True)
+    try:
+        ids_a, probs_a = mm.forward_u8(ims)
+        ids_b, probs_b = pn.forward_u8(ims)
+        np.testing.assert_array_equal(ids_a, ids_b)
+        np.testing.assert_allclose(probs_a, probs_b, atol=5e-6, rtol=0)
+        for name in STAGE_OUT:
+            a, b = mm.tap(name, 3), pn.tap(name, 3)
+            assert float(np.abs(a - b).max()) <= 2e-5 * max(float(np.abs(b).max()), 1e-3), name
+    finally:
+        mm.close()
+        pn.close()
