@@ -169,6 +169,8 @@ __device__ __forceinline__ void tail_phase(const TailArgs& a, const unsigned sho
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int S = a.a.Si;
+    // (every barrier of this phase is lds_barrier(): the phases talk through LDS only; __syncthreads() also drained the stage
+    //  outputs' and taps' global stores -- a write acknowledgement of 1-2 us at each of its eight barriers)
     // per-channel tables -> LDS: stage a at ttab[0..47], stage b at ttab[48..95] followed by its second BN at ttab[96..143]
     if (tid < 144) {
         const int t = tid / 16, c = tid % 16;
@@ -186,23 +188,23 @@ __device__ __forceinline__ void tail_phase(const TailArgs& a, const unsigned sho
         hd_inv[d] = on && a.head.inv[d] ? a.head.inv[d][tid] : 0.f;
         hd_shift[d] = on && a.head.inv[d] ? a.head.shift[d][tid] : 0.f;
     }
-    __syncthreads();
+    lds_barrier();
     // ---- second and third step of the block: pooled rows dealt to the four waves
     {
         const int per = (a.a.So + 3) / 4;
         tail_stage<DT, false>(xin, xa, a.a, a, nullptr, 0, img, min(wave * per, a.a.So), min((wave + 1) * per, a.a.So), lane, ttab);
     }
-    __syncthreads();
+    lds_barrier();
     {
         const int per = (a.b.So + 3) / 4;
         tail_stage<DT, true>(xa, xb, a.b, a, xin, S, img, min(wave * per, a.b.So), min((wave + 1) * per, a.b.So), lane, ttab + 48);
     }
-    __syncthreads();
+    lds_barrier();
     // ---- flatten + dense chain + softmax + argmax: head_kernel's arithmetic, wave 0 computes
     const HeadArgs& h = a.head;
     const int nin0 = h.nin[0];
     for (int i = tid; i < nin0; i += 256) buf0[i] = from16<DT>(xb[i]);
-    __syncthreads();
+    lds_barrier();
     const float* cur = buf0;
 #pragma unroll
     for (int d = 0; d < RN_MAX_DENSE; ++d) {       // (unrolled: the per-layer constants above stay in registers)
@@ -223,7 +225,7 @@ __device__ __forceinline__ void tail_phase(const TailArgs& a, const unsigned sho
             }
             dst[tid] = v;
         }
-        __syncthreads();
+        lds_barrier();
         cur = dst;
     }
     if (wave != 0) return;
