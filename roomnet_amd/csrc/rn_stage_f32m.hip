@@ -245,7 +245,7 @@ __global__ __launch_bounds__(512) void stage_f32m_kernel(const F32StageArgs a) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(pbuf + i * 1024) = f32x4{acc[4 * i], acc[4 * i + 1], acc[4 * i + 2], acc[4 * i + 3]};
             }
-            __syncthreads();
+            lds_barrier();
             if (kh == 0) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
@@ -318,9 +318,10 @@ __global__ __launch_bounds__(512) void stage_f32m_kernel(const F32StageArgs a) {
             }
         }
 
-        if constexpr (NSL == 3) __syncthreads();          // everybody is past row `it` before its slot is refilled
+        // (lds_barrier: the waves talk through LDS only; the row's output stores stay in flight across it)
+        if constexpr (NSL == 3) lds_barrier();            // everybody is past row `it` before its slot is refilled
         if (have_next) store_row(it + 3);
-        __syncthreads();
+        lds_barrier();
     };
     if constexpr (RING_ROT) {
         for (int it = 0; it < nconv; it += 3) {
