@@ -214,7 +214,20 @@ __device__ __forceinline__ void tail_phase(const TailArgs& a, const unsigned sho
         if (tid < nout) {
             float v = 0.f;
             const float* wd = w_off[d] >= 0 ? wl + w_off[d] : h.w[d];
-            for (int k = 0; k < nin; ++k) v = fmaf(cur[k], wd[k * nout + tid], v);
+            // the same fma chain over k = 0 .. nin - 1, its operands read eight steps ahead of their use (one step at a time every
+            // fma waited for its own two LDS reads: 2 500 cycles for the 64-input layer; in-kernel stamps)
+            int k = 0;
+            for (; k + 8 <= nin; k += 8) {
+                float cv[8], wv[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    cv[j] = cur[k + j];
+                    wv[j] = wd[(k + j) * nout + tid];
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v = fmaf(cv[j], wv[j], v);
+            }
+            for (; k < nin; ++k) v = fmaf(cur[k], wd[k * nout + tid], v);
             if (h.bias[d]) v = __fadd_rn(v, d < HD_REG ? hd_bias[d] : h.bias[d][tid]);
             if (h.tap_mm[d]) h.tap_mm[d][static_cast<int64_t>(img) * nout + tid] = v;
             v = fminf(fmaxf(v, 0.f), 6.f);
@@ -231,16 +244,21 @@ __device__ __forceinline__ void tail_phase(const TailArgs& a, const unsigned sho
     if (wave != 0) return;
     const int nc = h.nout[h.n_dense - 1];
     const float logit = lane < nc ? cur[lane] : -INFINITY;
+    // butterflies over the smallest power-of-two group of lanes that holds the nc classes (lanes past it hold the neutral element
+    // and are never read back): three exchange steps instead of six for the six classes
+    int off0 = 1;
+    while (off0 < nc) off0 <<= 1;
+    off0 >>= 1;
     float mx = logit;
-    for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+    for (int off = off0; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
     const float e = lane < nc ? expf(logit - mx) : 0.f;
     float sum = e;
-    for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off);
+    for (int off = off0; off > 0; off >>= 1) sum += __shfl_xor(sum, off);
     const float p = e / sum;
     if (lane < nc) a.probs[static_cast<int64_t>(img) * nc + lane] = p;
     float bestv = lane < nc ? p : -1.f;
     int besti = lane < nc ? lane : 0x7fffffff;
-    for (int off = 32; off > 0; off >>= 1) {
+    for (int off = off0; off > 0; off >>= 1) {
         const float ov = __shfl_xor(bestv, off);
         const int oi = __shfl_xor(besti, off);
         if (ov > bestv || (ov == bestv && oi < besti)) {
@@ -261,7 +279,24 @@ __device__ __forceinline__ void tail_stage_dense(const HeadArgs& h, float* wl, i
         const int cnt = h.nin[d] * h.nout[d];
         if (off + cnt <= T_W_LDS) {
             w_off[d] = off;
-            for (int i = tid; i < cnt; i += nthreads) wl[off + i] = h.w[d][i];
+            // 16-byte pieces, every load of a thread issued before its first LDS store (element by element each store waited for
+            // its own load: eleven dependent L2 round trips per thread in front of the tail kernel's first barrier)
+            if (cnt % 4 == 0 && off % 4 == 0 && (reinterpret_cast<uintptr_t>(h.w[d]) & 15) == 0) {
+                const f32x4* src = reinterpret_cast<const f32x4*>(h.w[d]);
+                f32x4* dst = reinterpret_cast<f32x4*>(wl + off);
+                const int n4 = cnt / 4;
+                for (int i0 = 0; i0 < n4; i0 += 4 * nthreads) {
+                    f32x4 t[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        if (i0 + u * nthreads + tid < n4) t[u] = src[i0 + u * nthreads + tid];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        if (i0 + u * nthreads + tid < n4) dst[i0 + u * nthreads + tid] = t[u];
+                }
+            } else {
+                for (int i = tid; i < cnt; i += nthreads) wl[off + i] = h.w[d][i];
+            }
             off += cnt;
         }
     }
