@@ -923,20 +923,14 @@ int rn_fused_prepare(rn_handle* h, const rn_weights* w) {
             break;
         }
     // stage 0 inside stage 1's kernel: the 8-channel register-weights variant computes stage 0 for its own ring columns
-    // (network.py:226 feeding :227's first step); needs the arithmetic form of the pre-processing table
+    // (network.py:226 feeding :227's first step)
     if (!(h->flags & (RN_FLAG_STAGE_LAUNCHES | RN_FLAG_GENERIC_KERNELS)) && h->stages.size() > 1) {
         const StagePlan& s1 = h->stages[1];
         bool feeds_others = false;
         for (size_t k = 2; k < h->stages.size(); ++k) feeds_others |= h->stages[k].skip_stage == 0;
         fs->fuse_s0 = fs->st[1].use_rw && fs->st[1].rw.variant == 0 && s1.skip_stage < 0 && !feeds_others;
-#ifdef RN_X_NO_S0F      // (A/B timing builds)
-        fs->fuse_s0 = false;
-#endif
     }
     fs->use_tail = !(h->flags & (RN_FLAG_STAGE_LAUNCHES | RN_FLAG_GENERIC_KERNELS)) && rn_tail_supported(h);
-#ifdef RN_X_NO_TAIL     // (A/B timing builds)
-    fs->use_tail = false;
-#endif
     {
         const size_t ns = h->stages.size();
         fs->use_backend = fs->use_tail && !(h->flags & RN_FLAG_PAIR_32X32) && ns >= 5 && rn_backend_supported(h) && fs->st[ns - 4].use_s6x &&

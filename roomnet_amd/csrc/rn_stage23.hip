@@ -31,14 +31,9 @@ using namespace rnk;
 // With NO "a" constraint anywhere in the kernel LLVM's attributor marks it amdgpu-no-agpr and the allocator gets one flat
 // file of 256 VGPRs per wave; with any "a" constraint it splits the wave's 256 registers 128 + 128 between architectural
 // and accumulator registers, and everything the VALU touches has to fit the 128 (spilled to AGPRs and copied back:
-// 300-500 v_accvgpr moves in this kernel).  -DRN_X_AGPR_PIN restores the pinned form for A/B timing.
-#ifdef RN_X_AGPR_PIN
-#define RN_WREG_OUT(x) "=a"(x)
-#define RN_WREG_IO(x) "+a"(x)
-#else
+// 300-500 v_accvgpr moves in this kernel).
 #define RN_WREG_OUT(x) "=v"(x)
 #define RN_WREG_IO(x) "+v"(x)
-#endif
 
 namespace {
 
@@ -89,10 +84,7 @@ __device__ __forceinline__ unsigned long long stamp23() {
 // handful of spilled registers costs 25 % and hipcc says nothing.
 template <int DT>
 __global__ __launch_bounds__(512, 2) void stage23pc_kernel(const Stage23Args a) {
-    #ifndef RN_X_BAHEAD
-#define RN_X_BAHEAD 4
-#endif
-    constexpr int KC = 18, BAHEAD = RN_X_BAHEAD;
+    constexpr int KC = 18, BAHEAD = 4;
     extern __shared__ __attribute__((aligned(64))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -316,16 +308,9 @@ __global__ __launch_bounds__(512, 2) void stage23pc_kernel(const Stage23Args a) 
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const f32x4 sc = tsc[g], sh = tsh[g];
-#ifdef RN_X_SCALAR_FMA
-                float yv[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) yv[j] = __builtin_fmaf(H[4 * g + j], sc[j], sh[j]);
-                const i32x2 d = {static_cast<int>(pack2<DT>(yv[0], yv[1])), static_cast<int>(pack2<DT>(yv[2], yv[3]))};
-#else
                 const f32x2 y0 = pk_fma(f32x2{H[4 * g], H[4 * g + 1]}, f32x2{sc[0], sc[1]}, f32x2{sh[0], sh[1]});
                 const f32x2 y1 = pk_fma(f32x2{H[4 * g + 2], H[4 * g + 3]}, f32x2{sc[2], sc[3]}, f32x2{sh[2], sh[3]});
                 const i32x2 d = {static_cast<int>(pack2<DT>(y0[0], y0[1])), static_cast<int>(pack2<DT>(y1[0], y1[1]))};
-#endif
                 asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(wb[T] ^ static_cast<unsigned>(g << 4)), "v"(d), "n"(off) : "memory");
             }
         };
@@ -586,18 +571,6 @@ __global__ __launch_bounds__(512, 2) void stage23pc_kernel(const Stage23Args a) 
              [&] {
             constexpr int g = G;
             const f32x4 sc1 = tsc1[g], sh1 = tsh1[g], sc2 = tsc2[g];
-#ifdef RN_X_SCALAR_FMA
-            float yv[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float y1 = __builtin_fmaf(H[4 * g + j], sc1[j], sh1[j]);
-                const float lo = r_lo[4 * g + j];
-                const float rs = __builtin_fmaf(r_hi[4 * g + j] - lo, cx.yl, lo);
-                yv[j] = __builtin_fmaf(rs, sc2[j], y1);
-            }
-            pk[g].x = pack2<DT>(yv[0], yv[1]);
-            pk[g].y = pack2<DT>(yv[2], yv[3]);
-#else
             f32x2 y[2];
             const f32x2 ylv = pk_splat(cx.yl);
 #pragma unroll
@@ -611,7 +584,6 @@ __global__ __launch_bounds__(512, 2) void stage23pc_kernel(const Stage23Args a) 
             }
             pk[g].x = pack2<DT>(y[0][0], y[0][1]);
             pk[g].y = pack2<DT>(y[1][0], y[1][1]);
-#endif
              }()),
              ...);
         }(std::make_integer_sequence<int, 4>{});
