@@ -23,8 +23,8 @@
 //     an fma, and the pooled tile never touches LDS or HBM before its final store.
 //   * neighbouring pixel tiles overlap by k-1 columns so that no cross-wave exchange is
 //     needed for the horizontal pool.
-// Stage 0 (3 input channels, K = 27) is not GEMM-shaped: `stage0_kernel` is a direct
-// VALU kernel that also fuses the uint8 -> [-1,1] pre-processing table.
+// Stage 0 (3 input channels, K = 27) runs on the matrix cores too (`stage0_kernel` below): its operand is the
+// uint8 pixel value, the uint8 -> [-1,1] pre-processing of network.py:129 is folded into its weights.
 #include "rn_fused.h"
 #include <map>
 #include <vector>
@@ -964,7 +964,7 @@ int rn_fused_launch_rep(const rn_handle* h, int stage) {
 int rn_fused_forward(rn_handle* h, const uint8_t* d_bgr, const float* d_rgb, int n, float* d_probs,
                      int64_t* d_ids) {
     if (!d_bgr || d_rgb) {
-        rn_set_error("16-bit handles take uint8 BGR input (the pre-processing table is fused into stage 0)");
+        rn_set_error("16-bit handles take uint8 BGR input (the pre-processing is folded into stage 0's weights)");
         return RN_E_STATE;
     }
     FusedState* fs = static_cast<FusedState*>(h->fused);
