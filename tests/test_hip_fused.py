@@ -77,6 +77,23 @@ def test_stage_outputs_vs_oracle(engine, weights, parity_images, record):
 def test_stage_outputs_vs_oracle_stagewise(engine_stagewise, weights, parity_images, record):
     _check_stage_outputs(engine_stagewise, weights, parity_images, record=record, label="one_launch_per_stage")
 
+
+def test_stage0_is_exact_up_to_the_rounding_of_its_output(engine_stagewise, weights, parity_images):
+    """Stage 0 of the 16-bit path multiplies the exact byte values by weights held as fp16 hi + lo pairs (rn_stage.h,
+    s0_pixel_halves) and accumulates in float32: what is left against the oracle is the ONE rounding of its output to
+    the storage type -- half an ulp of the value, element by element (2^-12 of the value for fp16, 2^-9 for bf16), plus
+    float32 summation noise.  With fp16-rounded inputs and weights the error was ~10 x that of the output rounding."""
+    idx = [0, 3, 26, 14]
+    ims = parity_images[idx]
+    want = np.asarray(c_oracle.infer(weights, ims, taps=True)["taps"]["s0.bn"], dtype=np.float64)
+    engine_stagewise.forward_u8(ims)
+    got = engine_stagewise.tap("s0.bn", len(idx)).astype(np.float64)
+    half_ulp = 2.0 ** -12 if engine_stagewise.dtype_name == "f16" else 2.0 ** -9
+    # (half an ulp relative to the value can reach 2 x half_ulp just above a power of two; 5e-6 absolute: float32 sums of ~100)
+    bound = 2.0 * half_ulp * np.abs(want) + 5e-6 * np.abs(want).max()
+    bad = np.abs(got - want) > bound
+    assert not bad.any(), (int(bad.sum()), float(np.abs(got - want).max()), float(np.abs(want).max()))
+
 def _same_up_to_sum_order(a, b, dtype, what, frac=1e-5, n_ulp=2):
     """Equal bit for bit -- except where the fp32 ORDER of the pooling sums shows through the 16-bit rounding: the fused
     pair adds its fp16 window terms in 16x16x32 MFMAs, the stage kernels in 32x32x16 ones, and a sum of fp16 values of
