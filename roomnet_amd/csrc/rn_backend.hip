@@ -103,7 +103,7 @@ __global__ __launch_bounds__(704) void backend_kernel(const BackendArgs a) {
         if (p >= W) *reinterpret_cast<i32x4*>(ring6 + slot * B_ROW6 + p * 128 + c * 16) = i32x4{0, 0, 0, 0};
     }
     int w_off[RN_MAX_DENSE];
-    tail_stage_dense(a.tail.head, reinterpret_cast<float*>(smem + B_OFF_WL), w_off, tid, 704);
+    tail_stage_dense_dma(a.tail.head, reinterpret_cast<float*>(smem + B_OFF_WL), w_off, wave, lane, 11);
 
     if (wave < 8) {
         // =============================================================== stage 6 (rn_stage6x.hip), output into the mid ring

@@ -302,6 +302,36 @@ __device__ __forceinline__ void tail_stage_dense(const HeadArgs& h, float* wl, i
     }
 }
 
+// The same staging by LDS-DMA (global_load_lds_dwordx4: no registers, nothing waits for it here): `nwaves` waves, wave `wave`
+// takes every nwaves-th kilobyte.  The caller retires it (vmcnt) before the first read -- in the back end the whole stage-6 /
+// stage-7 row loop lies in between; as register loads + LDS stores in front of that loop every wave waited ~10 000 cycles for
+// the first touch of the dense kernels (in-kernel stamps).  Layers that are not 16-byte granular fall back to tail_stage_dense's
+// element loop.
+__device__ __forceinline__ void tail_stage_dense_dma(const HeadArgs& h, float* wl, int (&w_off)[RN_MAX_DENSE], int wave, int lane, int nwaves) {
+    int off = 0;
+#pragma unroll
+    for (int d = 0; d < RN_MAX_DENSE; ++d) {
+        w_off[d] = -1;
+        if (d >= h.n_dense) continue;
+        const int cnt = h.nin[d] * h.nout[d];
+        if (off + cnt <= T_W_LDS) {
+            w_off[d] = off;
+            if (cnt % 4 == 0 && off % 4 == 0 && (reinterpret_cast<uintptr_t>(h.w[d]) & 15) == 0) {
+                const int n4 = cnt / 4;
+                const char* src = reinterpret_cast<const char*>(h.w[d]);
+                char* dst = reinterpret_cast<char*>(wl + off);
+                for (int i0 = wave * 64; i0 < n4; i0 += nwaves * 64) {
+                    const unsigned long long mask = n4 - i0 >= 64 ? ~0ull : (1ull << (n4 - i0)) - 1ull;
+                    dma16_masked(src + static_cast<size_t>(i0 + lane) * 16, dst + static_cast<size_t>(i0) * 16, mask);
+                }
+            } else {
+                for (int i = wave * 64 + lane; i < cnt; i += nwaves * 64) wl[off + i] = h.w[d][i];
+            }
+            off += cnt;
+        }
+    }
+}
+
 }  // namespace rnk
 
 void rn_tail_fill_args(rn_handle* h, const rnk::i32x4* wfrag_a, const rnk::i32x4* wfrag_b, const HeadArgs& head, float* d_probs, int64_t* d_ids,
