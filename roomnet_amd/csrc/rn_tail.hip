@@ -37,7 +37,7 @@ __global__ __launch_bounds__(256) void tail_kernel(const TailArgs a) {
         for (int i = tid; i < nchunk; i += 256) reinterpret_cast<i32x4*>(xin)[i] = src[i];
     }
     int w_off[RN_MAX_DENSE];
-    tail_stage_dense(a.head, wl, w_off, tid, 256);
+    tail_stage_dense_dma(a.head, wl, w_off, __builtin_amdgcn_readfirstlane(tid >> 6), tid & 63, 4);      // lands while the conv phases run; tail_phase retires it
     tail_phase<DT>(a, xin, xa, xb, buf0, small, wl, w_off, ttab, img, tid);
 }
 

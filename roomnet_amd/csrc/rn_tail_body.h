@@ -204,6 +204,7 @@ __device__ __forceinline__ void tail_phase(const TailArgs& a, const unsigned sho
     const HeadArgs& h = a.head;
     const int nin0 = h.nin[0];
     for (int i = tid; i < nin0; i += 256) buf0[i] = from16<DT>(xb[i]);
+    wait_vmcnt<0>();          // the dense kernels' LDS-DMA of this wave (tail_stage_dense_dma) has landed; the barrier publishes it
     lds_barrier();
     const float* cur = buf0;
 #pragma unroll
