@@ -10,7 +10,7 @@ if [ "${1:-}" = "hwid" ]; then SUF="_hwid"; DEFS+=(-DRN_STAMP_HWID); fi
 OBJ="$ROOT/build/stamps$SUF"; mkdir -p "$OBJ"
 FLAGS=(--offload-arch=gfx950 -O3 -std=c++20 -fno-slp-vectorize -fPIC -fvisibility=hidden -I"$ROOT/include" -I"$SRC"
        -Wall -Wno-unused-function -DRN_BUILDING "${DEFS[@]}")
-for f in rn_api rn_kernels_f32 rn_fused rn_imageops rn_group rn_tail rn_conv16; do /opt/rocm/bin/hipcc "${FLAGS[@]}" -c "$SRC/$f.hip" -o "$OBJ/$f.o" & done
+for f in rn_api rn_kernels_f32 rn_fused rn_imageops rn_group rn_tail rn_conv16 rn_stage_f32m rn_backend; do /opt/rocm/bin/hipcc "${FLAGS[@]}" -c "$SRC/$f.hip" -o "$OBJ/$f.o" & done
 /opt/rocm/bin/hipcc "${FLAGS[@]}" -mllvm -amdgpu-mfma-vgpr-form -c "$SRC/rn_stage_rw.hip" -o "$OBJ/rn_stage_rw.o" &
 /opt/rocm/bin/hipcc "${FLAGS[@]}" -mllvm -amdgpu-mfma-vgpr-form -c "$SRC/rn_stage23.hip" -o "$OBJ/rn_stage23.o" &
 /opt/rocm/bin/hipcc "${FLAGS[@]}" -mllvm -amdgpu-mfma-vgpr-form -c "$SRC/rn_stage23x.hip" -o "$OBJ/rn_stage23x.o" &
