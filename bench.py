@@ -15,22 +15,24 @@ collective run on ONE explicit (non-default) stream, so the all-gather is stream
 Before anything is timed the SAME handle classifies the 40 parity images (roomnet_amd/synth.parity_batch) and the
 result is checked against tests/golden/parity_224.npz at the SURVEY 8c tolerance: the timed kernels are the tested ones.
 
-Clock spin-up: the engine clock takes tens of milliseconds of load to leave its idle state and the driver's W = 5 warm-up
-steps are 7 ms, so `--spinup-steps` (default 240, ~0.3 s) of the same passes run, untimed, BEFORE the W warm-up steps; then W
-warm-up steps, then EXACTLY K timed steps between barriers as the contract says.  A 20-step sample then shows the sustained
-rate a 200- or 6000-step run shows (measured on one box: 190 k img/s cold, 202 k with the spin-up, 202 k at 200 steps);
-the count is reported as `spinup_steps`, `--spinup-steps 0` turns it off.
+Two measurements per run, both complete passes, both reported.  (1) the COLD / contract pass: W warm-up steps and K timed
+steps on a chip that idled through the parity check, nothing else in front of it -> `cold_images_per_sec` (the strict reading
+of the command line; with the driver's W = 5, K = 20 that is 33 ms of work, inside the tens of milliseconds the engine clock
+needs to leave its idle state: it reads ~5 % low).  (2) `value`: W warm-up steps + K timed steps again, on the same handle,
+directly behind (1) -- so `value` is preceded by W + K + W untimed-for-value steps, reported as `untimed_steps_before_value`
+(+ `--spinup-steps`, default 0).  `--no-cold-pass` drops (1): then `value` IS the strict reading.
 
-Two handles: the steps alternate between two engine handles (own activation tensors, own stream, own result buffer), so the
-small launches at the end of step k (stages 6, 7 and the tail: one latency-bound workgroup per image) overlap the first launch
-of step k + 1: +1-1.5 % (`--handles 1`: one handle, strictly serial steps).  Every step is one complete pass over one
-resident batch; both handles pass the parity gate; `ms_per_step` = elapsed / K can be a little below the sum of the launch
-times, which are measured on one handle alone.
+`--handles 2` (default 1): the steps alternate between two engine handles (own activation tensors, stream, result buffer) so
+the last launch of step k overlaps the first of step k + 1 (+0.3 % since the back end is one launch).
+
+`python3 bench.py --gpus N` without a launcher (no WORLD_SIZE in the environment) starts the N ranks itself (`self_launch`)
+before torch / HIP are touched; under torch.distributed.run it is one of the ranks.
 
 Rank 0 prints ONE JSON line.  Extra objects:
-  roofline      the dominant launch (longest kernel, timed live with HIP events on the launch stream): ALGORITHMIC
-                stage-boundary bytes of the stages it computes / duration vs 8 TB/s (SURVEY.md 8d byte model; a
-                cross-stage fused launch is credited with the bytes of all its stages, `traffic` shows what it moves)
+  roofline      `frac` = the whole path against the roof the target is stated in (images/sec x 27.309 MB
+                / (n_gpu x 8 TB/s)); `launches[]` = every launch of a step timed live with HIP events on the launch stream, each
+                with `credited_frac` (algorithmic stage-boundary bytes of the stages it computes / time: a fused launch is
+                credited with tensors that stay in LDS), `physical_frac` (PMC HBM bytes / time) and `mfma_frac`
   cpu_baseline  the CPU restatements (oracle/) timed on this host's cores on a bounded sample: batch-1 loop
                 (infer.py:79-82) and batch 8, all cores and 1 thread, median of 3 -- a reported baseline, not the target
 """
@@ -212,6 +214,40 @@ def _rendezvous(world):
     return {"init_method": "tcp://127.0.0.1:%d" % port}
 
 
+def self_launch(n, argv):
+    """`python3 bench.py --gpus N` without a launcher (no WORLD_SIZE / RANK in the environment): start the N ranks as
+    child processes of THIS file -- before torch is imported or anything touches HIP in this process, and never by exec --
+    one per GPU, rendezvous on 127.0.0.1; rank 0 writes its JSON line straight to our stdout, the other ranks' stdout goes
+    to stderr.  Returns the exit code (first failing rank's; the others are then ended by PID)."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RN_BENCH_SELF_LAUNCHED="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        env.setdefault("OMP_NUM_THREADS", "1")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=None if r == 0 else sys.stderr))
+    rc = 0
+    live = list(procs)
+    while live:
+        for p in list(live):
+            try:
+                code = p.wait(timeout=0.2)
+            except subprocess.TimeoutExpired:
+                continue
+            live.remove(p)
+            if code != 0 and rc == 0:
+                rc = code
+                for q in live:                     # a rank died: the others would wait in a collective forever
+                    q.terminate()
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -247,6 +283,8 @@ def main():
                          "path.pcie_inclusive_images_per_sec, never as `value`")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        sys.exit(self_launch(args.gpus, sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -531,6 +569,7 @@ def main():
                        "images_per_gpu": B, "global_batch": world * B, "im_side": args.side,
                        "parallelism": "dp%d" % world},
             "parity": parity, "spinup_steps": spinup_steps, "handles": len(engs),
+            "untimed_steps_before_value": (args.warmup + args.steps if cold_elapsed is not None else 0) + spinup_steps + args.warmup,
         }
         if cold_elapsed is not None:
             out["cold_images_per_sec"] = world * B * args.steps / cold_elapsed
@@ -538,46 +577,55 @@ def main():
                            "spinup_steps": 0, "what": "the same W + K steps timed BEFORE the spin-up on one handle, strictly serial: "
                                                      "the figure of a strict reading of the command line"}
         if not stub:
+            # ---- roofline: the WHOLE PATH against the roof the target is stated in (BASELINE.md section 3:
+            # img/s x algorithmic bytes per image / (n_gpu x 8 TB/s); float32: img/s x flops per image / matrix-fp32 peak).
+            # Per launch (`launches[]`, HIP events on the launch stream): `credited_frac` = algorithmic stage-boundary bytes of
+            # every stage the launch computes / its time / 8 TB/s -- a fused launch is credited with tensors that never leave
+            # LDS, so this figure is NOT a bandwidth and may pass 1; `physical_frac` = what the PMC counters say the launch
+            # moved (profiles/*_hbm_traffic.json of this configuration) / its time / 8 TB/s; `mfma_frac` = algorithmic conv
+            # flops / time / dense matrix peak of the dtype.
             dom = int(np.argmax(group_ms))
-            dom_stages = groups[dom]
-            dom_bytes = sum(sbytes[k] for k in dom_stages) * B
-            dom_s = group_ms[dom] * 1e-3
-            if f32:
-                # float32: the matrix-fp32 roofline bounds the path
-                dom_flops = sum(sflops[k] for k in dom_stages) * B
-                out["roofline"] = {"bound": "mfma", "achieved": dom_flops / dom_s / 1e12, "peak": MFMA_PEAK_F32 / 1e12,
-                                   "unit": "TFLOP/s", "frac": dom_flops / dom_s / MFMA_PEAK_F32, "traffic": None,
-                                   "kernel": "stage_f32m_kernel (v_mfma_f32_32x32x2_f32), stage %d" % dom_stages[0], "stages": dom_stages,
-                                   "kernel_ms": group_ms[dom], "algorithmic_flops_per_launch": dom_flops}
-            else:
-                achieved = dom_bytes / dom_s
-                s0 = graph.stages[dom_stages[0]]
-                if len(dom_stages) > 1 and dom_stages[0] == 0:
+            mfma_peak = MFMA_PEAK_F32 if f32 else MFMA_PEAK_16
+            launches = []
+            for j, g in enumerate(groups):
+                sec = max(group_ms[j], 1e-9) * 1e-3
+                gb = sum(sbytes[k] for k in g) * B
+                gf = sum(sflops[k] for k in g) * B
+                tr = measured_traffic(g, B, args.side, args.dtype)
+                s0 = graph.stages[g[0]]
+                if f32:
+                    kname = "stage_f32m_kernel / per-node kernels, stage %s" % "+".join(map(str, g))
+                elif len(g) > 1 and g[0] == 0:
                     kname = "stage_rw_kernel (S0F), stages 0+1 fused (3->8->32 ch)"
-                elif len(dom_stages) > 1 and dom_stages[-1] == len(graph.stages) - 1:
-                    kname = "tail_kernel, stages %s + dense head fused" % "+".join(map(str, dom_stages))
-                elif len(dom_stages) > 1:
+                elif len(g) > 1 and g[-1] == n_st - 1:
+                    kname = "%s, stages %s + dense head fused" % ("backend_kernel" if g[0] == 6 else "tail_kernel", "+".join(map(str, g)))
+                elif len(g) > 1:
                     kname = "%s, stages %s fused (%d->%d ch x%d + residual)" % (
-                        "stage23pc_kernel" if args.pair32 else "stage23x_kernel", "+".join(map(str, dom_stages)), s0.cin, s0.cout, len(dom_stages))
-                elif dom_stages[0] == 0:
-                    kname = "stage0_kernel"
+                        "stage23pc_kernel" if args.pair32 else "stage23x_kernel", "+".join(map(str, g)), s0.cin, s0.cout, len(g))
                 else:
-                    kname = "stage_rw_kernel, stage %d (%d->%d ch%s)" % (dom_stages[0], s0.cin, s0.cout,
-                                                                         " + residual" if s0.residual else "")
-                traffic = measured_traffic(dom_stages, B, args.side, args.dtype)
-                dom_flops = sum(sflops[k] for k in dom_stages) * B
-                out["roofline"] = {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                                   "frac": achieved / HBM_PEAK,
-                                   "traffic": traffic,
-                                   "kernel": kname, "stages": dom_stages, "kernel_ms": group_ms[dom],
-                                   "algorithmic_bytes_per_launch": int(dom_bytes),
-                                   # `achieved` / `frac` are EFFECTIVE figures under the contract's stage-boundary byte model
-                                   # (SURVEY 8d): a launch that fuses stages is credited with the bytes those stages would
-                                   # move as separate launches.  What the launch physically moves is `traffic` (PMC):
-                                   "achieved_kind": "effective: algorithmic stage-boundary bytes of every stage the launch computes / launch time",
-                                   "measured_gbps": None if traffic is None else traffic / dom_s / 1e9,
-                                   "measured_frac": None if traffic is None else traffic / dom_s / HBM_PEAK,
-                                   "mfma_frac": dom_flops / dom_s / MFMA_PEAK_16}
+                    kname = "stage %d kernel (%d->%d ch%s)" % (g[0], s0.cin, s0.cout, " + residual" if s0.residual else "")
+                launches.append({"kernel": kname, "stages": g, "ms": group_ms[j], "algorithmic_bytes": int(gb),
+                                 "credited_frac": gb / sec / HBM_PEAK, "traffic": tr,
+                                 "physical_frac": None if tr is None else tr / sec / HBM_PEAK,
+                                 "mfma_frac": gf / sec / mfma_peak})
+            traffics = [l["traffic"] for l in launches]
+            path_traffic = None if any(t is None for t in traffics) else int(sum(traffics))
+            bpi = graph.boundary_elements_per_image() * elem
+            if f32:
+                ach = value * graph.flops_per_image() / world
+                out["roofline"] = {"bound": "mfma", "achieved": ach / 1e12, "peak": MFMA_PEAK_F32 / 1e12, "unit": "TFLOP/s",
+                                   "frac": ach / MFMA_PEAK_F32, "traffic": path_traffic,
+                                   "scope": "whole path: images/sec x 4.4864 GFLOP per image (SURVEY 8d) / matrix-fp32 peak per GPU",
+                                   "dominant": dom, "launches": launches}
+            else:
+                ach = value * bpi / world
+                out["roofline"] = {"bound": "hbm", "achieved": ach / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                                   "frac": ach / HBM_PEAK, "traffic": path_traffic,
+                                   "scope": "whole path (BASELINE.md section 3): images/sec x algorithmic stage-boundary bytes per image "
+                                            "/ (n_gpu x 8 TB/s); `traffic` = physical HBM bytes of one step (PMC, all launches)",
+                                   "algorithmic_bytes_per_step": int(bpi * B),
+                                   "physical_frac": None if path_traffic is None else path_traffic / (elapsed / args.steps) / HBM_PEAK,
+                                   "dominant": dom, "launches": launches}
             med = float(np.median(event_ms))
             out["path"] = {"algorithmic_bytes_per_image": int(bytes_per_img),
                            "hbm_frac": value * bytes_per_img / (world * HBM_PEAK),

@@ -216,8 +216,14 @@ RN_API int rn_set_stream_null(rn_handle* h);
 
 /* ---- introspection -----------------------------------------------------------
  * rn_tap copies graph node `node_id` of the last forward call to host float32
- * (layout [n, h, w, c]); needs RN_FLAG_TAPS for conv/pool/add nodes, stage
- * outputs ("sK.bn" / "sK.bn2") are always available.  This is the per-layer
+ * (layout [n, h, w, c]); needs RN_FLAG_TAPS for conv/pool/add nodes; the
+ * tensors a launch WRITES are always available: every stage's output node
+ * ("sK.bn", for the residual stages "sK.bn2") unless the stage is fused into
+ * its successor's launch.  The first BN output "sK.bn" of a residual stage
+ * exists only where that stage runs one launch per graph node (float32 handles
+ * with RN_FLAG_TAPS, and stages the matrix-core float32 kernels do not cover);
+ * 16-bit handles never materialise it.  Asking for a node that was not written
+ * returns RN_E_STATE.  This is the per-layer
  * debug read-out the reference gets from self.layers (network.py:30, :207). */
 RN_API int rn_node_count(const rn_handle* h);
 RN_API int rn_node_info_get(const rn_handle* h, int node_id, rn_node_info* out);

@@ -842,6 +842,16 @@ extern "C" int rn_tap(rn_handle* h, int node_id, float* out, size_t cap_elems, s
     }
     const bool shared_scratch = !(h->flags & RN_FLAG_TAPS) && !fused_mode(h);
     if (shared_scratch) {
+        // a residual stage that runs as ONE matrix-core launch (rn_stage_f32m.hip) writes its output node (sK.bn2) only: the
+        // first BN output never leaves the kernel
+        for (size_t i = 0; i < h->stages.size(); ++i) {
+            const StagePlan& s = h->stages[i];
+            if (node_id == s.node_bn && s.node_bn2 >= 0 && rn_f32m_covers(h, static_cast<int>(i))) {
+                rn_set_error("rn_tap: node %s stays inside the stage's matrix-core launch on this handle and is never written "
+                             "(create with RN_FLAG_TAPS)", nb.info.name);
+                return RN_E_STATE;
+            }
+        }
         const char* nm = nb.info.name;
         const size_t len = std::strlen(nm);
         const bool inter = (len > 5 && (!std::strcmp(nm + len - 5, ".conv") || !std::strcmp(nm + len - 5, ".pool"))) ||

@@ -669,6 +669,14 @@ int rn_fused_prepare(rn_handle* h, const rn_weights* w) {
                     } else {
                         continue;
                     }
+                    // the folded values live in fp16 hi + lo pairs: a checkpoint whose stage-0 weights (or their sum over the
+                    // 27 taps) reach 65504 / 2^8 = 255.9 would turn into infinities and NaN outputs without a word.  (Small
+                    // weights are safe: hi + lo resolves 2^-24 absolutely, below the fp32 ulp of any weight above 2^-1.)
+                    if (!(std::fabs(v) < 65504.0)) {
+                        rn_set_error("16-bit path: stage-0 weight fold out of fp16 range (cout %d: |%g| >= 65504 after the 2^8 scale; "
+                                     "conv2d/kernel must stay below ~255 per weight and per 27-tap sum) -- use RN_DTYPE_F32", co, v);
+                        return RN_E_INVALID;
+                    }
                     const unsigned short hi = f32_to_f16(static_cast<float>(v));
                     const unsigned short lo = f32_to_f16(static_cast<float>(v - static_cast<double>(f16_to_f32(hi))));
                     frag[(ky * 64 + l) * 8 + j] = part == 0 ? hi : lo;
@@ -1017,10 +1025,10 @@ int rn_fused_forward(rn_handle* h, const uint8_t* d_bgr, const float* d_rgb, int
             for (size_t k = i; k + 1 < ns; ++k) rn_record_event(h, 2 + static_cast<int>(k));
             HeadArgs head;
             rn_fill_head_args(h, &head);
-            fs->last_backend = true;
             int rc = rn_backend_launch(h, fs->st[ns - 4].wfrag16, fs->st[ns - 4].ptab, fs->st[ns - 3].wfrag16, fs->st[ns - 3].ptab, fs->st[ns - 2].wfrag,
                                        fs->st[ns - 1].wfrag, head, n, d_probs, d_ids);
             if (rc != RN_OK) return rc;
+            fs->last_backend = true;         // (only now: a failed launch must not report s6.bn / s7.bn as elided)
             rn_record_event(h, 2 + static_cast<int>(ns - 1));
             rn_record_event(h, 2 + static_cast<int>(ns));
 #ifdef RN_CLOCK

@@ -303,11 +303,12 @@ __device__ __forceinline__ void tail_stage_dense(const HeadArgs& h, float* wl, i
     }
 }
 
-// The same staging by LDS-DMA (global_load_lds_dwordx4: no registers, nothing waits for it here): `nwaves` waves, wave `wave`
-// takes every nwaves-th kilobyte.  The caller retires it (vmcnt) before the first read -- in the back end the whole stage-6 /
-// stage-7 row loop lies in between; as register loads + LDS stores in front of that loop every wave waited ~10 000 cycles for
-// the first touch of the dense kernels (in-kernel stamps).  Layers that are not 16-byte granular fall back to tail_stage_dense's
-// element loop.
+// The same staging by LDS-DMA (global_load_lds_dwordx4: no registers, no LDS store instructions): `nwaves` waves, wave `wave`
+// takes every nwaves-th kilobyte.  The caller retires it (vmcnt) before the first read.  In the back end it is issued in front
+// of the weight-fragment loads and retires WITH them at the prologue's `s_waitcnt vmcnt(0)` (the row loop's counted waits start
+// from an empty queue), so it does not ride under the row loop: what it saves against register loads + LDS stores in front of
+// the loop (every wave ~10 000 cycles there, in-kernel stamps) is the second round trip and the store issue, ~2 us of the
+// launch.  Layers that are not 16-byte granular fall back to tail_stage_dense's element loop.
 __device__ __forceinline__ void tail_stage_dense_dma(const HeadArgs& h, float* wl, int (&w_off)[RN_MAX_DENSE], int wave, int lane, int nwaves) {
     int off = 0;
 #pragma unroll

@@ -66,7 +66,16 @@ def _classify(nn, ims):
     return outs if isinstance(outs, tuple) else (outs, None)
 
 
-DECODE_THREADS = min(16, os.cpu_count() or 1)
+def _usable_cores():
+    try:
+        return len(os.sched_getaffinity(0))          # the cores THIS process may run on (cgroup / taskset aware)
+    except (AttributeError, OSError):
+        return os.cpu_count() or 1
+
+
+# Pillow releases the GIL inside the decoder, the array conversions around it do not: past ~64 threads the pool only queues on
+# the GIL (tools/bench_images.py --threads sweeps it; DESIGN.md section 5 has the figures of the GPU box's 256-thread host).
+DECODE_THREADS = max(1, min(64, _usable_cores()))
 
 
 def _infer_files(nn, fpaths, batch_size, decode_threads=None):

@@ -36,6 +36,43 @@ def test_bench_two_ranks_gloo_stub_engine():
     assert d["unit"] == "images/sec" and d["higher_is_better"] is True and d["vs_baseline"] is None
 
 
+@pytest.mark.timeout(300)
+def test_bench_gpus_2_without_a_launcher_starts_two_ranks():
+    """`python3 bench.py --gpus 2` as the driver types it -- no torch.distributed.run, no WORLD_SIZE: bench.py starts the
+    two ranks itself (self_launch) and relays rank 0's single JSON line."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    env["OMP_NUM_THREADS"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--stub-engine", "--steps", "3", "--warmup", "1",
+                        "--batch", "4", "--no-cpu-baseline"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=280)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 8 and d["config"]["parallelism"] == "dp2"
+    assert d["steps"] == 3 and d["warmup"] == 1 and d["value"] > 0
+    assert "all-gather" in d["config"]["workload"]
+
+
+@pytest.mark.timeout(120)
+def test_self_launch_reports_a_failing_rank():
+    """A rank that dies takes the job down with its exit code instead of leaving the others in a collective."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--stub-engine", "--steps", "1", "--warmup", "0",
+                        "--batch", "0", "--no-cpu-baseline"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=100)
+    assert r.returncode != 0
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+
+
+@pytest.mark.timeout(120)
+def test_group_bench_dry_run_prints_the_plan():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "group_bench.py"), "--gpus", "8", "--dry-run"], cwd=ROOT,
+                       capture_output=True, text=True, timeout=100)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert d["n_gpus"] == 8 and d["dry_run"] is True and d["config"]["global_batch"] == 8 * 256
+    assert d["shards"] == [[g * 256, (g + 1) * 256] for g in range(8)]
+
+
 def test_bench_single_rank_stub_engine():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--batch", "3",
                         "--stub-engine", "--no-cpu-baseline"], cwd=ROOT, capture_output=True, text=True, timeout=280)

@@ -219,26 +219,33 @@ def test_results_do_not_depend_on_the_batch_geometry(weights, parity_images, nb)
 @pytest.mark.parametrize("dtype", ["bf16", "f16"])
 def test_one_launch_back_end_is_bit_identical_to_the_stage_launches(weights, parity_images, dtype):
     """Stage 6 -> 7 -> 8 -> 9 -> head as one launch per image (default handle, 160 images) against one launch per stage
-    (RN_FLAG_STAGE_LAUNCHES): same arithmetic, operand values and summation order -- every tensor behind it and the results agree
-    bit for bit; and against the oracle-pinned small-batch results."""
+    (RN_FLAG_STAGE_LAUNCHES): agreement up to the fp32 summation order of the fused pair in front of it; and bit for bit, every
+    tensor behind the back end (s8.bn, s9.bn2, the logits) and the results, against the default handle at a small batch, whose back
+    end is the three launches (40 images < half a chip of images) and whose results the oracle tests pin."""
     nb = 160
     pick = (np.arange(nb) * 3) % len(parity_images)
     ims = parity_images[pick]
     fused = _capi.Engine(build_graph(6, 224), weights, device=0, dtype=dtype, max_batch=nb)
     plain = _capi.Engine(build_graph(6, 224), weights, device=0, dtype=dtype, max_batch=nb, stage_launches=True)
-    small = _capi.Engine(build_graph(6, 224), weights, device=0, dtype=dtype, max_batch=8)
+    small = _capi.Engine(build_graph(6, 224), weights, device=0, dtype=dtype, max_batch=len(parity_images))
     try:
         ids_f, probs_f = fused.forward_u8(ims)
         ids_p, probs_p = plain.forward_u8(ims)
-        assert fused.launch_groups()[-1] == [6, 7, 8, 9]
-        for name in ("s8.bn", "s9.bn2", "d3.relu"):
-            a, b = fused.tap(name, nb), plain.tap(name, nb)
-            if name == "s8.bn":                  # (the pair's fp32 summation order: see _same_up_to_sum_order)
-                _same_up_to_sum_order(a, b, dtype, name, frac=2e-3, n_ulp=4)
+        assert fused.launch_groups()[-1] == [6, 7, 8, 9] and len(parity_images) < 128
+        taps_f = {name: fused.tap(name, nb) for name in ("s8.bn", "s9.bn2", "d3.relu")}
+        # against one launch per stage: the fused PAIR (stages 2+3) in front of both back ends sums its pooling windows in
+        # another fp32 order than the per-stage launches (see _same_up_to_sum_order), so from s3.bn2 on the two handles agree up
+        # to that -- 16-bit tensors within a few ulp on a few elements, the fp32 logits within the bound the probabilities get
+        for name in ("s8.bn", "s9.bn2"):
+            _same_up_to_sum_order(taps_f[name], plain.tap(name, nb), dtype, name, frac=2e-3, n_ulp=4)
+        np.testing.assert_allclose(taps_f["d3.relu"], plain.tap("d3.relu", nb), rtol=0, atol=1e-2)
         np.testing.assert_allclose(probs_f, probs_p, rtol=0, atol=2e-3)
         np.testing.assert_array_equal(ids_f, ids_p)
+        # against the default handle at a small batch (same fused pair, back end as three launches): bit for bit, every tensor
         ids8, probs8 = small.forward_u8(parity_images)
-        np.testing.assert_array_equal(probs_f, probs8[pick])         # default handle, small batch: three launches -- same bits
+        for name in ("s8.bn", "s9.bn2", "d3.relu"):
+            np.testing.assert_array_equal(taps_f[name], small.tap(name, len(parity_images))[pick], err_msg=name)
+        np.testing.assert_array_equal(probs_f, probs8[pick])
         np.testing.assert_array_equal(ids_f, ids8[pick])
     finally:
         fused.close()

@@ -1,7 +1,8 @@
 """The committed evidence under profiles/ is self-consistent (CPU test: reads files only).
 
  * the newest bench line carries the contract keys plus the `roofline` and `cpu_baseline` objects;
- * its roofline arithmetic adds up (achieved = algorithmic bytes / kernel time, frac = achieved / peak);
+ * its roofline arithmetic adds up (frac = the whole path against 8 TB/s; per launch: credited = algorithmic bytes / launch
+   time, physical = PMC bytes / launch time);
  * the HBM-traffic summary is what tools/hbm_traffic.py derives from the two committed PMC passes, and the
    bench line's `roofline.traffic` is that file's figure for the dominant stage;
  * the rocprofv3 kernel-trace summary of the same command agrees with the live HIP-event time of that kernel."""
@@ -35,7 +36,25 @@ def test_bench_line_contract_and_roofline_arithmetic():
     r = b["roofline"]
     assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s")
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
-    assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["kernel_ms"] * 1e-3) / 1e9) < 1e-3 * r["achieved"]
+    if "launches" in r:
+        # round 5 on: `frac` is the whole path against the roof the target is stated in; the per-launch
+        # figures live in launches[] and a fused launch's credited figure is not the headline any more
+        assert r["bound"] == "hbm" and r["peak"] == 8000.0
+        assert abs(r["achieved"] * 1e9 - b["value"] * b["path"]["algorithmic_bytes_per_image"] / b["n_gpus"]) < 1e-6 * r["achieved"] * 1e9
+        assert abs(r["frac"] - b["path"]["hbm_frac"]) < 1e-9 and r["frac"] < 1.0
+        ls = r["launches"]
+        assert [l["stages"] for l in ls] == b["path"]["launch_groups"]
+        assert r["dominant"] == max(range(len(ls)), key=lambda j: ls[j]["ms"])
+        for l in ls:
+            assert abs(l["credited_frac"] - l["algorithmic_bytes"] / (l["ms"] * 1e-3) / 8e12) < 1e-6
+            if l["traffic"] is not None:
+                assert abs(l["physical_frac"] - l["traffic"] / (l["ms"] * 1e-3) / 8e12) < 1e-6 and l["physical_frac"] < 1.0
+            assert 0 < l["mfma_frac"] < 1.0
+        if r["traffic"] is not None:
+            assert r["traffic"] == sum(l["traffic"] for l in ls)
+        assert sum(l["algorithmic_bytes"] for l in ls) <= r["algorithmic_bytes_per_step"]     # + the head's 64 -> 6 elements
+    else:
+        assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["kernel_ms"] * 1e-3) / 1e9) < 1e-3 * r["achieved"]
     assert abs(b["value"] - b["config"]["global_batch"] / (b["ms_per_step"] * 1e-3)) < 1e-6 * b["value"]
     c = b["cpu_baseline"]
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
@@ -67,8 +86,14 @@ def test_hbm_traffic_summary_is_reproducible_from_the_pmc_passes():
             # round-2 stage 4 re-read 4 halo columns per 30: up to 1.12
             assert 0.50 <= s["traffic_over_algorithmic"] <= (1.12 if s["stage"] in (4, 7) else 1.05), s
     b = json.load(open(os.path.join(PROF, tag + "_bench.json")))
-    dom = [s for s in t["stages"] if s["algorithmic_bytes"] == b["roofline"]["algorithmic_bytes_per_launch"]]
-    assert dom and abs(dom[0]["traffic_bytes"] - b["roofline"]["traffic"]) <= 1e-3 * dom[0]["traffic_bytes"]
+    r = b["roofline"]
+    if "launches" in r:
+        for l in r["launches"]:
+            m = [s for s in t["stages"] if s.get("stages", [s["stage"]]) == l["stages"]]
+            assert m and l["traffic"] == m[0]["traffic_bytes"], l
+    else:
+        dom = [s for s in t["stages"] if s["algorithmic_bytes"] == r["algorithmic_bytes_per_launch"]]
+        assert dom and abs(dom[0]["traffic_bytes"] - r["traffic"]) <= 1e-3 * dom[0]["traffic_bytes"]
 
 
 def test_kernel_trace_agrees_with_live_event_timing():
@@ -78,4 +103,6 @@ def test_kernel_trace_agrees_with_live_event_timing():
     rows = list(csv.DictReader(open(ks)))
     top = max((r for r in rows if "stage" in r["Name"]), key=lambda r: float(r["AverageNs"]))
     # the profiler's own overhead and box-to-box spread stay within 12 %
-    assert abs(float(top["AverageNs"]) * 1e-6 - b["roofline"]["kernel_ms"]) <= 0.12 * b["roofline"]["kernel_ms"]
+    r = b["roofline"]
+    live_ms = r["launches"][r["dominant"]]["ms"] if "launches" in r else r["kernel_ms"]
+    assert abs(float(top["AverageNs"]) * 1e-6 - live_ms) <= 0.12 * live_ms

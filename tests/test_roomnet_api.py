@@ -67,6 +67,55 @@ def test_training_mode_infer_returns_ids_only(weights, parity_images):
     net.sess.close()
 
 
+def test_save_then_load_none_round_trip_runs_the_same_bits(nn, weights, parity_images, tmp_path, monkeypatch, capsys):
+    """SURVEY 8 f3 on the GPU: `save()` (network.py:93-103) -> a fresh model's `load(None)` (network.py:108-121: newest step in
+    all_trained_models/trained_models) -> the engine built from the restored variables returns the bits of the original handle.
+    Also the optimized-mode `save()` -> ./roomnet (network.py:94-97: how final_model/ was made) -> `load('roomnet')`."""
+    from roomnet_amd.network import RoomNet
+    monkeypatch.chdir(tmp_path)
+    ims = parity_images[[1, 9, 14, 22, 30, 38]]
+    ids0, probs0 = nn.infer(ims)
+    s5_0 = nn._engine().tap("s5.bn2", len(ims))
+    # a training-mode model holding the trained values (its restorer skips the dense blocks: network.py:242, so they are assigned)
+    tr = RoomNet(num_classes=6, im_side=224, compute_bn_mean_var=False, max_batch=8)
+    tr.load(MODEL_PREFIX)
+    tr.set_variables({k: v for k, v in weights.items() if any(k.startswith(p) for p in tr._restore_excluded)})
+    for step in (300, 4242, 77):              # load(None) must take the HIGHEST step, not the newest file
+        tr.step = step
+        if step == 4242:
+            tr.save(suffix="0.88")
+        else:
+            w_other = {k: (v * 0.5).astype(np.float32) for k, v in weights.items()}
+            from roomnet_amd import tf_bundle
+            tf_bundle.write_bundle("all_trained_models/trained_models/roomnet--%d" % step, w_other)
+    assert os.path.isfile("all_trained_models/trained_models/roomnet--0.88--4242.index")
+    assert "Model saved at all_trained_models/trained_models/roomnet--0.88--4242" in capsys.readouterr().out
+    np.testing.assert_array_equal(tr.infer(ims), ids0)
+    tr.sess.close()
+    fresh = RoomNet(num_classes=6, im_side=224, compute_bn_mean_var=False, optimized_inference=True, max_batch=8)
+    fresh.load()                               # model_path None
+    assert fresh.step == 4242 and fresh.start_step == 4242
+    assert "Model restored from all_trained_models/trained_models/roomnet--0.88--4242" in capsys.readouterr().out
+    ids1, probs1 = fresh.infer(ims)
+    np.testing.assert_array_equal(probs1, probs0)
+    np.testing.assert_array_equal(ids1, ids0)
+    np.testing.assert_array_equal(fresh._engine().tap("s5.bn2", len(ims)), s5_0)
+    # optimized-mode save(): ./roomnet.{index,data-00000-of-00001}, byte-identical data file, same bits through the engine
+    fresh.save()
+    assert "Model Saved in optimized inference mode" in capsys.readouterr().out
+    assert open("roomnet.data-00000-of-00001", "rb").read() == open(MODEL_PREFIX + ".data-00000-of-00001", "rb").read()
+    fresh.sess.close()
+    again = RoomNet(num_classes=6, im_side=224, compute_bn_mean_var=False, optimized_inference=True, max_batch=8, dtype="bf16")
+    again.load("roomnet")
+    ref16 = RoomNet(num_classes=6, im_side=224, compute_bn_mean_var=False, optimized_inference=True, max_batch=8, dtype="bf16")
+    ref16.load(MODEL_PREFIX)
+    a, b = again.infer(ims), ref16.infer(ims)
+    np.testing.assert_array_equal(a[1], b[1])
+    np.testing.assert_array_equal(a[0], b[0])
+    again.sess.close()
+    ref16.sess.close()
+
+
 def test_classify_im_dir_end_to_end(nn, weights, parity_images, tmp_path, capsys):
     from roomnet_amd.infer import CLASS_LABELS, classify_im_dir
     d = tmp_path / "images"

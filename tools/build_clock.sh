@@ -1,5 +1,5 @@
 #!/bin/bash
-# Diagnostic build with in-kernel clock stamps (never shipped): roomnet_amd/lib/libroomnet_hip_clock.so
+# Diagnostic build with in-kernel clock stamps (never shipped): tools/ab/libroomnet_hip_clock.so
 # Every stage-kernel workgroup stamps s_memtime / s_memrealtime at entry and exit; rn_forward prints the median clock per launch.
 # Run AFTER >= 2 s of back-to-back launches (tools/gpu_clock.sh does that).  (run csrc/build.sh first: other objects are reused)
 set -euo pipefail

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Diagnostic build with in-kernel s_memtime stamps (never shipped): roomnet_amd/lib/libroomnet_hip_stamps[_chain].so
+# Diagnostic build with in-kernel s_memtime stamps (never shipped): tools/ab/libroomnet_hip_stamps[_chain].so
 # usage: tools/build_stamps.sh [chain]     then run with ROOMNET_HIP_LIB=<that .so> python bench.py --steps 1 --warmup 1 --no-cpu-baseline
 set -euo pipefail
 ROOT="$(cd "$(dirname "${BASH_SOURCE[0]}")/.." && pwd)"
@@ -18,5 +18,5 @@ for f in rn_api rn_kernels_f32 rn_fused rn_imageops rn_group rn_tail rn_conv16 r
 /opt/rocm/bin/hipcc "${FLAGS[@]}" -mllvm -amdgpu-mfma-vgpr-form -c "$SRC/rn_stage4x.hip" -o "$OBJ/rn_stage4x.o" &
 /opt/rocm/bin/hipcc "${FLAGS[@]}" -mllvm -amdgpu-mfma-vgpr-form -c "$SRC/rn_stage6x.hip" -o "$OBJ/rn_stage6x.o" &
 wait
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC "$OBJ"/*.o -ldl -lpthread -o "$ROOT/roomnet_amd/lib/libroomnet_hip_stamps$SUF.so"
-echo "built $ROOT/roomnet_amd/lib/libroomnet_hip_stamps$SUF.so"
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC "$OBJ"/*.o -ldl -lpthread -o "$ROOT/tools/ab/libroomnet_hip_stamps$SUF.so"
+echo "built $ROOT/tools/ab/libroomnet_hip_stamps$SUF.so"

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Stamp build (tools/build_stamps.sh must have run) with ONE file rebuilt with extra flags:
-#   tools/build_stamps_variant.sh NAME FILE [-D...]  ->  roomnet_amd/lib/libroomnet_hip_stamps_NAME.so   (diagnostic only)
+#   tools/build_stamps_variant.sh NAME FILE [-D...]  ->  tools/ab/libroomnet_hip_stamps_NAME.so   (diagnostic only)
 set -euo pipefail
 ROOT="$(cd "$(dirname "${BASH_SOURCE[0]}")/.." && pwd)"
 SRC="$ROOT/roomnet_amd/csrc"
@@ -13,5 +13,5 @@ OBJS=()
 for f in rn_api rn_kernels_f32 rn_fused rn_imageops rn_group rn_tail rn_conv16 rn_stage_rw rn_stage23 rn_stage23x rn_stage5x rn_stage4x rn_stage6x rn_stage_f32m rn_backend; do
   if [ "$f" = "$FILE" ]; then OBJS+=("$OBJ/$f.o"); else OBJS+=("$ROOT/build/stamps/$f.o"); fi
 done
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC "${OBJS[@]}" -ldl -lpthread -o "$ROOT/roomnet_amd/lib/libroomnet_hip_stamps_$NAME.so"
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC "${OBJS[@]}" -ldl -lpthread -o "$ROOT/tools/ab/libroomnet_hip_stamps_$NAME.so"
 echo "built libroomnet_hip_stamps_$NAME.so"

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Experimental build of ONE kernel file: tools/build_variant.sh NAME FILE [extra hipcc flags]   (FILE = rn_stage_rw | rn_stage23)
-# -> roomnet_amd/lib/libroomnet_hip_NAME.so (other objects are taken from build/obj: run csrc/build.sh first).
+# -> tools/ab/libroomnet_hip_NAME.so (other objects are taken from build/obj: run csrc/build.sh first).
 # Select at run time with ROOMNET_HIP_LIB=<path>.  Diagnostic only; never shipped.
 set -euo pipefail
 ROOT="$(cd "$(dirname "${BASH_SOURCE[0]}")/.." && pwd)"
@@ -14,6 +14,6 @@ OBJS=()
 for f in rn_api rn_kernels_f32 rn_fused rn_imageops rn_group rn_tail rn_conv16 rn_stage_rw rn_stage23 rn_stage23x rn_stage5x rn_stage4x rn_stage6x rn_stage_f32m rn_backend; do
   if [ "$f" = "$FILE" ]; then OBJS+=("$OBJ/$f.o"); else OBJS+=("$ROOT/build/obj/$f.o"); fi
 done
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC "${OBJS[@]}" -ldl -lpthread -o "$ROOT/roomnet_amd/lib/libroomnet_hip_$NAME.so"
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC "${OBJS[@]}" -ldl -lpthread -o "$ROOT/tools/ab/libroomnet_hip_$NAME.so"
 echo "built libroomnet_hip_$NAME.so"
 "$ROOT/tools/spills.sh" "$OBJ/$FILE.o" | awk '$0 ~ /spills +[1-9]/ {print "  spills: " $0}' | cut -c1-70,95-200 || true

@@ -6,6 +6,6 @@ for arm in "" "--stage-launches"; do python bench.py --steps 50 --warmup 10 --no
 import sys,json
 d=json.loads(sys.stdin.readline())
 print('%-16s %.0f img/s  ' % ('$arm', d['value']) + ' '.join('%.3f'%x for x in d['path']['stage_ms']))"; done
-if [ -f roomnet_amd/lib/libroomnet_hip_stamps.so ]; then
-ROOMNET_HIP_LIB=roomnet_amd/lib/libroomnet_hip_stamps.so python bench.py --steps 2 --warmup 1 --no-cpu-baseline --profile-steps 1 2>&1 | grep -E "stamps. (fused|  wave 0)" | tail -2
+if [ -f tools/ab/libroomnet_hip_stamps.so ]; then
+ROOMNET_HIP_LIB=tools/ab/libroomnet_hip_stamps.so python bench.py --steps 2 --warmup 1 --no-cpu-baseline --profile-steps 1 2>&1 | grep -E "stamps. (fused|  wave 0)" | tail -2
 fi

@@ -3,7 +3,7 @@
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
 for v in "$@"; do
-  if [ "$v" = base ]; then unset ROOMNET_HIP_LIB; else export ROOMNET_HIP_LIB=$R/roomnet_amd/lib/libroomnet_hip_$v.so; fi
+  if [ "$v" = base ]; then unset ROOMNET_HIP_LIB; else export ROOMNET_HIP_LIB=$R/tools/ab/libroomnet_hip_$v.so; fi
   for c in FETCH_SIZE WRITE_SIZE; do
     rm -rf /tmp/pf_$c && rocprofv3 --pmc $c -d /tmp/pf_$c -o p --output-format csv -- python3 $R/bench.py --steps 3 --warmup 1 --spinup-steps 0 --no-cpu-baseline --no-parity-check --profile-steps 1 > /tmp/pf.log 2>&1
     f=$(find /tmp/pf_$c -name "*counter_collection.csv" | head -1)

@@ -3,7 +3,7 @@
 cd $GRAFT_REPO_ROOT
 for rep in 1 2; do
 for v in "$@"; do
-  if [ "$v" = base ]; then unset ROOMNET_HIP_LIB; else export ROOMNET_HIP_LIB=roomnet_amd/lib/libroomnet_hip_$v.so; fi
+  if [ "$v" = base ]; then unset ROOMNET_HIP_LIB; else export ROOMNET_HIP_LIB=tools/ab/libroomnet_hip_$v.so; fi
   python bench.py --steps 30 --warmup 5 --no-cpu-baseline 2>&1 | tail -1 | python -c "
 import sys,json
 l=sys.stdin.readline()

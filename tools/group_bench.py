@@ -40,10 +40,21 @@ def main():
     ap.add_argument("--batch", type=int, default=None, help="images per GPU (default 256 at 224, 64 at 600)")
     ap.add_argument("--side", type=int, default=224)
     ap.add_argument("--dtype", default=None, choices=["bf16", "f16"])
+    ap.add_argument("--dry-run", action="store_true",
+                    help="no library, no GPU: print the plan of the run (devices, contiguous shards of the global batch, bytes of the "
+                         "all-gather) as one JSON line and exit -- what a box without N GPUs can check of this tool")
     args = ap.parse_args()
     B = args.batch or (256 if args.side == 224 else 64)
     dtype = args.dtype or ("bf16" if args.side == 224 else "f16")
     N = args.gpus
+    if args.dry_run:
+        g = build_graph(6, args.side)
+        print(json.dumps({"dry_run": True, "n_gpus": N, "devices": list(range(N)), "steps": args.steps, "warmup": args.warmup,
+                          "dtype": dtype, "shards": [[d * B, (d + 1) * B] for d in range(N)],
+                          "all_gather_bytes_per_device": B * (g.num_classes * 4 + 8), "gathered_bytes": N * B * (g.num_classes * 4 + 8),
+                          "config": {"images_per_gpu": B, "global_batch": N * B, "im_side": args.side, "parallelism": "dp%d" % N,
+                                     "host": "single process, C ABI rn_group_*, ctypes"}}))
+        return
     weights = BundleReader(os.path.join(ROOT, "roomnet_amd", "final_model", "roomnet")).load_all()
     if args.side != 224:
         rng = np.random.default_rng(600)      # the checkpoint's dense/kernel only fits 224: seeded synthetic one
