@@ -12,7 +12,7 @@ uint8 BGR [B,224,224,3] -> stage kernels -> head -> probs [B,6] + ids [B] in HBM
 scaling (each rank owns its own batch of B images: BASELINE config 4 is 8 x 256).  The library and the
 collective run on ONE explicit (non-default) stream, so the all-gather is stream-ordered behind the head kernel.
 
-Before anything is timed the SAME handle classifies the 40 parity images (roomnet_amd/synth.parity_batch) and the
+Before anything is timed the SAME handle classifies the 64 parity images (roomnet_amd/synth.parity_set: all six classes) and the
 result is checked against tests/golden/parity_224.npz at the SURVEY 8c tolerance: the timed kernels are the tested ones.
 
 Two measurements per run, both complete passes, both reported.  (1) the COLD / contract pass: W warm-up steps and K timed
@@ -97,13 +97,14 @@ def measured_traffic(stages, batch, side, dtype):
 def check_parity(forward, side, dtype, max_batch):
     """Classify the parity images with `forward(uint8 batch) -> (ids, probs)` and compare with the committed golden
     results (fp64 restatement, tests/golden/).  Raises AssertionError when the handle does not reproduce them."""
-    from roomnet_amd.synth import parity_batch
+    from roomnet_amd.synth import parity_set
     name = "parity_%d.npz" % side
     path = os.path.join(ROOT, "tests", "golden", name)
     if not os.path.isfile(path):
         return {"checked": False, "reason": "no golden file for side %d" % side}
     g = np.load(path)
-    ims = parity_batch(side, seed=1)
+    # 40 seeded images + the 24 class-covering colour fields (all six classes of infer.py:22 are reached)
+    ims = parity_set(side, np.load(os.path.join(ROOT, "tests", "golden", "class_fields.npz"))["fields_u8"])
     if "image_indices" in g.files:
         ims = ims[g["image_indices"]]
     ids, probs = [], []
@@ -118,7 +119,8 @@ def check_parity(forward, side, dtype, max_batch):
     wrong = int((ids[safe] != g["ids"][safe]).sum())
     assert err <= tol_p, "parity: probabilities differ from the golden by %g (tolerance %g)" % (err, tol_p)
     assert wrong == 0, "parity: %d class ids differ from the golden where the top-2 margin exceeds %g" % (wrong, tol_m)
-    return {"checked": True, "golden": "tests/golden/" + name, "images": int(len(ims)), "max_abs_dprob": err, "tol_dprob": tol_p,
+    return {"checked": True, "golden": "tests/golden/" + name, "images": int(len(ims)), "classes_reached": sorted(set(int(i) for i in ids)),
+            "max_abs_dprob": err, "tol_dprob": tol_p,
             "ids_compared": int(safe.sum()), "ids_wrong": wrong, "ids_differ_all": int((ids != g["ids"]).sum())}
 
 

@@ -18,14 +18,12 @@ def _nm(base, i):
     return base if i == 0 else "%s_%d" % (base, i)
 
 
-def infer(weights, ims_u8, threads=None):
-    """uint8 BGR [n, S, S, 3] -> dict(logits, probs, ids) (float32 / int64 numpy arrays)."""
+def forward_tensor(w, x, raw_logits=False):
+    """The graph on a torch tensor: x float [n, 3, S, S] (RGB, already scaled to [-1, 1]) and w = {name: tensor} -> logits [n, 6]
+    (`raw_logits`: the last dense block's output BEFORE its ReLU6 -- what tools/make_golden.py's image search climbs, since the
+    clamp has no gradient where it is active).  Differentiable: autograd runs through it when x requires grad."""
     import torch
     import torch.nn.functional as F
-    if threads:
-        torch.set_num_threads(int(threads))
-    x = torch.from_numpy(R.preprocess_batch(np.asarray(ims_u8))).permute(0, 3, 1, 2).contiguous()
-    w = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in weights.items()}
     state = {"conv": 0, "bn": 0}
 
     def bn(t):
@@ -41,8 +39,8 @@ def infer(weights, ims_u8, threads=None):
         _, _, h, wd = t.shape
         ylo, yhi, yl = R.resize_tables(h, out)
         xlo, xhi, xl = R.resize_tables(wd, out)
-        yl = torch.from_numpy(yl).view(1, 1, -1, 1)
-        xl = torch.from_numpy(xl).view(1, 1, 1, -1)
+        yl = torch.from_numpy(yl).to(t.dtype).view(1, 1, -1, 1)
+        xl = torch.from_numpy(xl).to(t.dtype).view(1, 1, 1, -1)
         rows0, rows1 = t[:, :, torch.from_numpy(ylo)], t[:, :, torch.from_numpy(yhi)]
         xlo_t, xhi_t = torch.from_numpy(xlo), torch.from_numpy(xhi)
         top = rows0[..., xlo_t] + (rows0[..., xhi_t] - rows0[..., xlo_t]) * xl
@@ -64,15 +62,26 @@ def infer(weights, ims_u8, threads=None):
             t = bn(t + legacy_resize(first, t.shape[2]))
         return t
 
+    t = block(x)                                  # network.py:226
+    t = block(t, k=4, s=1, depth=3)               # :227
+    t = block(t, k=4, s=2, depth=2)               # :228
+    t = block(t, pooling=False)                   # :229
+    t = block(t, k=4, s=2, depth=3)               # :230
+    t = t.permute(0, 2, 3, 1).reshape(t.shape[0], -1)     # NHWC flatten, :231-233
+    for i in range(3):
+        t = bn(torch.clamp(t @ w[_nm("dense", i) + "/kernel"], 0.0, 6.0))
+    raw = t @ w["dense_3/kernel"] + w["dense_3/bias"]
+    return raw if raw_logits else torch.clamp(raw, 0.0, 6.0)
+
+
+def infer(weights, ims_u8, threads=None):
+    """uint8 BGR [n, S, S, 3] -> dict(logits, probs, ids) (float32 / int64 numpy arrays)."""
+    import torch
+    if threads:
+        torch.set_num_threads(int(threads))
+    x = torch.from_numpy(R.preprocess_batch(np.asarray(ims_u8))).permute(0, 3, 1, 2).contiguous()
+    w = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in weights.items()}
     with torch.no_grad():
-        t = block(x)                                  # network.py:226
-        t = block(t, k=4, s=1, depth=3)               # :227
-        t = block(t, k=4, s=2, depth=2)               # :228
-        t = block(t, pooling=False)                   # :229
-        t = block(t, k=4, s=2, depth=3)               # :230
-        t = t.permute(0, 2, 3, 1).reshape(t.shape[0], -1)     # NHWC flatten, :231-233
-        for i in range(3):
-            t = bn(torch.clamp(t @ w[_nm("dense", i) + "/kernel"], 0.0, 6.0))
-        logits = torch.clamp(t @ w["dense_3/kernel"] + w["dense_3/bias"], 0.0, 6.0)
+        logits = forward_tensor(w, x)
         probs = torch.softmax(logits, dim=-1)
     return {"logits": logits.numpy(), "probs": probs.numpy(), "ids": probs.argmax(-1).numpy().astype(np.int64)}

@@ -30,6 +30,22 @@ def _upsample_bilinear(coarse: np.ndarray, side: int) -> np.ndarray:
     return np.transpose(out, (1, 2, 0))
 
 
+def field_image(grid_u8: np.ndarray, side: int) -> np.ndarray:
+    """A low-frequency colour field: coarse uint8 grid [3 (B, G, R), g, g] -> [side, side, 3] uint8, the same separable
+    up-sampling as the seeded low-pass images below.  The class-covering parity images (tests/golden/class_fields.npz, found by
+    tools/search_class_images.py) are stored as such grids and regenerated at 224 and 600."""
+    field = _upsample_bilinear(np.asarray(grid_u8, np.float64), side)          # values in [0, 255]
+    return np.ascontiguousarray(np.clip(field, 0, 255).astype(np.uint8))
+
+
+def parity_set(side: int, fields_u8=None, seed: int = 1) -> np.ndarray:
+    """The parity images of a side: the seeded batch below followed by one image per class-covering grid."""
+    ims = parity_batch(side, seed)
+    if fields_u8 is None or len(fields_u8) == 0:
+        return ims
+    return np.ascontiguousarray(np.concatenate([ims, np.stack([field_image(f, side) for f in fields_u8])], 0))
+
+
 def parity_batch(side: int = 224, seed: int = 1) -> np.ndarray:
     rng = np.random.default_rng(seed)
     ims = []

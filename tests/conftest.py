@@ -22,10 +22,20 @@ def weights():
     return BundleReader(MODEL_PREFIX).load_all()
 
 
+def class_fields():
+    """The 24 coarse colour grids (4 per class of infer.py:22) found by tools/search_class_images.py."""
+    return np.load(os.path.join(GOLDEN, "class_fields.npz"))["fields_u8"]
+
+
+def parity_set_of(side):
+    """The parity images of a side: 40 seeded images + the 24 class-covering field images (rows of parity_<side>.npz refer to it)."""
+    from roomnet_amd.synth import parity_set
+    return parity_set(side, class_fields())
+
+
 @pytest.fixture(scope="session")
 def parity_images():
-    from roomnet_amd.synth import parity_batch
-    return parity_batch(224, seed=1)
+    return parity_set_of(224)
 
 
 @pytest.fixture(scope="session")

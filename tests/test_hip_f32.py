@@ -29,7 +29,7 @@ def test_library_sees_a_gpu():
 
 def test_logits_probs_ids_vs_golden(engine, parity_images, golden_parity):
     ids, probs, logits = [], [], []
-    for i in range(0, len(parity_images), 8):               # 40 images = five chunks of max_batch; logits tapped after each
+    for i in range(0, len(parity_images), 8):               # 64 images = eight chunks of max_batch; logits tapped after each
         a, b = engine.forward_u8(parity_images[i:i + 8])
         ids.append(a)
         probs.append(b)

@@ -149,13 +149,19 @@ def test_cross_stage_fusion_is_bit_identical_to_stage_launches(weights, parity_i
 
 def test_logits_probs_ids_vs_golden(engine, parity_images, golden_parity, record):
     errs = []
-    for i in range(0, 40, 8):                  # logits of all 40 images, in chunks of the engine's capacity
+    for i in range(0, len(parity_images), 8):    # logits of all 64 images, in chunks of the engine's capacity
         engine.forward_u8(parity_images[i:i + 8])
         errs.append(np.abs(engine.tap("d3.relu", 8) - golden_parity["logits_f64"][i:i + 8]).max(1))
     errs = np.concatenate(errs)
     ids, probs = engine.forward_u8(parity_images)
     err = errs.max()
-    record("parity_set_40_images_224", engine.dtype_name, {
+    # every class of infer.py:22 is reached, on the GPU too, and the logit error is reported per class
+    assert set(ids.tolist()) == {0, 1, 2, 3, 4, 5}
+    gids = golden_parity["ids"]
+    record("parity_set_64_images_224", engine.dtype_name, {
+        "max_abs_dlogit_vs_fp64_by_fp64_class": {str(c): float(errs[gids == c].max()) for c in range(6)},
+        "images_by_fp64_class": {str(c): int((gids == c).sum()) for c in range(6)},
+        "ids_by_class_gpu": {str(c): int((ids == c).sum()) for c in range(6)},
         "max_abs_dlogit_vs_fp64": float(err), "mean_abs_dlogit_per_image_max": float(errs.mean()),
         "max_abs_dprob_vs_fp64": float(np.abs(probs - golden_parity["probs_f64"]).max()),
         "ids_differing_from_fp64": int((ids != golden_parity["ids"]).sum()),
@@ -164,7 +170,7 @@ def test_logits_probs_ids_vs_golden(engine, parity_images, golden_parity, record
     safe = golden_parity["top2_margin"] > MARGIN
     assert safe.sum() >= 25
     np.testing.assert_array_equal(ids[safe], golden_parity["ids"][safe])
-    # north_star: "argmax IDs bit-exact".  Over ALL 40 images: how many ids differ, and none of them may belong to an
+    # north_star: "argmax IDs bit-exact".  Over ALL 64 images: how many ids differ, and none of them may belong to an
     # image whose fp64 top-2 margin exceeds the tolerance (a flip below it is a tie broken by 16-bit rounding)
     differ = np.nonzero(ids != golden_parity["ids"])[0]
     print("%s: %d of %d class ids differ from the fp64 golden%s" % (
@@ -221,7 +227,7 @@ def test_one_launch_back_end_is_bit_identical_to_the_stage_launches(weights, par
     """Stage 6 -> 7 -> 8 -> 9 -> head as one launch per image (default handle, 160 images) against one launch per stage
     (RN_FLAG_STAGE_LAUNCHES): agreement up to the fp32 summation order of the fused pair in front of it; and bit for bit, every
     tensor behind the back end (s8.bn, s9.bn2, the logits) and the results, against the default handle at a small batch, whose back
-    end is the three launches (40 images < half a chip of images) and whose results the oracle tests pin."""
+    end is the three launches (64 images < half a chip of images) and whose results the oracle tests pin."""
     nb = 160
     pick = (np.arange(nb) * 3) % len(parity_images)
     ims = parity_images[pick]
@@ -299,7 +305,7 @@ def test_full_batch_256_properties(weights, parity_images, golden_parity, dtype)
     try:
         ids, probs = big.forward_u8(ims)
         s7 = big.tap("s8.bn", 256)              # (the first tensor behind the one-launch back end, rn_backend.hip)
-        ids8, probs8 = small.forward_u8(parity_images)          # 40 images in chunks of 8
+        ids8, probs8 = small.forward_u8(parity_images)          # 64 images in chunks of 8
         np.testing.assert_array_equal(probs, probs8[pick])
         np.testing.assert_array_equal(ids, ids8[pick])
         safe = golden_parity["top2_margin"][pick] > MARGIN
@@ -323,7 +329,7 @@ def test_full_batch_256_properties(weights, parity_images, golden_parity, dtype)
 def test_randomized_batch_256_against_the_f32_hip_path(weights, record):
     """256 random images (uniform noise, blurred noise, extremes) through the fused bf16 path at bench size vs the
     per-node float32 HIP path: every image's logits within the 16-bit tolerance and the late stage outputs finite and
-    close everywhere -- a localized corruption (one tile-row of one workgroup) cannot hide in a maximum over 40 images."""
+    close everywhere -- a localized corruption (one tile-row of one workgroup) cannot hide in a maximum over 64 images."""
     rng = np.random.default_rng(20261002)
     ims = rng.integers(0, 256, (256, 224, 224, 3), dtype=np.uint8)
     ims[0] = 0
@@ -421,15 +427,16 @@ def test_600_variant_vs_golden(weights, dtype, tol, record):
     import os
     from conftest import GOLDEN
     from oracle import roomnet_ref as R
-    from roomnet_amd.synth import parity_batch
+    from conftest import parity_set_of
     g = np.load(os.path.join(GOLDEN, "parity_600.npz"))
     w = dict(weights)
     w["dense/kernel"] = R.synth_dense_kernel_600()
-    ims = parity_batch(600, seed=1)[g["image_indices"]]
-    e = _capi.Engine(build_graph(6, 600), w, device=0, dtype=dtype, max_batch=4)
+    ims = parity_set_of(600)[g["image_indices"]]
+    assert len(ims) >= 16 and g["top2_margin"].min() > 0.25
+    e = _capi.Engine(build_graph(6, 600), w, device=0, dtype=dtype, max_batch=len(ims))
     try:
         ids, probs = e.forward_u8(ims)
-        logits = e.tap("d3.relu", 4)
+        logits = e.tap("d3.relu", len(ims))
         rec = {"max_abs_dlogit_vs_fp64": float(np.abs(logits - g["logits_f64"]).max()),
                "ids_differing_from_fp64": int((ids != g["ids"]).sum()), "images": int(len(ids))}
         assert np.abs(logits - g["logits_f64"]).max() <= tol
@@ -695,11 +702,11 @@ def test_600_variant_at_baseline_size_64_images(weights, dtype):
     import os
     from conftest import GOLDEN
     from oracle import roomnet_ref as R
-    from roomnet_amd.synth import parity_batch
-    g = np.load(os.path.join(GOLDEN, "parity_600.npz"))
+    from conftest import parity_set_of
+    g = {k: v[:4] for k, v in np.load(os.path.join(GOLDEN, "parity_600.npz")).items() if k != "note"}    # the first four of the set
     w = dict(weights)
     w["dense/kernel"] = R.synth_dense_kernel_600()
-    pool = parity_batch(600, seed=1)
+    pool = parity_set_of(600)
     gi = [int(i) for i in g["image_indices"]]
     rng = np.random.default_rng(64)
     pick = np.concatenate([gi, rng.integers(0, len(pool), 60)])

@@ -12,13 +12,19 @@ Fixtures
                          plus the TF version string -- the reference's own shape pin.
   bundle_index.json      name / shape / offset / size / masked CRC32C of the 79
                          tensors in final_model/roomnet.index.
+  class_fields.npz       (input of this script; written by tools/search_class_images.py)
+                         24 coarse colour grids, 4 per class of infer.py:22, whose
+                         up-sampled images the checkpoint classifies with fp64 top-2
+                         margins of 2.4-3.8.
   parity_224.npz         SELF-GENERATED (TF parity unpinned): for the 40 seeded
-                         images of roomnet_amd.synth.parity_batch(224, seed=1):
+                         images of roomnet_amd.synth.parity_batch(224, seed=1) followed
+                         by the 24 class-covering field images (synth.parity_set):
                          fp64-truth logits/probs/ids, fp32 logits, top-2 margins.
   taps_224.npz           SELF-GENERATED: for image 14 of that batch, per graph node:
                          mean, abs-max and 16 sampled elements (fp64 truth).
-  parity_600.npz         SELF-GENERATED: 4 images at 600x600 with the seeded
-                         synthetic dense/kernel.
+  parity_600.npz         SELF-GENERATED: 16 images of synth.parity_set(600) with the
+                         seeded synthetic dense/kernel, chosen by
+                         fp64 top-2 margin (none below 0.25: no ties).
 """
 from __future__ import annotations
 
@@ -32,7 +38,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 from roomnet_amd import tf_bundle  # noqa: E402
-from roomnet_amd.synth import parity_batch  # noqa: E402
+from roomnet_amd.synth import parity_set  # noqa: E402
 from oracle import roomnet_ref as R  # noqa: E402
 
 GOLD = os.path.join(ROOT, "tests", "golden")
@@ -178,7 +184,9 @@ def sample_positions(size, k=TAP_SAMPLES):
 
 def make_parity():
     w = tf_bundle.BundleReader(os.path.join(ROOT, "roomnet_amd", "final_model", "roomnet")).load_all()
-    ims = parity_batch(224, seed=1)
+    fields = np.load(os.path.join(GOLD, "class_fields.npz"))
+    ims = parity_set(224, fields["fields_u8"])
+    wanted = np.concatenate([np.full(len(ims) - len(fields["wanted_ids"]), -1, np.int64), fields["wanted_ids"]])
     logits64, probs64, ids64, logits32 = [], [], [], []
     taps = None
     for i in range(0, len(ims), 8):
@@ -199,7 +207,9 @@ def make_parity():
                         note=np.array("self-generated by oracle/roomnet_ref.py (fp64); TF parity unpinned"),
                         logits_f64=logits64, probs_f64=np.concatenate(probs64).astype(np.float64),
                         ids=np.concatenate(ids64), logits_f32=np.concatenate(logits32),
-                        top2_margin=srt[:, -1] - srt[:, -2])
+                        top2_margin=srt[:, -1] - srt[:, -2], wanted_ids=wanted)
+    got = np.concatenate(ids64)
+    assert (got[wanted >= 0] == wanted[wanted >= 0]).all(), "a class-covering image is not in its class any more"
     out = {"note": np.array("self-generated by oracle/roomnet_ref.py (fp64); TF parity unpinned"),
            "image_index": np.array(TAP_IMAGE)}
     for name in R.node_names():
@@ -212,20 +222,46 @@ def make_parity():
     print("classes reached:", sorted(set(np.concatenate(ids64).tolist())))
 
 
-def make_parity_600():
+def make_parity_600(n_keep=16, min_margin=0.25):
+    from oracle import c_oracle
     w = tf_bundle.BundleReader(os.path.join(ROOT, "roomnet_amd", "final_model", "roomnet")).load_all()
     w = dict(w)
     w["dense/kernel"] = R.synth_dense_kernel_600()
-    ims = parity_batch(600, seed=1)[[2, 14, 22, 30]]
-    r64 = R.infer(w, ims, np.float64)
-    r32 = R.infer(w, ims, np.float32)
+    fields = np.load(os.path.join(GOLD, "class_fields.npz"))["fields_u8"]
+    ims = parity_set(600, fields)
+    # pre-selection with the (fast) C restatement: per class the images with the largest fp32 margins, round-robin over the
+    # classes the synthetic head reaches, so that the 16 kept images spread over as many ids as it offers
+    pre = [c_oracle.infer(w, ims[i:i + 8]) for i in range(0, len(ims), 8)]
+    lg = np.concatenate([p["logits"] for p in pre])
+    ids = np.concatenate([p["ids"] for p in pre])
+    srt = np.sort(lg, axis=1)
+    m32 = srt[:, -1] - srt[:, -2]
+    by_class = {c: sorted(np.nonzero((ids == c) & (m32 > 2 * min_margin))[0].tolist(), key=lambda i: -m32[i]) for c in sorted(set(ids.tolist()))}
+    pick = []
+    while len(pick) < n_keep and any(by_class.values()):
+        for c in list(by_class):
+            if by_class[c] and len(pick) < n_keep:
+                pick.append(by_class[c].pop(0))
+    pick = np.array(sorted(pick))
+    r64 = {"logits": [], "probs": [], "ids": []}
+    r32 = []
+    for i in range(0, len(pick), 2):
+        a = R.infer(w, ims[pick[i:i + 2]], np.float64)
+        for k in r64:
+            r64[k].append(a[k])
+        r32.append(R.infer(w, ims[pick[i:i + 2]], np.float32)["logits"])
+        print("600 chunk", i, a["ids"], flush=True)
+    r64 = {k: np.concatenate(v) for k, v in r64.items()}
     srt = np.sort(r64["logits"], axis=1)
+    margin = srt[:, -1] - srt[:, -2]
+    assert margin.min() > min_margin, margin
     np.savez_compressed(os.path.join(GOLD, "parity_600.npz"),
-                        note=np.array("self-generated; synthetic dense/kernel (seed 600); TF parity unpinned"),
-                        image_indices=np.array([2, 14, 22, 30]),
+                        note=np.array("self-generated; synthetic dense/kernel (seed 600); images = synth.parity_set(600, "
+                                      "class_fields.npz fields)[image_indices]; TF parity unpinned"),
+                        image_indices=pick,
                         logits_f64=r64["logits"], probs_f64=r64["probs"].astype(np.float64), ids=r64["ids"],
-                        logits_f32=r32["logits"], top2_margin=srt[:, -1] - srt[:, -2])
-    print("600:", r64["ids"], r64["logits"])
+                        logits_f32=np.concatenate(r32), top2_margin=margin)
+    print("600:", pick.tolist(), r64["ids"].tolist(), np.round(margin, 3).tolist())
 
 
 if __name__ == "__main__":
