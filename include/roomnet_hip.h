@@ -181,7 +181,9 @@ RN_API int rn_forward_u8(rn_handle* h, const uint8_t* bgr_nhwc, int n, float* pr
  * copy stream and enqueues its forward pass + result download behind it; rn_collect waits for that slot and copies the
  * results out.  With  submit(0) submit(1) collect(0) submit(0) collect(1) ...  the upload of one batch overlaps the kernels
  * of the previous one (from pageable memory the upload call itself blocks the calling thread, the GPU does not idle;
- * from pinned memory it is asynchronous).  slot = 0 or 1; a slot must be collected before it is submitted again. */
+ * from pinned memory -- rn_host_alloc -- it is asynchronous: the caller then keeps the slot's source buffer unchanged
+ * until rn_collect(slot) has returned, i.e. one pinned buffer per slot).  slot = 0 or 1; a slot must be collected before
+ * it is submitted again. */
 RN_API int rn_submit_u8(rn_handle* h, const uint8_t* bgr_nhwc, int n, int slot);
 RN_API int rn_collect(rn_handle* h, int slot, float* probs, int64_t* ids);
 
@@ -256,10 +258,11 @@ RN_API int rn_stage_launch(const rn_handle* h, int stage);
  * every rn_group_* call leaves the caller's current HIP device as it found it.
  * SCALING: rn_group_forward_u8_device is the entry that scales -- the shards are already in
  * each device's HBM (as in BASELINE's measurement contract) and nothing but 32 B per image
- * crosses a link.  rn_group_forward_u8 takes one pageable host buffer: it uploads the
- * shards with one short-lived host thread per device (a pageable copy blocks its caller)
- * and is bound by the host's memory and PCIe bandwidth (38.5 MB per device and call at
- * 256 x 224 x 224), not by the GPUs.
+ * crosses a link.  rn_group_forward_u8 takes one host buffer: it uploads the shards through
+ * one persistent host thread per device (started by rn_group_create, parked between calls:
+ * a copy out of pageable memory blocks the thread that issues it; out of an rn_host_alloc
+ * buffer it does not) and is bound by the host's memory and PCIe bandwidth (38.5 MB per
+ * device and call at 256 x 224 x 224), not by the GPUs.
  * VALIDATION: groups of more than one device have not run on hardware yet (the
  * development pool has one MI355X per box); the one-device group is tested on the GPU. */
 typedef struct rn_group rn_group;
@@ -276,7 +279,10 @@ RN_API int rn_group_forward_u8(rn_group* g, const uint8_t* bgr_nhwc, int n, floa
 /* Device-resident form: d_shards[d] = device d's images already in its HBM, counts[d] of them.
  * Asynchronous: enqueues the forward passes and the all-gather on the devices' streams;
  * afterwards rn_group_result_buffer(g, d, ...) on ANY device holds all devices' packed results
- * ([ndev][slot_bytes], device d's slot at d * slot_bytes).  rn_group_sync waits for all of it. */
+ * ([ndev][slot_bytes], device d's slot at d * slot_bytes).  rn_group_sync waits for all of it.
+ * A device with counts[d] == 0 runs nothing but still takes part in the all-gather: its slot
+ * keeps what its last non-empty call left there (zeros before the first); only the first
+ * counts[d] entries of a slot belong to this call. */
 RN_API int rn_group_forward_u8_device(rn_group* g, const uint8_t* const* d_shards, const int* counts);
 RN_API int rn_group_result_buffer(rn_group* g, int index, void** d_gathered, size_t* slot_bytes);
 RN_API int rn_group_sync(rn_group* g);
@@ -287,6 +293,16 @@ RN_API int rn_device_malloc(rn_handle* h, size_t bytes, void** d_ptr);
 RN_API int rn_device_free(rn_handle* h, void* d_ptr);
 RN_API int rn_memcpy_h2d(rn_handle* h, void* d_dst, const void* src, size_t bytes);
 RN_API int rn_memcpy_d2h(rn_handle* h, void* dst, const void* d_src, size_t bytes);
+
+/* ---- pinned host memory ------------------------------------------------------------
+ * The reference hands TensorFlow pageable NumPy arrays (network.py:133); a copy out of pageable
+ * memory blocks the calling thread while the runtime stages it.  A batch buffer from
+ * rn_host_alloc (page-locked, usable with every device of the process) makes the upload of
+ * rn_submit_u8 / rn_forward_u8 / rn_group_forward_u8 a true asynchronous DMA: the two-slot
+ * pipeline then hides it completely behind the previous batch's kernels.  Free with
+ * rn_host_free (NULL is a no-op).  No handle is needed: call before or after rn_create. */
+RN_API int rn_host_alloc(size_t bytes, void** ptr);
+RN_API int rn_host_free(void* ptr);
 
 #ifdef __cplusplus
 }

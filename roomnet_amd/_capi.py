@@ -35,7 +35,7 @@ EXPORTED_SYMBOLS = (
     "rn_forward_u8", "rn_submit_u8", "rn_collect", "rn_forward_f32", "rn_forward_u8_device", "rn_forward_f32_device", "rn_sync",
     "rn_set_stream", "rn_set_stream_null", "rn_node_count", "rn_node_info_get", "rn_tap", "rn_set_profiling", "rn_timing",
     "rn_dominant_stage", "rn_stage_launch", "rn_device_malloc", "rn_device_free", "rn_memcpy_h2d", "rn_memcpy_d2h",
-    "rn_crop_resize_u8_device", "rn_classify_images_u8",
+    "rn_crop_resize_u8_device", "rn_classify_images_u8", "rn_host_alloc", "rn_host_free",
     "rn_group_create", "rn_group_destroy", "rn_group_size", "rn_group_handle", "rn_group_forward_u8",
     "rn_group_forward_u8_device", "rn_group_result_buffer", "rn_group_sync",
 )
@@ -137,6 +137,10 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.rn_device_free.restype = i32
     lib.rn_memcpy_h2d.argtypes = [vp, vp, vp, sz]
     lib.rn_memcpy_h2d.restype = i32
+    lib.rn_host_alloc.argtypes = [sz, C.POINTER(vp)]
+    lib.rn_host_alloc.restype = i32
+    lib.rn_host_free.argtypes = [vp]
+    lib.rn_host_free.restype = i32
     lib.rn_memcpy_d2h.argtypes = [vp, vp, vp, sz]
     lib.rn_memcpy_d2h.restype = i32
     lib.rn_crop_resize_u8_device.argtypes = [vp, vp, i32, i32, vp, i32]
@@ -438,6 +442,33 @@ class Engine:
                 raise RoomNetLibraryError(self.lib.rn_last_error().decode())
             groups.setdefault(rep, []).append(i)
         return [groups[k] for k in sorted(groups)]
+
+
+class PinnedArray:
+    """A NumPy array over page-locked host memory (``rn_host_alloc``): uploads out of it are asynchronous DMAs, so the
+    two-slot pipeline (``Engine.submit_u8`` / ``collect``) hides them behind the previous batch's kernels.  Fill
+    ``.array`` in place; ``close()`` (or garbage collection) frees the memory -- do not use ``.array`` afterwards."""
+
+    def __init__(self, shape, dtype=np.uint8, lib_path: Optional[str] = None):
+        self.lib = load_library(lib_path)
+        nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        p = C.c_void_p()
+        _check(self.lib, self.lib.rn_host_alloc(max(nbytes, 1), C.byref(p)), "rn_host_alloc")
+        self._p = p
+        buf = (C.c_uint8 * max(nbytes, 1)).from_address(p.value)
+        self.array = np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+
+    def close(self) -> None:
+        if self._p:
+            self.array = None
+            self.lib.rn_host_free(self._p)
+            self._p = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class Group:

@@ -574,6 +574,7 @@ extern "C" int rn_forward_f32_device(rn_handle* h, const float* d_rgb, int n, fl
     int rc = check_call(h, n, d_rgb, d_probs, d_ids);
     if (rc != RN_OK) return rc;
     DeviceGuard guard(h->device);
+    (void)hipGetLastError();      // a stale status of the CALLER's own runtime calls on this thread is not this pass's launch failure
     h->timing_valid = false;
     record(h, 0);
     record(h, 1);
@@ -597,6 +598,7 @@ extern "C" int rn_forward_u8_device(rn_handle* h, const uint8_t* d_bgr, int n, f
     int rc = check_call(h, n, d_bgr, d_probs, d_ids);
     if (rc != RN_OK) return rc;
     DeviceGuard guard(h->device);
+    (void)hipGetLastError();      // (see rn_forward_f32_device)
     h->timing_valid = false;
     record(h, 0);
     if (fused_mode(h)) {
@@ -983,5 +985,29 @@ extern "C" int rn_memcpy_d2h(rn_handle* h, void* dst, const void* d_src, size_t 
     DeviceGuard guard(h->device);
     RN_HIP(hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, h->stream));
     RN_HIP(hipStreamSynchronize(h->stream));
+    return RN_OK;
+}
+
+// ---- pinned host memory: what makes the host-buffer entries asynchronous (rn_submit_u8, rn_group_forward_u8)
+extern "C" int rn_host_alloc(size_t bytes, void** ptr) {
+    if (!ptr || bytes == 0) {
+        rn_set_error("rn_host_alloc: bad argument");
+        return RN_E_INVALID;
+    }
+    *ptr = nullptr;
+    // portable: usable as a copy source for every device of the process (a group's shards come out of one buffer)
+    hipError_t e = hipHostMalloc(ptr, bytes, hipHostMallocPortable);
+    if (e != hipSuccess) {
+        rn_set_error("rn_host_alloc: hipHostMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e));
+        (void)hipGetLastError();       // reported: it must not surface again as the next kernel's "launch failure"
+        *ptr = nullptr;
+        return RN_E_NOMEM;
+    }
+    return RN_OK;
+}
+
+extern "C" int rn_host_free(void* ptr) {
+    if (!ptr) return RN_OK;
+    RN_HIP(hipHostFree(ptr));
     return RN_OK;
 }

@@ -10,9 +10,11 @@
 // path).  One host thread drives all devices: per device one stream (the handle's own), the forward pass is
 // enqueued device by device, the all-gather is one ncclGroupStart/End bracket over all communicators, so the
 // collective is stream-ordered behind each device's head kernel without a host synchronisation in between.
-// The host-buffer entry rn_group_forward_u8 additionally starts one short-lived upload thread per device: a copy out
-// of pageable memory blocks the thread that issues it, and one thread issuing eight of them would run them one
-// after the other.  Every entry point leaves the caller's current HIP device as it found it.
+// The host-buffer entry rn_group_forward_u8 hands the shards to one PERSISTENT upload thread per device (started by
+// rn_group_create, parked on a condition variable between calls, joined by rn_group_destroy): a copy out of pageable
+// memory blocks the thread that issues it, and one thread issuing eight of them would run them one after the other.
+// From pinned memory (rn_host_alloc) hipMemcpyAsync returns at once; the workers then cost two wake-ups per call.
+// Every entry point leaves the caller's current HIP device as it found it.
 //
 // Groups of more than one device have NOT run on hardware yet (the development pool has one MI355X per box): the
 // one-device group is what tests/test_group.py validates.
@@ -21,11 +23,13 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
+#include <condition_variable>
 #include <cstdlib>
 #include <cstring>
+#include <exception>
+#include <memory>
 #include <mutex>
 #include <new>
-#include <exception>
 #include <thread>
 
 namespace {
@@ -97,6 +101,61 @@ struct CurrentDeviceRestore {
 
 }  // namespace
 
+// One upload worker per device: bound to its device once, then: wait for a job (source, bytes) -> hipMemcpyAsync on the
+// device's stream -> report.  post() / wait() are called by the thread that owns the group (calls on a group are serialised).
+struct UploadWorker {
+    std::thread th;
+    std::mutex mu;
+    std::condition_variable cv;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    void* dst = nullptr;
+    const void* src = nullptr;      // job: non-null while one is pending
+    size_t bytes = 0;
+    bool pending = false, done = false, quit = false;
+    hipError_t rc = hipSuccess;
+
+    void run() {
+        hipError_t bind = hipSetDevice(device);
+        std::unique_lock<std::mutex> lk(mu);
+        for (;;) {
+            cv.wait(lk, [&] { return pending || quit; });
+            if (quit) return;
+            const void* s = src;
+            const size_t b = bytes;
+            lk.unlock();
+            hipError_t e = bind != hipSuccess ? bind : hipMemcpyAsync(dst, s, b, hipMemcpyHostToDevice, stream);
+            lk.lock();
+            rc = e;
+            pending = false;
+            done = true;
+            cv.notify_all();
+        }
+    }
+    void post(const void* s, size_t b) {
+        std::lock_guard<std::mutex> lk(mu);
+        src = s;
+        bytes = b;
+        done = false;
+        pending = true;
+        cv.notify_all();
+    }
+    hipError_t wait() {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return done; });
+        done = false;
+        return rc;
+    }
+    void stop() {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            quit = true;
+            cv.notify_all();
+        }
+        if (th.joinable()) th.join();
+    }
+};
+
 struct rn_group {
     int ndev = 0;
     int cap = 0;                       // images per device and call (max_batch_per_device)
@@ -111,11 +170,14 @@ struct rn_group {
     std::vector<uint8_t*> d_recv;      // [ndev][slot_bytes]: every device's results, on every device
     std::vector<uint8_t> h_recv;       // host copy of device 0's gathered buffer
     std::vector<int> counts;           // images per device of the last call
+    std::vector<std::unique_ptr<UploadWorker>> workers;   // host-buffer entry: one persistent upload thread per device
 };
 
 extern "C" void rn_group_destroy(rn_group* g) {
     if (!g) return;
     CurrentDeviceRestore restore;
+    for (auto& w : g->workers)
+        if (w) w->stop();
     for (int d = 0; d < static_cast<int>(g->handles.size()); ++d) {
         if (hipSetDevice(g->devices[d]) != hipSuccess) continue;
         (void)hipDeviceSynchronize();
@@ -185,6 +247,11 @@ extern "C" int rn_group_create(const rn_weights* w, int ndev, const int* devices
             rn_set_error("rn_group_create: device %d: buffer allocation failed", g->devices[d]);
             return fail(RN_E_NOMEM);
         }
+        // (a device that never gets an image still sends its slot in every all-gather: zeros, not uninitialised memory)
+        if (hipMemset(g->d_send[d], 0, g->slot_bytes) != hipSuccess) {
+            rn_set_error("rn_group_create: device %d: hipMemset failed", g->devices[d]);
+            return fail(RN_E_HIP);
+        }
     }
     ncclResult_t r = g_rccl.CommInitAll(g->comms.data(), ndev, g->devices.data());
     if (r != ncclSuccess) {
@@ -192,6 +259,20 @@ extern "C" int rn_group_create(const rn_weights* w, int ndev, const int* devices
         return fail(RN_E_HIP);
     }
     g->h_recv.resize(g->slot_bytes * ndev);
+    // (no C++ exception may cross the C ABI: a thread that cannot be started fails the call with a status)
+    try {
+        for (int d = 0; d < ndev; ++d) {
+            g->workers.emplace_back(new UploadWorker());
+            UploadWorker& w = *g->workers.back();
+            w.device = g->devices[d];
+            w.stream = g->handles[d]->stream;
+            w.dst = g->d_in[d];
+            w.th = std::thread([&w] { w.run(); });
+        }
+    } catch (const std::exception& ex) {
+        rn_set_error("rn_group_create: cannot start the upload threads: %s", ex.what());
+        return fail(RN_E_STATE);
+    }
     *out = g;
     return RN_OK;
 }
@@ -214,7 +295,9 @@ static void shard(int n, int ndev, int d, int* lo, int* cnt) {
 }
 
 static int group_run(rn_group* g, const uint8_t* const* d_shards, const int* counts) {
-    // forward pass per device into its packed send buffer, then ONE all-gather bracket
+    // forward pass per device into its packed send buffer, then ONE all-gather bracket.  A device with counts[d] == 0 still
+    // takes part in the collective (every rank must): it contributes its slot as it stands -- the results of its last
+    // non-empty call, or zeros before the first -- and only the first counts[d] entries of a slot are results of THIS call.
     for (int d = 0; d < g->ndev; ++d) {
         g->counts[d] = counts[d];
         if (counts[d] == 0) continue;
@@ -292,39 +375,31 @@ extern "C" int rn_group_forward_u8(rn_group* g, const uint8_t* bgr_nhwc, int n, 
     const size_t img_bytes = static_cast<size_t>(g->im_side) * g->im_side * 3;
     std::vector<const uint8_t*> shards(g->ndev, nullptr);
     std::vector<int> counts(g->ndev, 0);
-    // one upload thread per device: hipMemcpyAsync out of pageable memory stages through the runtime's pinned buffers
-    // on the CALLING thread and returns when the source has been read -- issued from one thread the devices' uploads
+    // the devices' persistent upload threads: hipMemcpyAsync out of pageable memory stages through the runtime's pinned
+    // buffers on the CALLING thread and returns when the source has been read -- issued from one thread the devices' uploads
     // (38.5 MB each at 256 images of 224 x 224) would follow one another (~1.5 ms each) in front of 1.6 ms of compute
-    std::vector<std::thread> uploads;
-    std::vector<hipError_t> up_rc(g->ndev, hipSuccess);
     for (int d = 0; d < g->ndev; ++d) {
         int lo, cnt;
         shard(n, g->ndev, d, &lo, &cnt);
         counts[d] = cnt;
         shards[d] = g->d_in[d];
         if (cnt == 0) continue;
-        const uint8_t* src = bgr_nhwc + static_cast<size_t>(lo) * img_bytes;
-        const size_t bytes = static_cast<size_t>(cnt) * img_bytes;
-        // (no C++ exception may cross the C ABI, and a joinable std::thread must not be destroyed: if a thread cannot be
-        //  started, the ones that were are joined and the call fails with a status)
-        try {
-            uploads.emplace_back([g, d, src, bytes, &up_rc] {
-                hipError_t e = hipSetDevice(g->devices[d]);
-                if (e == hipSuccess) e = hipMemcpyAsync(g->d_in[d], src, bytes, hipMemcpyHostToDevice, g->handles[d]->stream);
-                up_rc[d] = e;
-            });
-        } catch (const std::exception& ex) {
-            for (auto& t : uploads) t.join();
-            rn_set_error("rn_group_forward_u8: cannot start the upload thread of device %d: %s", g->devices[d], ex.what());
-            return RN_E_STATE;
+        g->workers[d]->post(bgr_nhwc + static_cast<size_t>(lo) * img_bytes, static_cast<size_t>(cnt) * img_bytes);
+    }
+    hipError_t up_fail = hipSuccess;
+    int up_dev = -1;
+    for (int d = 0; d < g->ndev; ++d) {
+        if (counts[d] == 0) continue;
+        const hipError_t e = g->workers[d]->wait();           // (every posted job is waited for, also after a failure)
+        if (e != hipSuccess && up_fail == hipSuccess) {
+            up_fail = e;
+            up_dev = d;
         }
     }
-    for (auto& t : uploads) t.join();
-    for (int d = 0; d < g->ndev; ++d)
-        if (up_rc[d] != hipSuccess) {
-            rn_set_error("rn_group_forward_u8: upload to device %d failed: %s", g->devices[d], hipGetErrorString(up_rc[d]));
-            return RN_E_HIP;
-        }
+    if (up_fail != hipSuccess) {
+        rn_set_error("rn_group_forward_u8: upload to device %d failed: %s", g->devices[up_dev], hipGetErrorString(up_fail));
+        return RN_E_HIP;
+    }
     int rc = group_run(g, shards.data(), counts.data());
     if (rc != RN_OK) return rc;
     // every device holds every device's results; read them back from the first one

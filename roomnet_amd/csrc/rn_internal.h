@@ -13,12 +13,15 @@
 
 void rn_set_error(const char* fmt, ...);
 
+// (a failing runtime call also leaves its status in the thread's sticky "last error", which RN_CHECK_LAUNCH reads: a failure
+//  that was reported here must not come back as the "launch failure" of the next, innocent kernel -- consume it)
 #define RN_HIP(expr)                                                                          \
     do {                                                                                      \
         hipError_t _e = (expr);                                                               \
         if (_e != hipSuccess) {                                                               \
             rn_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__,     \
                          __LINE__);                                                           \
+            (void)hipGetLastError();                                                          \
             return RN_E_HIP;                                                                  \
         }                                                                                     \
     } while (0)

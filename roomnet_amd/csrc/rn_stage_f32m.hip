@@ -334,8 +334,163 @@ __global__ __launch_bounds__(512) void stage_f32m_kernel(const F32StageArgs a) {
     }
 }
 
+
+// ---- 16-cout stages (128 -> 16 and 16 -> 16, avg-pool 4/2, no residual) on v_mfma_f32_16x16x4_f32: a 32 x 32 x 2 tile would
+// idle half of its rows on 16 couts, and its weights (9 x 128 x 32 floats) would not fit the LDS next to the ring.  Same
+// structure as stage_f32m_kernel: wave = tile of 16 conv columns (7 pooled columns: stride 14), lane = (pixel, k group), one
+// ds_read_b128 of the ring is the B operand of four MFMAs (lane (pixel, k) reads channels 16 q + 4 k .. + 3 of a tap, MFMA i
+// contracts channels {16 q + 4 k + i, k = 0..3}), weights in LDS in fragment order; the accumulator holds 4 couts of the
+// lane's pixel: ReLU6, horizontal window by row-local DPP shifts, vertical window in a register ring, un-contracted BN, one
+// 16-byte store.  KS = 3: the K sum of the 128-channel stage is split by KERNEL ROW over three waves per tile (one image row of
+// the ring each), partial sums meet in LDS and are added in a fixed order by the first.
+__device__ __forceinline__ f32x4 mfma_f32_16(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+
+template <int CIN, int KS, int LPT>
+__global__ __launch_bounds__(576) void stage_f32m16_kernel(const F32StageArgs a) {
+    constexpr int COUT = 16, PK = 4, PS = 2, NSL = 3;
+    constexpr int CP = CIN / 4;                          // 16-byte chunks per pixel
+    constexpr int KG = CIN / 16;                         // 16-channel groups per tap = ds_read_b128 per tap and lane
+    constexpr int KC = 9 * KG;                           // weight fragments (1 KB each)
+    constexpr int TSTRIDE = 14, NOUT_T = 7;
+    constexpr int PIXB = CIN * 4;
+    static_assert(CIN % 16 == 0 && (KS == 1 || KS == 3), "channel groups of 16; K split = one kernel row per wave");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave = wave_all / KS, kh = wave_all % KS;
+    const int px = lane & 15, kq = lane >> 4;
+    const int nthreads = blockDim.x;
+    const int npt = a.npt;
+    const int cb = blockIdx.x % a.n_colblocks, band = blockIdx.x / a.n_colblocks, n = blockIdx.y;
+    const int ringcols = a.ringcols;
+    const int rowbytes = ringcols * PIXB;
+    char* const wl = smem;
+    float* const tabs = reinterpret_cast<float*>(smem + KC * 1024);          // [3][16]: mean, inv, beta
+    char* const ring = smem + KC * 1024 + 256;
+    [[maybe_unused]] char* const pbuf = ring + NSL * rowbytes;                 // KS == 3: [2][npt] partial tiles of 1 KB
+
+    const int yo0 = band * a.rows_per_band;
+    const int yo1 = min(a.Ho, yo0 + a.rows_per_band);
+    const int yc0 = yo0 * PS;
+    const int nconv = (yo1 - yo0 - 1) * PS + PK;
+    const int nin = nconv + 2;
+    const int x0c = cb * npt * TSTRIDE;
+    const int xo_blk0 = x0c / PS;
+
+    for (int i = tid; i < KC * 64; i += nthreads) reinterpret_cast<f32x4*>(wl)[i] = a.wfrag[i];
+    for (int i = tid; i < 48; i += nthreads) tabs[i] = (i < 16 ? a.bn_mean : i < 32 ? a.bn_inv : a.bn_beta)[i & 15];
+
+    const int nchunks = ringcols * CP;
+    const float* const in_img = a.in + static_cast<int64_t>(n) * a.H * a.W * CIN;
+    int ld_goff[LPT], ld_loff[LPT];
+#pragma unroll
+    for (int i = 0; i < LPT; ++i) {
+        const int q = tid + i * nthreads;
+        const int p = q / CP, c4 = q % CP;
+        ld_loff[i] = q < nchunks ? (p * CP + (c4 ^ chunk_swz<CP>(p))) * 16 : -1;
+        ld_goff[i] = (q < nchunks ? min(x0c + p, a.W - 1) : 0) * CIN + c4 * 4;
+    }
+    f32x4 pre[LPT];
+    auto fetch_row = [&](int j) {
+        const float* row = in_img + static_cast<int64_t>(yc0 + j) * a.W * CIN;
+#pragma unroll
+        for (int i = 0; i < LPT; ++i) pre[i] = *reinterpret_cast<const f32x4*>(row + ld_goff[i]);
+    };
+    auto store_row = [&](int j) {
+        char* dst = ring + (j % NSL) * rowbytes;
+#pragma unroll
+        for (int i = 0; i < LPT; ++i)
+            if (ld_loff[i] >= 0) *reinterpret_cast<f32x4*>(dst + ld_loff[i]) = pre[i];
+    };
+    for (int j = 0; j < 3; ++j) {
+        fetch_row(j);
+        store_row(j);
+    }
+    __syncthreads();
+
+    const int xrel0 = wave * TSTRIDE + px;
+    int boff[3], bswz[3];
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+        boff[kx] = (xrel0 + kx) * PIXB;
+        bswz[kx] = chunk_swz<CP>(xrel0 + kx);
+    }
+    const int xc = x0c + xrel0;
+    const int xo = xc / PS;
+    const bool lane_out = (px % PS == 0 && px <= 16 - PK) && xo < a.Wo && (xo - xo_blk0) < npt * NOUT_T;
+    float vring[3][4];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) vring[i][g] = 0.f;
+    const char* const wl_lane = wl + lane * 16;
+    const f32x4 t_mean = *reinterpret_cast<const f32x4*>(tabs + 4 * kq), t_inv = *reinterpret_cast<const f32x4*>(tabs + 16 + 4 * kq),
+                t_beta = *reinterpret_cast<const f32x4*>(tabs + 32 + 4 * kq);
+
+    for (int it = 0; it < nconv; ++it) {
+        const bool have_next = it + 3 < nin;
+        if (have_next) fetch_row(it + 3);
+        const bool emit = it >= PK - 1 && ((it - (PK - 1)) % PS) == 0;
+        const int yo = yo0 + (it - (PK - 1)) / PS;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t3 = 0; t3 < (KS == 3 ? 3 : 9); ++t3) {
+            const int ky = KS == 3 ? kh : t3 / 3, kx = t3 % 3;        // (KS == 3: ky is wave-uniform)
+            const char* rowp = ring + ((it + ky) % NSL) * rowbytes;
+            const char* wrow = wl_lane + (ky * 3 + kx) * KG * 1024;
+#pragma unroll
+            for (int q = 0; q < KG; ++q) {
+                const f32x4 b = *reinterpret_cast<const f32x4*>(rowp + boff[kx] + (((4 * q + kq) ^ bswz[kx]) << 4));
+                const f32x4 wv = *reinterpret_cast<const f32x4*>(wrow + q * 1024);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc = mfma_f32_16(wv[i], b[i], acc);
+            }
+        }
+        if constexpr (KS == 3) {
+            if (kh > 0) *reinterpret_cast<f32x4*>(pbuf + ((kh - 1) * npt + wave) * 1024 + lane * 16) = acc;
+            lds_barrier();
+            if (kh == 0) {
+                const f32x4 p1 = *reinterpret_cast<const f32x4*>(pbuf + wave * 1024 + lane * 16);
+                const f32x4 p2 = *reinterpret_cast<const f32x4*>(pbuf + (npt + wave) * 1024 + lane * 16);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[j] = (acc[j] + p1[j]) + p2[j];
+            }
+        }
+        if (kh == 0) {
+            float tot[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float v = relu6f(acc[g]);
+                const float t = v + row_next<1>(v);
+                const float hs = t + row_next<2>(t);
+                float s = vring[0][g];
+                s += vring[1][g];
+                s += vring[2][g];
+                tot[g] = s + hs;
+                vring[0][g] = vring[1][g];
+                vring[1][g] = vring[2][g];
+                vring[2][g] = hs;
+            }
+            if (emit && lane_out) {
+                f32x4 y;
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    y[j] = __fadd_rn(__fmul_rn(__fsub_rn(__fmul_rn(tot[j], 1.0f / 16.0f), t_mean[j]), t_inv[j]), t_beta[j]);
+                *reinterpret_cast<f32x4*>(a.out + ((static_cast<int64_t>(n) * a.Ho + yo) * a.Wo + xo) * COUT + 4 * kq) = y;
+            }
+        }
+        lds_barrier();            // everybody is past row `it` (and the partial tiles) before its slot is refilled
+        if (have_next) store_row(it + 3);
+        lds_barrier();
+    }
+}
+
 struct F32mStage {
     bool on = false;
+    bool m16 = false;             // stage_f32m16_kernel (16 couts): ks / lpt16 below
+    int ks16 = 1;
     f32x4* wfrag = nullptr;
     int variant = -1, npt = 1, n_colblocks = 1, n_ctg = 1, nsl = 4, ringcols = 34;
     size_t lds = 0;
@@ -373,6 +528,27 @@ const F32Variant kF32Variants[] = {
     {64, 128, 0, 1, 0, 3, 8, 2, launch_f32m<64, 128, 0, 1, false, 3, 8, 2>},    // stage 6
 };
 
+template <int CIN, int KS, int LPT>
+void launch_f32m16(const F32StageArgs& a, dim3 grid, dim3 block, size_t lds, hipStream_t s) {
+    auto kern = stage_f32m16_kernel<CIN, KS, LPT>;
+    static std::atomic<unsigned long long> attr_devices{0};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (!(attr_devices.load(std::memory_order_acquire) >> (dev & 63) & 1ull)) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_devices.fetch_or(1ull << (dev & 63), std::memory_order_release);
+    }
+    hipLaunchKernelGGL(kern, grid, block, lds, s, a);
+}
+struct F32Variant16 {
+    int cin, ks, lpt;
+    F32LaunchFn fn;
+};
+const F32Variant16 kF32Variants16[] = {
+    {128, 3, 4, launch_f32m16<128, 3, 4>},      // stage 7 (npt = 3: 576 threads, a 46-pixel ring row = 1 472 chunks)
+    {16, 1, 2, launch_f32m16<16, 1, 2>},        // stage 8
+};
+
 }  // namespace
 
 void rn_f32m_release(rn_handle* h) {
@@ -394,6 +570,50 @@ int rn_f32m_prepare(rn_handle* h, const rn_weights* w) {
             if (k.cin == s.cin && k.cout == s.cout && k.pk == s.pool_k && (s.pool_k == 0 || k.ps == s.pool_s) &&
                 k.res == (s.skip_stage >= 0 ? 1 : 0))
                 f.variant = static_cast<int>(v);
+        }
+        if (f.variant < 0 && s.cout == 16 && s.pool_k == 4 && s.pool_s == 2 && s.skip_stage < 0) {
+            // 16-cout stages: stage_f32m16_kernel; frag[tap * CIN / 16 + q][lane][i] = W[tap][channel 16 q + 4 (lane / 16) + i][cout lane % 16]
+            for (size_t v = 0; v < sizeof(kF32Variants16) / sizeof(kF32Variants16[0]); ++v) {
+                const F32Variant16& k = kF32Variants16[v];
+                if (k.cin != s.cin) continue;
+                const int kg = s.cin / 16, tiles = (s.out_side + 6) / 7;
+                int npt = std::min(tiles, 576 / (64 * k.ks));
+                size_t lds = 0;
+                int ringcols = 0;
+                for (; npt >= 1; --npt) {
+                    ringcols = std::min((npt - 1) * 14 + 18, s.in_side);
+                    lds = static_cast<size_t>(9 * kg) * 1024 + 256 + static_cast<size_t>(3) * ringcols * s.cin * 4 + (k.ks == 3 ? 2 * npt * 1024 : 0);
+                    if (lds <= 160 * 1024 && ringcols * (s.cin / 4) <= k.lpt * 64 * npt * k.ks) break;
+                }
+                if (npt < 1) continue;
+                std::vector<float> frag(static_cast<size_t>(9 * kg) * 64 * 4, 0.f);
+                const float* wsrc = w->stages[si].kernel;      // HWIO = [tap][cin][cout]
+                for (int tap = 0; tap < 9; ++tap)
+                    for (int q = 0; q < kg; ++q)
+                        for (int l = 0; l < 64; ++l)
+                            for (int i = 0; i < 4; ++i)
+                                frag[((static_cast<size_t>(tap) * kg + q) * 64 + l) * 4 + i] =
+                                    wsrc[(static_cast<size_t>(tap) * s.cin + 16 * q + 4 * (l >> 4) + i) * 16 + (l & 15)];
+                void* d = nullptr;
+                if (hipMalloc(&d, frag.size() * 4) != hipSuccess) {
+                    rn_set_error("hipMalloc(fp32 MFMA weights) failed");
+                    return RN_E_NOMEM;
+                }
+                h->allocs.push_back(d);
+                RN_HIP(hipMemcpy(d, frag.data(), frag.size() * 4, hipMemcpyHostToDevice));
+                f.wfrag = static_cast<f32x4*>(d);
+                f.m16 = true;
+                f.variant = static_cast<int>(v);
+                f.ks16 = k.ks;
+                f.npt = npt;
+                f.ringcols = ringcols;
+                f.lds = lds;
+                f.n_colblocks = (tiles + npt - 1) / npt;
+                f.n_ctg = 1;
+                f.on = true;
+                break;
+            }
+            continue;
         }
         if (f.variant < 0) continue;
         if (s.skip_stage >= 0 && h->stages[s.skip_stage].node_bn2 >= 0) continue;      // skip source = a first BN output
@@ -490,7 +710,10 @@ int rn_f32m_launch(rn_handle* h, int stage, const float* in, int n) {
     if (per_band * bands < h->n_cu) bands = static_cast<int>(std::min<long>((h->n_cu + per_band - 1) / per_band, max_bands));
     a.rows_per_band = (s.out_side + bands - 1) / bands;
     a.n_bands = (s.out_side + a.rows_per_band - 1) / a.rows_per_band;
-    kF32Variants[f.variant].fn(a, dim3(a.n_bands * a.n_colblocks * a.n_ctg, n), dim3(64 * f.npt * kF32Variants[f.variant].ks), f.lds, h->stream);
+    if (f.m16)
+        kF32Variants16[f.variant].fn(a, dim3(a.n_bands * a.n_colblocks, n), dim3(64 * f.npt * f.ks16), f.lds, h->stream);
+    else
+        kF32Variants[f.variant].fn(a, dim3(a.n_bands * a.n_colblocks * a.n_ctg, n), dim3(64 * f.npt * kF32Variants[f.variant].ks), f.lds, h->stream);
     RN_CHECK_LAUNCH();
     return RN_OK;
 }

@@ -26,6 +26,33 @@ def test_one_device_group_matches_the_plain_handle(weights, parity_images):
         eng.close()
 
 
+def test_group_host_entry_reuses_its_upload_thread_and_takes_pinned_buffers(weights, parity_images):
+    """rn_group_forward_u8 hands the shards to the group's persistent per-device upload threads: many calls on one group (the
+    thread is parked and woken, not re-created), pageable and page-locked sources, a second group alive beside the first."""
+    g = build_graph(6, 224)
+    grp = _capi.Group(g, weights, devices=[0], dtype="f16", max_batch_per_device=4)
+    grp2 = _capi.Group(g, weights, devices=[0], dtype="f16", max_batch_per_device=4)
+    eng = _capi.Engine(g, weights, device=0, dtype="f16", max_batch=4)
+    pin = _capi.PinnedArray((4, 224, 224, 3), np.uint8)
+    try:
+        for rep in range(12):
+            idx = [(rep * 5 + j) % len(parity_images) for j in range(1 + rep % 4)]
+            ims = parity_images[idx]
+            ids_e, probs_e = eng.forward_u8(ims)
+            src = ims
+            if rep % 2:
+                pin.array[:len(idx)] = ims
+                src = pin.array[:len(idx)]
+            ids_g, probs_g = (grp if rep % 3 else grp2).forward_u8(src)
+            np.testing.assert_array_equal(probs_g, probs_e)
+            np.testing.assert_array_equal(ids_g, ids_e)
+    finally:
+        pin.close()
+        grp.close()
+        grp2.close()
+        eng.close()
+
+
 def test_group_argument_checks(weights):
     g = build_graph(6, 224)
     with pytest.raises(ValueError):
