@@ -2,7 +2,7 @@
 
   python tools/bench_images.py [H W [N]]          N decoded images of one size (decode excluded):
         host centre-crop + resize (roomnet_amd.imageops) + rn_forward_u8   vs   rn_classify_images_u8 (crop + resize on the GPU)
-  python tools/bench_images.py --dir [H W [N]]    a generated directory of N JPEG files of that size through
+  python tools/bench_images.py --dir [--threads=T] [H W [N]]    a generated directory of N JPEG files of that size through
         classify_im_dir(overlay=False) and groundtruth_validation (decode on the thread pool, crop + resize + forward on
         the GPU), next to decode alone and to the one-image-at-a-time loop of the reference's caller (infer.py:79-82)
 """
@@ -22,6 +22,10 @@ from roomnet_amd.graph import build_graph
 from roomnet_amd.imageops import resize_linear_u8
 from roomnet_amd.tf_bundle import BundleReader
 
+THREADS = None
+for _a in sys.argv[1:]:
+    if _a.startswith('--threads='):
+        THREADS = int(_a.split('=', 1)[1])          # decode threads of the directory drivers (default: infer.DECODE_THREADS)
 args = [a for a in sys.argv[1:] if not a.startswith('--')]
 H = int(args[0]) if len(args) > 0 else 1080
 W = int(args[1]) if len(args) > 1 else 1920
@@ -56,6 +60,8 @@ def decoded_images():
 def directory():
     from roomnet_amd import infer
     from roomnet_amd.network import RoomNet
+    if THREADS:
+        infer.DECODE_THREADS = THREADS
     root = tempfile.mkdtemp(prefix='rn_bench_')
     d = os.path.join(root, 'images')
     os.makedirs(d)

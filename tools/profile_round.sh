@@ -25,7 +25,7 @@ cd /tmp
 rm -rf /tmp/kt && rocprofv3 --kernel-trace --stats -d /tmp/kt -o kt --output-format csv -- python3 $R/bench.py --no-cpu-baseline > /tmp/kt.log 2>&1
 f=$(find /tmp/kt -name "*kernel_stats.csv" | head -1); cp "$f" $O/${tag}_kernel_stats.csv
 $R/tools/pmc_run.sh $tag > $O/${tag}_sq_summary.txt 2>&1
-if [ -f $R/roomnet_amd/lib/libroomnet_hip_stamps.so ]; then
-  cd $R && ROOMNET_HIP_LIB=roomnet_amd/lib/libroomnet_hip_stamps.so python3 bench.py --steps 2 --warmup 1 --spinup-steps 0 --no-cpu-baseline --profile-steps 1 2>&1 | grep "stamps" > $O/${tag}_stamps.txt
+if [ -f $R/tools/ab/libroomnet_hip_stamps.so ]; then
+  cd $R && ROOMNET_HIP_LIB=tools/ab/libroomnet_hip_stamps.so python3 bench.py --steps 2 --warmup 1 --spinup-steps 0 --no-cpu-baseline --profile-steps 1 2>&1 | grep "stamps" > $O/${tag}_stamps.txt
 fi
 head -c 600 $O/${tag}_bench.json; echo; head -14 $O/${tag}_kernel_stats.csv | cut -c1-160
