@@ -276,6 +276,8 @@ def main():
                          "spin-up and reported as `cold_images_per_sec`")
     ap.add_argument("--stage-launches", action="store_true",
                     help="one launch per conv stage (RN_FLAG_STAGE_LAUNCHES): the unfused comparison arm")
+    ap.add_argument("--compute-frozen", action="store_true",
+                    help="RN_FLAG_COMPUTE_FROZEN: convolve the channels rn_create proves constant too (the comparison arm: same bits)")
     ap.add_argument("--stub-engine", action="store_true", help=argparse.SUPPRESS)    # CPU tensors + gloo (tests)
     ap.add_argument("--force-collective", action="store_true",
                     help="run the N > 1 code path (RCCL process group, per-step all-gather, barriers, gathered-block check) "
@@ -328,11 +330,11 @@ def main():
             weights["dense/kernel"] = np.random.default_rng(600).uniform(
                 -0.04, 0.04, (graph.flat_len, 32)).astype(np.float32)
         eng = _capi.Engine(graph, weights, device=local_rank, dtype=args.dtype, max_batch=B,
-                           stage_launches=args.stage_launches, pair32=args.pair32)
+                           stage_launches=args.stage_launches, pair32=args.pair32, compute_frozen=args.compute_frozen)
     engs = [eng]
     if not stub and args.handles == 2:
         engs.append(_capi.Engine(graph, weights, device=local_rank, dtype=args.dtype, max_batch=B,
-                                 stage_launches=args.stage_launches, pair32=args.pair32))
+                                 stage_launches=args.stage_launches, pair32=args.pair32, compute_frozen=args.compute_frozen))
 
     ims = torch.from_numpy(perf_batch(B, args.side, seed=rank)).to(dev)
     # probs [B,6] fp32 and ids [B] int64 live in ONE byte buffer per rank, so the result exchange is a single

@@ -19,6 +19,7 @@ RN_FLAG_TAPS = 1
 RN_FLAG_STAGE_LAUNCHES = 2      # 16-bit handles: one launch per conv stage (no cross-stage fusion)
 RN_FLAG_GENERIC_KERNELS = 4     # 16-bit handles: generic stage kernel everywhere (diagnostic cross-check)
 RN_FLAG_PAIR_32X32 = 8          # 16-bit handles: the fused stage pair on the round-2 32x32x16 kernel (comparison arm)
+RN_FLAG_COMPUTE_FROZEN = 16     # 16-bit handles: convolve the provably constant channels too (comparison arm: same bits)
 RN_MAX_STAGES = 16
 RN_MAX_DENSE = 8
 RN_NAME_LEN = 32
@@ -238,7 +239,8 @@ class Engine:
 
     def __init__(self, graph: Graph, weights: Dict[str, np.ndarray], device: int = 0, dtype="f32",
                  max_batch: int = 64, taps: bool = False, lib_path: Optional[str] = None,
-                 stage_launches: bool = False, generic_kernels: bool = False, pair32: bool = False):
+                 stage_launches: bool = False, generic_kernels: bool = False, pair32: bool = False,
+                 compute_frozen: bool = False):
         self.lib = load_library(lib_path)
         self.graph = graph
         self.dtype = DTYPES[dtype] if isinstance(dtype, str) else int(dtype)
@@ -249,7 +251,8 @@ class Engine:
         rc = self.lib.rn_create(C.byref(packed.w), self.device, self.dtype, self.max_batch,
                                 (RN_FLAG_TAPS if taps else 0) | (RN_FLAG_STAGE_LAUNCHES if stage_launches else 0)
                                 | (RN_FLAG_GENERIC_KERNELS if generic_kernels else 0)
-                                | (RN_FLAG_PAIR_32X32 if pair32 else 0), C.byref(h))
+                                | (RN_FLAG_PAIR_32X32 if pair32 else 0)
+                                | (RN_FLAG_COMPUTE_FROZEN if compute_frozen else 0), C.byref(h))
         _check(self.lib, rc, "rn_create")
         self._h = h
         self._nodes: Optional[Dict[str, Tuple[int, Tuple[int, int, int]]]] = None

@@ -624,6 +624,9 @@ struct FusedState {
     bool pair_x16 = false;       // the pair runs on 16x16x32 tiles (rn_stage23x.hip) with the fragments below
     i32x4* pair_wfrag_a = nullptr;
     i32x4* pair_wfrag_b = nullptr;
+    float* pair_ptab_x = nullptr;    // rn_stage23x.hip's table: pair_ptab with the first stage's channels in the B ring's order
+    int pair_producer_halves = 2;    // 1: 16 channels of the pair's on-chip tensor are frozen and not computed (Stage23Args)
+    int pair_frozen = 0;             // how many channels of it are frozen on this handle
     // stage 0
     i32x4* s0_wfrag = nullptr;
     float* s0_ptab = nullptr;
@@ -911,12 +914,94 @@ int rn_fused_prepare(rn_handle* h, const rn_weights* w) {
             fs->pair_ptab = static_cast<float*>(dt);
             fs->pair_first = static_cast<int>(i);
             if (!(h->flags & RN_FLAG_PAIR_32X32)) {
+                // ---- frozen channels of the pair's on-chip tensor B (the first stage's output).  The epilogue stores
+                // to16(fma(H, sc, sh)) with H = a sum of 16 ReLU6 / 6 values in [0, 16]: when |sc| * 16 is so small that every
+                // value of [sh - d, sh + d] rounds to the SAME 16-bit number, the channel is that constant whatever the image --
+                // in this kernel's arithmetic bit for bit, and (d < 1e-10 of an O(1) tensor) in the reference's float32 too.
+                // The shipped checkpoint has 18 such channels of 32 (its L2 regulariser drove their BN gamma to ~1e-20): with
+                // >= 16 of them the first conv computes half of its couts.  perm[p] = the channel at B-ring position p; the
+                // positions (p & 7) >= 4 -- the second half of every 8-cout group -- take frozen channels.
+                int perm[32];
+                {
+                    std::vector<int> frozen, live;
+                    for (int c = 0; c < 32; ++c) {
+                        const double sc = t1[c], sh = t1[32 + c];
+                        const double d = std::fabs(sc) * 16.0 * (1.0 + 1e-6);      // (fma and conversion round monotonically)
+                        const auto cv = [&](double v) { return h->dtype == RN_DTYPE_BF16 ? f32_to_bf16(static_cast<float>(v)) : f32_to_f16(static_cast<float>(v)); };
+                        const bool fz = d < 1e-10 && cv(sh - d) == cv(sh + d) && cv(sh - d) == cv(sh);
+                        (fz ? frozen : live).push_back(c);
+                    }
+                    fs->pair_frozen = static_cast<int>(frozen.size());
+                    fs->pair_producer_halves = (frozen.size() >= 16 && !(h->flags & RN_FLAG_COMPUTE_FROZEN)) ? 1 : 2;
+                    if (fs->pair_producer_halves == 1) {
+                        while (frozen.size() > 16) {             // the spare frozen channels are computed like live ones
+                            live.push_back(frozen.back());
+                            frozen.pop_back();
+                        }
+                        std::sort(live.begin(), live.end());
+                        size_t nl = 0, nf = 0;
+                        for (int p = 0; p < 32; ++p) perm[p] = (p & 7) >= 4 ? frozen[nf++] : live[nl++];
+                    } else {
+                        for (int p = 0; p < 32; ++p) perm[p] = p;
+                    }
+                    std::vector<float> tabx(tab);
+                    tabx.resize(6 * 32, 0.f);
+                    for (int p = 0; p < 32; ++p) {
+                        tabx[p] = t1[perm[p]];
+                        tabx[32 + p] = t1[32 + perm[p]];
+                    }
+                    if (fs->pair_producer_halves == 1) {
+                        // row 5: what the 16 frozen channels (B positions (p & 7) >= 4) add to every output of the second conv:
+                        // sum over the nine taps of (16-bit weight / 6) x (the channel's stored 16-bit value) -- the products the
+                        // matrix cores would form, summed here in double
+                        const auto cv = [&](float v) { return h->dtype == RN_DTYPE_BF16 ? f32_to_bf16(v) : f32_to_f16(v); };
+                        const auto bk = [&](unsigned short u) {
+                            if (h->dtype != RN_DTYPE_BF16) return f16_to_f32(u);
+                            const unsigned bits = static_cast<unsigned>(u) << 16;
+                            float f;
+                            std::memcpy(&f, &bits, 4);
+                            return f;
+                        };
+                        const float* w3src = w->stages[i + 1].kernel;       // [tap][cin][cout]
+                        for (int co = 0; co < 32; ++co) {
+                            double sum = 0.0;
+                            for (int p = 0; p < 32; ++p) {
+                                if ((p & 7) < 4) continue;
+                                const double val = bk(cv(t1[32 + perm[p]]));
+                                for (int tap = 0; tap < 9; ++tap)
+                                    sum += static_cast<double>(bk(cv(w3src[(static_cast<size_t>(tap) * 32 + perm[p]) * 32 + co] / 6.0f))) * val;
+                            }
+                            tabx[160 + co] = static_cast<float>(sum);
+                        }
+                    }
+                    void* dx = nullptr;
+                    if (hipMalloc(&dx, tabx.size() * 4) != hipSuccess) {
+                        rn_set_error("hipMalloc(fused pair tables) failed");
+                        return RN_E_NOMEM;
+                    }
+                    h->allocs.push_back(dx);
+                    RN_HIP(hipMemcpy(dx, tabx.data(), tabx.size() * 4, hipMemcpyHostToDevice));
+                    fs->pair_ptab_x = static_cast<float*>(dx);
+                }
                 for (int which = 0; which < 2; ++which) {
                     std::vector<unsigned short> f16;
                     // (both stages are pool 4/1 register-weights stages: `sixth` weights, like their fragments above)
-                    std::vector<float> w6(w->stages[i + which].kernel, w->stages[i + which].kernel + static_cast<size_t>(9) * 32 * 32);
-                    for (float& v : w6) v /= 6.0f;
-                    rn_stage23x_pack(w6.data(), h->dtype, f32_to_bf16, f32_to_f16, &f16);
+                    std::vector<float> w6(static_cast<size_t>(9) * 32 * 32);
+                    const float* wsrc6 = w->stages[i + which].kernel;       // [tap][cin][cout]
+                    for (int tap = 0; tap < 9; ++tap)
+                        for (int ci = 0; ci < 32; ++ci)
+                            for (int co = 0; co < 32; ++co)
+                                w6[(static_cast<size_t>(tap) * 32 + ci) * 32 + co] =
+                                    (which == 0 ? wsrc6[(static_cast<size_t>(tap) * 32 + ci) * 32 + perm[co]]        // B's channels = the first conv's couts
+                                                : wsrc6[(static_cast<size_t>(tap) * 32 + perm[ci]) * 32 + co]) / 6.0f; // ... and the second conv's cins
+                    if (which == 1 && fs->pair_producer_halves == 1) {
+                        int ring_cin[16];
+                        for (int r = 0; r < 16; ++r) ring_cin[r] = perm[8 * (r >> 2) + (r & 3)];
+                        std::vector<float> w3s(static_cast<size_t>(9) * 32 * 32);
+                        for (size_t q = 0; q < w3s.size(); ++q) w3s[q] = wsrc6[q] / 6.0f;
+                        rn_stage23x_pack_narrow(w3s.data(), ring_cin, h->dtype, f32_to_bf16, f32_to_f16, &f16);
+                    } else
+                        rn_stage23x_pack(w6.data(), h->dtype, f32_to_bf16, f32_to_f16, &f16);
                     void* d16 = nullptr;
                     if (hipMalloc(&d16, f16.size() * 2) != hipSuccess) {
                         rn_set_error("hipMalloc(fused pair weights) failed");
@@ -1062,7 +1147,9 @@ int rn_fused_forward(rn_handle* h, const uint8_t* d_bgr, const float* d_rgb, int
             fa.out = static_cast<unsigned short*>(h->nodes[s2.node_bn2].ptr);
             fa.wfrag2 = fs->pair_x16 ? fs->pair_wfrag_a : f.wfrag;
             fa.wfrag3 = fs->pair_x16 ? fs->pair_wfrag_b : fs->st[i + 1].wfrag;
-            fa.ptab = fs->pair_ptab;
+            fa.ptab = fs->pair_x16 ? fs->pair_ptab_x : fs->pair_ptab;
+            fa.producer_halves = fs->pair_x16 ? fs->pair_producer_halves : 2;
+            fa.narrow_b = fa.producer_halves == 1 ? 1 : 0;
             fa.rlo = s2.rt.lo;
             fa.rhi = s2.rt.hi;
             fa.rlerp = s2.rt.lerp;

@@ -301,6 +301,13 @@ struct Stage23Args {
     int n_cblocks;
     int cb_x0[4], cb_wo[4];
     unsigned long long* stamp_buf; // diagnostic build (-DRN_STAMPS) only: per-wave cycle sums
+    // rn_stage23x.hip only: 1 = the first stage computes the first half of every 8-cout group only (B-ring channels 8 j .. 8 j + 3);
+    // the other 16 channels of B are FROZEN -- constants whatever the input (rn_fused_prepare proves it per channel for the
+    // handle's dtype and orders the channels accordingly) -- and are written from the table, bit for bit what the full
+    // computation would store.  2 = every channel is computed.
+    int producer_halves;
+    int narrow_b;                 // (with producer_halves == 1) the B ring holds the 16 computed channels only; wfrag3 = rn_stage23x_pack_narrow's
+                                  // 12 fragments, ptab row 5 = the second conv's constant of the frozen channels
 };
 
 // 64 -> 128 stage without pooling on 16x16x32 matrix tiles (rn_conv16.hip)

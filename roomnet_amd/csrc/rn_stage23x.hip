@@ -50,7 +50,8 @@ constexpr int X_ROWA = X_WMAX * 64;              // bytes per A ring row (32 cha
 constexpr int X_BDUMMY = X_WMAX - 5;             // B ring column that invalid lanes write to (never read for a valid output)
 constexpr int X_ROWB = (X_BDUMMY + 1) * 64;
 constexpr int X_SKROW = 64 * 64;                 // one private skip row: 64 columns
-constexpr int X_NTAB = 5 * 32;                   // folded BN tables: sc2, sh2 | sc3', sh3', sc4
+constexpr int X_ROWB_N = (X_BDUMMY + 1) * 32;    // ... of the narrow B ring (16 channels per pixel)
+constexpr int X_NTAB = 6 * 32;                   // folded BN tables: sc2, sh2 | sc3', sh3', sc4 | narrow form: the second conv's per-cout constant
 constexpr int X_RINGA_OFF = 1024;
 constexpr int X_RINGB_OFF = X_RINGA_OFF + X_NA * X_ROWA;
 constexpr int X_SKIP_OFF = X_RINGB_OFF + X_NB * X_ROWB;
@@ -82,8 +83,20 @@ __device__ __forceinline__ f32x4 mfma16(i32x4 a, i32x4 b, f32x4 c) {
         return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
 }
 
-template <int DT>
+// PH = halves of every 8-cout group the PRODUCER computes: 2 = all 32 channels of B; 1 = the first half only -- the other 16
+// channels are frozen (Stage23Args::producer_halves: constants for every input, proven per channel by rn_fused_prepare) and are
+// written from the table, the same bits the full computation stores.  Half of the first conv's matrix instructions (9 + 2 of
+// 18 + 4 per tile) and half of its epilogue go; two adjacent tiles then share a chain so that it still alternates two
+// independent accumulators.
+// NB (with PH = 1) = the NARROW form of the B tensor: the ring holds only the 16 computed channels (32 bytes per pixel, ring
+// channel 4 g + i = B position 8 g + i); the second conv contracts them two kernel columns at a time (K = 32 = [kx 0 | kx 1],
+// then [kx 2 | zero weights]: 6 operand reads and 12 MFMAs per tile where the 32-channel ring takes 9 and 18) and starts its
+// accumulators from the per-cout constant of the 16 frozen channels (Stage23Args::ptab row 5: sum over taps and frozen
+// channels of weight x stored 16-bit value -- a VALID convolution sees every tap of every pixel, so the constant is exact).
+template <int DT, int PH, bool NB>
 __global__ __launch_bounds__(512, 2) void stage23x_kernel(const Stage23Args a) {
+    static_assert(!NB || PH == 1, "the narrow B ring holds the computed half only");
+    constexpr int ROWB = NB ? X_ROWB_N : X_ROWB;
 // Registers: the kernel sits at 256 VGPRs with six spilled dwords, two of them reloaded inside the consumer's loop.  A build that
 // keeps four of the consumers' weight fragments in LDS instead has no scratch access at all and is 3 % SLOWER (0.490 against
 // 0.475 ms, one session, round 4; two fragments: equal); the reloads are not what bounds the kernel (NOTES.md).
@@ -245,6 +258,7 @@ __global__ __launch_bounds__(512, 2) void stage23x_kernel(const Stage23Args a) {
         i32x4 w2[2 * X_KT];
 #pragma unroll
         for (int f = 0; f < 2 * X_KT; ++f) {
+            if (PH == 1 && (f & 1)) continue;             // (fragment 2 tap + half: the second halves are not computed)
             const i32x4* src = a.wfrag2 + f * 64 + lane;
             asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(w2[f]) : "v"(src) : "memory");
         }
@@ -289,7 +303,10 @@ __global__ __launch_bounds__(512, 2) void stage23x_kernel(const Stage23Args a) {
             const int xo = xw + 16 * k + px16;
             const bool last = k == (has4 ? 3 : 2);
             const int col = (xo < Wb && !(last && px16 >= 13) && (k < 3 || has4)) ? xo : X_BDUMMY;
-            wbB[k] = ringB_lds + static_cast<unsigned>(col * 64 + ((g ^ swzx(col)) << 4));
+            if constexpr (NB)       // 8 bytes (the lane's 4 computed couts) at 8 g of the 32-byte pixel; 16-byte chunks XOR bit 3 of the column
+                wbB[k] = ringB_lds + static_cast<unsigned>(col * 32 + ((((g >> 1) ^ ((col >> 3) & 1)) << 4) | ((g & 1) << 3)));
+            else
+                wbB[k] = ringB_lds + static_cast<unsigned>(col * 64 + ((g ^ swzx(col)) << 4));
         }
         // folded BN of the lane's 8 couts (8 g .. 8 g + 7)
         f32x4 scv[2], shv[2];
@@ -309,8 +326,96 @@ __global__ __launch_bounds__(512, 2) void stage23x_kernel(const Stage23Args a) {
         int ylo_nxt = ylo_step(0);                       // lo skip row of the output row the coming step finishes
         wait_vmcnt<0>();
 #pragma unroll
-        for (int f = 0; f < 2 * X_KT; ++f) asm volatile("" : "+v"(w2[f]));
+        for (int f = 0; f < 2 * X_KT; ++f)
+            if (PH == 2 || !(f & 1)) asm volatile("" : "+v"(w2[f]));
         lds_barrier();
+        // PH == 1: the frozen channels of the lane's group (positions 8 g + 4 .. 8 g + 7) as the two dwords every store carries
+        [[maybe_unused]] const int cdead0 = static_cast<int>(pack2<DT>(shv[1][0], shv[1][1])), cdead1 = static_cast<int>(pack2<DT>(shv[1][2], shv[1][3]));
+
+        // ---- PH == 1: two adjacent tiles share a chain (one accumulator each: two independent MFMA chains, as the two halves of a
+        // tile are in the full form); a tap costs two operand reads and two MFMAs
+        [[maybe_unused]] auto chain2 = [&](auto S0C, auto K0C, auto K1C, f32x4& acc0, f32x4& acc1, auto&& hook) __attribute__((always_inline)) {
+            constexpr int S0 = decltype(S0C)::value, k0 = decltype(K0C)::value, k1 = decltype(K1C)::value;
+            i32x4 fa[X_KT], fb[X_KT];
+            auto rd = [&](auto TC, auto KC_, float dep) __attribute__((always_inline)) -> i32x4 {
+                constexpr int tap = decltype(TC)::value, ky = tap / 3, kx = tap % 3, k = decltype(KC_)::value;
+                constexpr int off = ((S0 + ky) % 4) * X_ROWA + k * 1024;
+                i32x4 v;
+                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(baseA[kx]), "n"(off), "v"(dep));
+                return v;
+            };
+            [&]<int... I>(std::integer_sequence<int, I...>) { ((fa[I] = rd(IC<I>{}, IC<k0>{}, 0.f), fb[I] = rd(IC<I>{}, IC<k1>{}, 0.f)), ...); }(std::make_integer_sequence<int, AHEAD>{});
+            [&]<int... I>(std::integer_sequence<int, I...>) {
+                (([&] {
+                     if constexpr (I + AHEAD < X_KT) {
+                         fa[I + AHEAD] = rd(IC<(I + AHEAD < X_KT ? I + AHEAD : 0)>{}, IC<k0>{}, I == 0 ? 0.f : acc0[0]);
+                         fb[I + AHEAD] = rd(IC<(I + AHEAD < X_KT ? I + AHEAD : 0)>{}, IC<k1>{}, I == 0 ? 0.f : acc1[0]);
+                     }
+                     constexpr int newer = (X_KT - 1 - I) < AHEAD ? (X_KT - 1 - I) : AHEAD;
+                     asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(fa[I]), "+v"(fb[I]) : "n"(2 * newer));
+                     acc0 = mfma16<DT>(fa[I], w2[2 * I], I == 0 ? zero4 : acc0);
+                     acc1 = mfma16<DT>(fb[I], w2[2 * I], I == 0 ? zero4 : acc1);
+                     hook(IC<I>{});
+                 }()),
+                 ...);
+            }(std::make_integer_sequence<int, X_KT>{});
+        };
+        // ... and a single tile (the third tile of a three-tile wave): one dependent chain
+        [[maybe_unused]] auto chain1 = [&](auto S0C, auto KC_, f32x4& acc0, auto&& hook) __attribute__((always_inline)) {
+            constexpr int S0 = decltype(S0C)::value, k = decltype(KC_)::value;
+            i32x4 fa[X_KT];
+            auto rd = [&](auto TC, float dep) __attribute__((always_inline)) -> i32x4 {
+                constexpr int tap = decltype(TC)::value, ky = tap / 3, kx = tap % 3;
+                constexpr int off = ((S0 + ky) % 4) * X_ROWA + k * 1024;
+                i32x4 v;
+                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(baseA[kx]), "n"(off), "v"(dep));
+                return v;
+            };
+            [&]<int... I>(std::integer_sequence<int, I...>) { ((fa[I] = rd(IC<I>{}, 0.f)), ...); }(std::make_integer_sequence<int, AHEAD>{});
+            [&]<int... I>(std::integer_sequence<int, I...>) {
+                (([&] {
+                     if constexpr (I + AHEAD < X_KT) fa[I + AHEAD] = rd(IC<(I + AHEAD < X_KT ? I + AHEAD : 0)>{}, I == 0 ? 0.f : acc0[0]);
+                     constexpr int newer = (X_KT - 1 - I) < AHEAD ? (X_KT - 1 - I) : AHEAD;
+                     asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(fa[I]) : "n"(newer));
+                     acc0 = mfma16<DT>(fa[I], w2[2 * I], I == 0 ? zero4 : acc0);
+                     hook(IC<I>{});
+                 }()),
+                 ...);
+            }(std::make_integer_sequence<int, X_KT>{});
+        };
+        // the first-half finish of two tiles behind MFMA pairs 1 .. 6 of the next chain
+        [[maybe_unused]] auto with_finish2 = [&](auto&& base, auto PRC, const f32x4 (&accx)[2], int (&hpx)[2][2], int (&q0x)[2][2], int (&q1x)[2][2], i32x4 (&opx)[2],
+                                const f32x4 (&accy)[2], int (&hpy)[2][2], int (&q0y)[2][2], int (&q1y)[2][2], i32x4 (&opy)[2], int (&vt)[2][2]) __attribute__((always_inline)) {
+            return [&, PRC](auto IC_) __attribute__((always_inline)) {
+                constexpr int i = decltype(IC_)::value;
+                base(IC_);
+                if constexpr (i >= 1 && i <= 3) finish_part(IC<(i >= 1 && i <= 3 ? i - 1 : 0)>{}, PRC, accx, hpx, q0x, q1x, opx, vt);
+                if constexpr (i >= 4 && i <= 6) finish_part(IC<(i >= 4 && i <= 6 ? i - 4 : 0)>{}, PRC, accy, hpy, q0y, q1y, opy, vt);
+            };
+        };
+        [[maybe_unused]] auto finish1 = [&](auto PRC, const f32x4 (&acc)[2], int (&hpx)[2][2], int (&q0x)[2][2], int (&q1x)[2][2], i32x4 (&opx)[2]) __attribute__((always_inline)) {
+            int vt[2][2];
+            finish_part(IC<0>{}, PRC, acc, hpx, q0x, q1x, opx, vt);
+            finish_part(IC<1>{}, PRC, acc, hpx, q0x, q1x, opx, vt);
+            finish_part(IC<2>{}, PRC, acc, hpx, q0x, q1x, opx, vt);
+        };
+        [[maybe_unused]] auto out1 = [&](auto KC, auto PC, const i32x4 (&opk)[2], const i32x4 (&opn)[2], bool cross) __attribute__((always_inline)) {
+            constexpr int k = decltype(KC)::value, P = decltype(PC)::value;
+            constexpr int off = ((P + 3) % X_NB) * ROWB;         // B row t-5
+            f32x4 H = mfma16<RN_DTYPE_F16>(opk[0], pm, zero4);
+            if (cross) H = mfma16<RN_DTYPE_F16>(opn[0], pmx, H);
+            float y[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) y[i] = __builtin_fmaf(H[i], scv[0][i], shv[0][i]);
+            auto& wb = wbB;
+            if constexpr (NB) {
+                const i32x2 d = {static_cast<int>(pack2<DT>(y[0], y[1])), static_cast<int>(pack2<DT>(y[2], y[3]))};
+                asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(wb[k]), "v"(d), "n"(off) : "memory");
+            } else {
+                const i32x4 d = {static_cast<int>(pack2<DT>(y[0], y[1])), static_cast<int>(pack2<DT>(y[2], y[3])), cdead0, cdead1};
+                asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(wb[k]), "v"(d), "n"(off) : "memory");
+            }
+        };
 
         auto out = [&](auto KC, auto PC, const i32x4 (&opk)[2], const i32x4 (&opn)[2], bool cross) __attribute__((always_inline)) {
             constexpr int k = decltype(KC)::value, P = decltype(PC)::value;
@@ -371,6 +476,44 @@ __global__ __launch_bounds__(512, 2) void stage23x_kernel(const Stage23Args a) {
                 if constexpr (i == 4) issue_skip_piece(IC<2>{}, sk_f, sk_slot);
                 if constexpr (i == 6) issue_skip_piece(IC<3>{}, sk_f, sk_slot);
             };
+            if constexpr (PH == 1) {
+                // the DMA pieces of A row t + 1 and the skip bookkeeping behind the first chain's MFMA pairs, the partner
+                // consumer's skip pieces and the two tiles' finish slices behind the second's
+                auto hookA = [&](auto IC_) __attribute__((always_inline)) {
+                    constexpr int i = decltype(IC_)::value;
+                    if constexpr (i == 0) issue_A_piece(IC<0>{}, a_next, (P + 1) % X_NA);
+                    if constexpr (i == 2) issue_A_piece(IC<1>{}, a_next, (P + 1) % X_NA);
+                    if constexpr (i == 4) issue_A_piece(IC<2>{}, a_next, (P + 1) % X_NA);
+                    if constexpr (i == 6) issue_A_piece(IC<3>{}, a_next, (P + 1) % X_NA);
+                    if constexpr (i == 3 || i == 7) hook0(IC_);              // (hook0's bookkeeping slots)
+                };
+                f32x4 ac0[2], ac1[2], ac2[2], ac3[2];
+                int vt[2][2];
+                i32x4 op[4][2];
+                op[3][0] = op[3][1] = i32x4{0, 0, 0, 0};
+                chain2(IC<(P + 2) % 4>{}, IC<0>{}, IC<1>{}, ac0[0], ac1[0], hookA);
+                if (has4) {
+                    chain2(IC<(P + 2) % 4>{}, IC<2>{}, IC<3>{}, ac2[0], ac3[0],
+                           with_finish2(hook2, IC<PR>{}, ac0, hp[0], q0[0], q1[0], op[0], ac1, hp[1], q0[1], q1[1], op[1], vt));
+                    out1(IC<0>{}, PC, op[0], op[1], true);
+                    finish1(IC<PR>{}, ac2, hp[2], q0[2], q1[2], op[2]);
+                    out1(IC<1>{}, PC, op[1], op[2], true);
+                    finish1(IC<PR>{}, ac3, hp[3], q0[3], q1[3], op[3]);
+                    out1(IC<2>{}, PC, op[2], op[3], true);
+                    out1(IC<3>{}, PC, op[3], op[3], false);
+                } else {
+                    chain1(IC<(P + 2) % 4>{}, IC<2>{}, ac2[0],
+                           with_finish2(hook2, IC<PR>{}, ac0, hp[0], q0[0], q1[0], op[0], ac1, hp[1], q0[1], q1[1], op[1], vt));
+                    out1(IC<0>{}, PC, op[0], op[1], true);
+                    finish1(IC<PR>{}, ac2, hp[2], q0[2], q1[2], op[2]);
+                    out1(IC<1>{}, PC, op[1], op[2], true);
+                    out1(IC<2>{}, PC, op[2], op[3], true);         // op[3] = 0, and columns 13..15 of the third tile go to the dummy column
+                }
+                wait_vmcnt<0>();
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                raw_barrier();
+                return;
+            }
             // tile k's ReLU6 / pack / pair sums ride behind the MFMAs of tile k + 1's chain (two accumulator pairs alternate)
             f32x4 accA[2], accB[2];
             int vt[2][2];
@@ -415,9 +558,10 @@ __global__ __launch_bounds__(512, 2) void stage23x_kernel(const Stage23Args a) {
     const bool has4 = wq >= 2;                                      // tiles of this wave: 3 3 4 4
     const int xw = xc_start(wq);
     const int xend = wq == 3 ? Wo : min(xc_start(wq + 1), Wo);      // this wave stores output columns [xw, xend)
+    constexpr int NW3 = NB ? 12 : 2 * X_KT;                          // narrow: fragment (2 ky + j) * 2 + half
     i32x4 w3[2 * X_KT];
 #pragma unroll
-    for (int f = 0; f < 2 * X_KT; ++f) {
+    for (int f = 0; f < NW3; ++f) {
         const i32x4* src = a.wfrag3 + f * 64 + lane;
         asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(w3[f]) : "v"(src) : "memory");
     }
@@ -427,6 +571,22 @@ __global__ __launch_bounds__(512, 2) void stage23x_kernel(const Stage23Args a) {
     for (int kx = 0; kx < 3; ++kx) {
         const int p = xw + px16 + kx;
         baseB[kx] = ringB_lds + static_cast<unsigned>(p * 64 + ((g ^ swzx(p)) << 4));
+    }
+    // narrow form: chunk (ky, j) of a tile = ring pixel px16 + 2 j + (g >> 1), channels 8 (g & 1) .. + 7
+    [[maybe_unused]] unsigned baseN[2];
+    [[maybe_unused]] f32x4 cinit[2] = {zero4, zero4};
+    if constexpr (NB) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int p = xw + px16 + 2 * j + (g >> 1);
+            baseN[j] = ringB_lds + static_cast<unsigned>(p * 32 + (((g & 1) ^ ((p >> 3) & 1)) << 4));
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const float c = a.ptab[160 + 8 * (px16 >> 2) + 4 * h + (px16 & 3)];       // D'[pixel][cout]: column px16 of half h
+            cinit[h] = f32x4{c, c, c, c};
+        }
+        for (int i = tid; i < X_NB * X_ROWB_N / 16; i += 512) *reinterpret_cast<i32x4*>(ringB + i * 16) = i32x4{0, 0, 0, 0};
     }
     // output stores: tile k = 1024 bytes further (immediate); a lane stores while its column lies left of the wave's limit
     // for that tile: lim(k) = columns of tile k this wave owns (13 in its last tile, cut at the next wave's start / the row end)
@@ -482,8 +642,39 @@ __global__ __launch_bounds__(512, 2) void stage23x_kernel(const Stage23Args a) {
     RowCtx cx{};
     wait_vmcnt<0>();                                      // the weight fragments have landed
 #pragma unroll
-    for (int f = 0; f < 2 * X_KT; ++f) asm volatile("" : "+v"(w3[f]));
+    for (int f = 0; f < NW3; ++f) asm volatile("" : "+v"(w3[f]));
     lds_barrier();
+    // the narrow second conv: six chunks (2 ky + j), one accumulator pair started from the frozen channels' constant
+    [[maybe_unused]] auto chainN = [&](auto S0C, auto KC, f32x4 (&acc)[2], auto&& hook) __attribute__((always_inline)) {
+        constexpr int S0 = decltype(S0C)::value, k = decltype(KC)::value;
+        i32x4 fq[6];
+        auto rd = [&](auto CC, float dep) __attribute__((always_inline)) -> i32x4 {
+            constexpr int c = decltype(CC)::value, ky = c >> 1, j = c & 1;
+            constexpr int off = ((S0 + ky) % 4) * X_ROWB_N + k * 512;
+            i32x4 v;
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(baseN[j]), "n"(off), "v"(dep));
+            return v;
+        };
+        [&]<int... I>(std::integer_sequence<int, I...>) { ((fq[I] = rd(IC<I>{}, 0.f)), ...); }(std::make_integer_sequence<int, AHEAD>{});
+        [&]<int... I>(std::integer_sequence<int, I...>) {
+            (([&] {
+                 if constexpr (I + AHEAD < 6) fq[I + AHEAD] = rd(IC<(I + AHEAD < 6 ? I + AHEAD : 0)>{}, I == 0 ? 0.f : acc[0][0]);
+                 constexpr int newer = (5 - I) < AHEAD ? (5 - I) : AHEAD;
+                 asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(fq[I]) : "n"(newer));
+                 acc[0] = mfma16<DT>(fq[I], w3[2 * I], I == 0 ? cinit[0] : acc[0]);
+                 acc[1] = mfma16<DT>(fq[I], w3[2 * I + 1], I == 0 ? cinit[1] : acc[1]);
+                 hook(IC<I + 1>{});                         // (the hooks count MFMA pairs 1 .. 6 of a nine-tap chain)
+             }()),
+             ...);
+        }(std::make_integer_sequence<int, 6>{});
+        hook(IC<7>{});
+    };
+    auto cchain = [&](auto PC_, auto KC, f32x4 (&acc)[2], auto&& hook) __attribute__((always_inline)) {
+        if constexpr (NB)
+            chainN(PC_, KC, acc, hook);
+        else
+            chain(PC_, IC<X_ROWB>{}, KC, baseB, w3, acc, hook);
+    };
 
     // The LDS reads of a tile's epilogue (8 transposed reads of the skip rows, 6 table reads) are issued in FRONT of the next
     // tile's ReLU6 / pack work (out_reads), their consumers run behind it (out_rest): the pack's ~25 VALU instructions cover
@@ -592,15 +783,15 @@ __global__ __launch_bounds__(512, 2) void stage23x_kernel(const Stage23Args a) {
         auto hook_c2 = [&](auto IC_) __attribute__((always_inline)) {
             if constexpr (decltype(IC_)::value == 7) vl_pre = vlerp_of(yo0 + min(max(jo + 2, 0), nrows - 1));
         };
-        chain(IC<P>{}, IC<X_ROWB>{}, IC<0>{}, baseB, w3, accA, no_hook);           // conv row t-8: B rows t-8 .. t-6
-        chain(IC<P>{}, IC<X_ROWB>{}, IC<1>{}, baseB, w3, accB, with_finish(no_hook, IC<PR>{}, accA, hp[0], q0[0], q1[0], op[0], vt));
+        cchain(IC<P>{}, IC<0>{}, accA, no_hook);           // conv row t-8: B rows t-8 .. t-6
+        cchain(IC<P>{}, IC<1>{}, accB, with_finish(no_hook, IC<PR>{}, accA, hp[0], q0[0], q1[0], op[0], vt));
         wait_vmcnt<0>();                                       // a skip row fetched at the top of this step has landed
         out_reads(IC<0>{}, R);
-        chain(IC<P>{}, IC<X_ROWB>{}, IC<2>{}, baseB, w3, accA, with_finish(hook_c2, IC<PR>{}, accB, hp[1], q0[1], q1[1], op[1], vt));
+        cchain(IC<P>{}, IC<2>{}, accA, with_finish(hook_c2, IC<PR>{}, accB, hp[1], q0[1], q1[1], op[1], vt));
         out_rest(IC<0>{}, R, op[0], op[1], true);
         if (has4) {
             out_reads(IC<1>{}, R);
-            chain(IC<P>{}, IC<X_ROWB>{}, IC<3>{}, baseB, w3, accB, with_finish(no_hook, IC<PR>{}, accA, hp[2], q0[2], q1[2], op[2], vt));
+            cchain(IC<P>{}, IC<3>{}, accB, with_finish(no_hook, IC<PR>{}, accA, hp[2], q0[2], q1[2], op[2], vt));
             out_rest(IC<1>{}, R, op[1], op[2], true);
             out_reads(IC<2>{}, R);
             finish(IC<PR>{}, accB, hp[3], q0[3], q1[3], op[3]);
@@ -665,6 +856,24 @@ void rn_stage23x_pack(const float* w_hwio, int dtype, unsigned short (*cvt_bf16)
                 }
 }
 
+// Narrow second conv (NB): frag[(2 ky + j)][half][lane][jj] = W[ky][kx = 2 j + (lane / 32)][cin = ring_cin[8 ((lane / 16) & 1) + jj]][cout(half, lane % 16)]
+// (kx = 3: zero); ring_cin[r] = the stage-2 channel at ring channel r (16 entries).  `w_hwio` is the UNpermuted [tap][cin][cout] kernel.
+void rn_stage23x_pack_narrow(const float* w_hwio, const int* ring_cin, int dtype, unsigned short (*cvt_bf16)(float), unsigned short (*cvt_f16)(float),
+                             std::vector<unsigned short>* out) {
+    out->assign(static_cast<size_t>(12) * 64 * 8, 0);
+    for (int c = 0; c < 6; ++c)
+        for (int h = 0; h < 2; ++h)
+            for (int l = 0; l < 64; ++l)
+                for (int jj = 0; jj < 8; ++jj) {
+                    const int ky = c >> 1, kx = 2 * (c & 1) + (l >> 5), nn = l & 15;
+                    if (kx > 2) continue;
+                    const int cin = ring_cin[8 * ((l >> 4) & 1) + jj];
+                    const int co = 8 * (nn >> 2) + 4 * h + (nn & 3);
+                    const float v = w_hwio[(static_cast<size_t>(ky * 3 + kx) * 32 + cin) * 32 + co];
+                    (*out)[((static_cast<size_t>(c) * 2 + h) * 64 + l) * 8 + jj] = dtype == RN_DTYPE_BF16 ? cvt_bf16(v) : cvt_f16(v);
+                }
+}
+
 int rn_stage23x_launch(int dtype, hipStream_t s, const Stage23Args& a, int n) {
     auto launch = [&](auto kern) -> int {
         static std::atomic<unsigned long long> attr_devices{0};     // per device and instantiation
@@ -678,6 +887,14 @@ int rn_stage23x_launch(int dtype, hipStream_t s, const Stage23Args& a, int n) {
         RN_CHECK_LAUNCH();
         return RN_OK;
     };
-    if (dtype == RN_DTYPE_BF16) return launch(stage23x_kernel<RN_DTYPE_BF16>);
-    return launch(stage23x_kernel<RN_DTYPE_F16>);
+    if (a.producer_halves == 1 && a.narrow_b) {
+        if (dtype == RN_DTYPE_BF16) return launch(stage23x_kernel<RN_DTYPE_BF16, 1, true>);
+        return launch(stage23x_kernel<RN_DTYPE_F16, 1, true>);
+    }
+    if (a.producer_halves == 1) {
+        if (dtype == RN_DTYPE_BF16) return launch(stage23x_kernel<RN_DTYPE_BF16, 1, false>);
+        return launch(stage23x_kernel<RN_DTYPE_F16, 1, false>);
+    }
+    if (dtype == RN_DTYPE_BF16) return launch(stage23x_kernel<RN_DTYPE_BF16, 2, false>);
+    return launch(stage23x_kernel<RN_DTYPE_F16, 2, false>);
 }

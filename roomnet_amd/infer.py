@@ -75,7 +75,7 @@ def _usable_cores():
 
 # Pillow releases the GIL inside the decoder, the array conversions around it do not: past ~64 threads the pool only queues on
 # the GIL (tools/bench_images.py --threads sweeps it; DESIGN.md section 5 has the figures of the GPU box's 256-thread host).
-DECODE_THREADS = max(1, min(64, _usable_cores()))
+DECODE_THREADS = max(1, min(16, _usable_cores()))
 
 
 def _infer_files(nn, fpaths, batch_size, decode_threads=None):

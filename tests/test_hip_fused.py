@@ -94,11 +94,15 @@ def test_stage0_is_exact_up_to_the_rounding_of_its_output(engine_stagewise, weig
     bad = np.abs(got - want) > bound
     assert not bad.any(), (int(bad.sum()), float(np.abs(got - want).max()), float(np.abs(want).max()))
 
-def _same_up_to_sum_order(a, b, dtype, what, frac=1e-5, n_ulp=2):
-    """Equal bit for bit -- except where the fp32 ORDER of the pooling sums shows through the 16-bit rounding: the fused
-    pair adds its fp16 window terms in 16x16x32 MFMAs, the stage kernels in 32x32x16 ones, and a sum of fp16 values of
-    very different magnitude is not exact in fp32.  Seen in ~1 of 4e7 values (one 16-bit ulp); downstream tensors inherit
-    it (`frac`, `n_ulp` wider there)."""
+def _same_up_to_sum_order(a, b, dtype, what, frac=1e-4, n_ulp=6):
+    """Equal up to the fp32 ORDER of sums, where it shows through the 16-bit rounding.  Two sources: (1) the fused pair adds
+    its fp16 pooling terms in 16x16x32 MFMAs, the stage kernels in 32x32x16 ones; (2) round 5: on the shipped checkpoint the
+    pair's second conv contracts 16 of the 32 channels of its input on the matrix cores and takes the other 16 -- FROZEN
+    channels, constants for every image (rn_fused_prepare proves it) -- as one per-cout constant summed on the host in double:
+    the same products, another summation order (and the channels sit in another order inside a tap).  Seen: 2-3e-5 of the
+    elements of s3.bn2 off by one 16-bit ulp (f16; bf16 5e-6), single elements near zero by up to 3 ulps of the 1 % floor;
+    downstream tensors inherit it (`frac`, `n_ulp` wider there).  The bound per element stays a few 16-bit ulps: a corrupted
+    tile is orders of magnitude outside it."""
     bad = a != b
     n = int(bad.sum())
     if n == 0:
@@ -115,7 +119,7 @@ def _same_up_to_sum_order(a, b, dtype, what, frac=1e-5, n_ulp=2):
 
 def _downstream_same(fused, plain, names, nb, dtype, probs_f, probs_p, ids_f, ids_p):
     for name in names:
-        _same_up_to_sum_order(fused.tap(name, nb), plain.tap(name, nb), dtype, name, frac=2e-3, n_ulp=4)
+        _same_up_to_sum_order(fused.tap(name, nb), plain.tap(name, nb), dtype, name, frac=3e-2, n_ulp=8)
     np.testing.assert_allclose(probs_f, probs_p, rtol=0, atol=2e-3)
     np.testing.assert_array_equal(ids_f, ids_p)
 
@@ -243,7 +247,7 @@ def test_one_launch_back_end_is_bit_identical_to_the_stage_launches(weights, par
         # another fp32 order than the per-stage launches (see _same_up_to_sum_order), so from s3.bn2 on the two handles agree up
         # to that -- 16-bit tensors within a few ulp on a few elements, the fp32 logits within the bound the probabilities get
         for name in ("s8.bn", "s9.bn2"):
-            _same_up_to_sum_order(taps_f[name], plain.tap(name, nb), dtype, name, frac=2e-3, n_ulp=4)
+            _same_up_to_sum_order(taps_f[name], plain.tap(name, nb), dtype, name, frac=3e-2, n_ulp=8)
         np.testing.assert_allclose(taps_f["d3.relu"], plain.tap("d3.relu", nb), rtol=0, atol=1e-2)
         np.testing.assert_allclose(probs_f, probs_p, rtol=0, atol=2e-3)
         np.testing.assert_array_equal(ids_f, ids_p)
@@ -804,3 +808,33 @@ def test_two_slot_pipeline_out_of_pinned_host_buffers(engine, parity_images):
     assert engine.lib.rn_host_free(None) == 0
     with pytest.raises(_capi.RoomNetLibraryError):
         _capi.PinnedArray((1 << 46,), np.uint8)                   # 64 TiB: the error convention, not an abort
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+def test_frozen_channels_fold_against_computing_them(weights, parity_images, dtype, record):
+    """Round 5: 16 of the 32 channels of the fused pair's on-chip tensor (stage 2's output) are FROZEN on the shipped checkpoint
+    -- the reference's L2 regulariser drove their BN gammas to ~1e-20, their stored 16-bit value is one number for every image,
+    which rn_create proves per channel -- so the default handle does not convolve them (RN_FLAG_COMPUTE_FROZEN: the arm that
+    does).  Both arms against each other at batch 1 / 8 / 160 (band decompositions, the one-launch back end) and against the
+    oracle through the shared parity tests; the probabilities agree far inside the parity tolerance."""
+    g = build_graph(6, 224)
+    for nb in (1, 8, 160):
+        pick = (np.arange(nb) * 5) % len(parity_images)
+        ims = parity_images[pick]
+        fold = _capi.Engine(g, weights, device=0, dtype=dtype, max_batch=nb)
+        full = _capi.Engine(g, weights, device=0, dtype=dtype, max_batch=nb, compute_frozen=True)
+        try:
+            ids_a, probs_a = fold.forward_u8(ims)
+            ids_b, probs_b = full.forward_u8(ims)
+            a, b = fold.tap("s3.bn2", nb), full.tap("s3.bn2", nb)
+            _same_up_to_sum_order(a, b, dtype, ("s3.bn2 folded vs computed", nb))
+            np.testing.assert_array_equal(fold.tap("s1.bn", nb), full.tap("s1.bn", nb))      # (in front of the pair: the same kernel)
+            np.testing.assert_allclose(probs_a, probs_b, rtol=0, atol=2e-3)
+            np.testing.assert_array_equal(ids_a, ids_b)
+            if nb == 160:
+                record("frozen_channel_fold", dtype, {"elements_differing_in_s3_bn2": int((a != b).sum()), "elements": int(a.size),
+                                                       "max_abs_diff_s3_bn2": float(np.abs(a - b).max()),
+                                                       "max_abs_dprob": float(np.abs(probs_a - probs_b).max())})
+        finally:
+            fold.close()
+            full.close()
