@@ -138,10 +138,11 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.rn_device_free.restype = i32
     lib.rn_memcpy_h2d.argtypes = [vp, vp, vp, sz]
     lib.rn_memcpy_h2d.restype = i32
-    lib.rn_host_alloc.argtypes = [sz, C.POINTER(vp)]
-    lib.rn_host_alloc.restype = i32
-    lib.rn_host_free.argtypes = [vp]
-    lib.rn_host_free.restype = i32
+    if hasattr(lib, "rn_host_alloc"):           # (absent from the older libraries tools/gpu_var.sh loads through ROOMNET_HIP_LIB as A/B arms)
+        lib.rn_host_alloc.argtypes = [sz, C.POINTER(vp)]
+        lib.rn_host_alloc.restype = i32
+        lib.rn_host_free.argtypes = [vp]
+        lib.rn_host_free.restype = i32
     lib.rn_memcpy_d2h.argtypes = [vp, vp, vp, sz]
     lib.rn_memcpy_d2h.restype = i32
     lib.rn_crop_resize_u8_device.argtypes = [vp, vp, i32, i32, vp, i32]

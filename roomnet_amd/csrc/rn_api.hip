@@ -885,6 +885,19 @@ extern "C" int rn_tap(rn_handle* h, int node_id, float* out, size_t cap_elems, s
             return rc;
         }
     }
+    // a handle may store this tensor with its channels relabelled (frozen-channel folding, rn_fused_prepare): hand it out in the
+    // reference's channel order
+    if (fused_mode(h)) {
+        if (const int* perm = rn_fused_node_perm(h, node_id)) {
+            const int c = nb.info.c;
+            std::vector<float> px(static_cast<size_t>(c));
+            for (size_t q = 0; q < total / static_cast<size_t>(c); ++q) {
+                float* pix = out + q * c;
+                for (int p = 0; p < c; ++p) px[perm[p]] = pix[p];
+                std::memcpy(pix, px.data(), static_cast<size_t>(c) * 4);
+            }
+        }
+    }
     return RN_OK;
 }
 

@@ -624,6 +624,11 @@ struct FusedState {
     bool pair_x16 = false;       // the pair runs on 16x16x32 tiles (rn_stage23x.hip) with the fragments below
     i32x4* pair_wfrag_a = nullptr;
     i32x4* pair_wfrag_b = nullptr;
+    // frozen first-BN channels of the 64 -> 64 residual stage (rn_fused_prepare): its index (or -1), the 16-cout quarters whose
+    // convolution still runs, and the channel relabelling of the tensors it touches (node id -> position p holds channel perm[p])
+    int fold5_stage = -1;
+    int fold5_live_q = 4;
+    std::map<int, std::vector<int>> node_perm;
     float* pair_ptab_x = nullptr;    // rn_stage23x.hip's table: pair_ptab with the first stage's channels in the B ring's order
     int pair_producer_halves = 2;    // 1: 16 channels of the pair's on-chip tensor are frozen and not computed (Stage23Args)
     int pair_frozen = 0;             // how many channels of it are frozen on this handle
@@ -639,12 +644,98 @@ void rn_fused_release(rn_handle* h) {
     h->fused = nullptr;
 }
 
-int rn_fused_prepare(rn_handle* h, const rn_weights* w) {
+int rn_fused_prepare(rn_handle* h, const rn_weights* w_in) {
     const int dti = h->dtype == RN_DTYPE_BF16 ? 0 : 1;
     (void)dti;
     auto* fs = new FusedState();
     fs->st.resize(h->stages.size());
     h->fused = fs;
+    // ---- frozen first-BN channels of a 64 -> 64 residual stage (stage 5 of the network; rn_stage5x.hip).  Its epilogue forms
+    // y1 = fma(H, sc1', sh1') with H = a pooled sum of ReLU6 / 6 values in [0, 16]: where |sc1'| * 16 < 2^-25 |sh1'| the fma
+    // returns sh1' EXACTLY in float32 for every input -- the channel's convolution cannot change a bit of the output (the
+    // reference's L2 regulariser drove 44 of the 64 gammas of the shipped checkpoint to ~1e-30).  With >= 32 such channels the
+    // channels of this stage's output are RELABELLED (a permutation of the weights of this stage, of the cout of the stage
+    // before -- whose output is this stage's input AND its skip tensor, paired channel by channel -- and of the cin of the stage
+    // behind) so that the last two 16-cout quarters are all frozen: their waves skip the convolution and its pooling.  The
+    // relabelling happens HERE, on a copy of the weight arrays, in front of everything else: every kernel family of every arm
+    // sees one consistent network; rn_tap puts the channels of the two affected tensors back in the reference's order.
+    std::vector<rn_conv_stage> stg(w_in->stages, w_in->stages + w_in->n_stages);
+    std::vector<std::vector<float>> owned;
+    rn_weights wp = *w_in;
+    wp.stages = stg.data();
+    const rn_weights* const w = &wp;
+    if (!(h->flags & (RN_FLAG_COMPUTE_FROZEN | RN_FLAG_GENERIC_KERNELS | RN_FLAG_PAIR_32X32))) {
+        for (int r = 2; r + 1 < w_in->n_stages; ++r) {
+            const rn_conv_stage& s5 = w_in->stages[r];
+            const rn_conv_stage& s4 = w_in->stages[r - 1];
+            const rn_conv_stage& s6 = w_in->stages[r + 1];
+            const StagePlan& p5 = h->stages[r];
+            if (!(s5.cin == 64 && s5.cout == 64 && s5.pool_k == 4 && s5.pool_s == 2 && s5.skip_stage == r - 1 && s5.gamma2 && s4.cout == 64 &&
+                  s4.skip_stage < 0 && s6.cin == 64 && s6.skip_stage < 0 &&
+                  rn_stage5x_supported(s5.cin, s5.cout, s5.pool_k, s5.pool_s, true, p5.in_side, p5.skip_side)))
+                continue;
+            bool other_use = false;          // nobody else may pair with the relabelled tensors
+            for (int k = 0; k < w_in->n_stages; ++k) other_use |= (k != r && w_in->stages[k].skip_stage == r - 1) || w_in->stages[k].skip_stage == r;
+            if (other_use) continue;
+            std::vector<int> frozen, live;
+            for (int c = 0; c < 64; ++c) {
+                // the table values exactly as the stage loop below builds them (float arithmetic, `sixth` weights)
+                const float inv = (1.0f / sqrtf(s5.variance[c] + w_in->bn_epsilon)) * s5.gamma[c];
+                float t0 = inv / 16.0f, t1 = s5.beta[c] - s5.mean[c] * inv;
+                const float inv2 = (1.0f / sqrtf(s5.variance2[c] + w_in->bn_epsilon)) * s5.gamma2[c];
+                const float sh2 = s5.beta2[c] - s5.mean2[c] * inv2;
+                t1 = t1 * inv2 + sh2;
+                t0 = t0 * inv2;
+                t0 *= 6.0f;
+                const bool fz = static_cast<double>(std::fabs(t0)) * 16.0 * (1.0 + 1e-6) < static_cast<double>(std::fabs(t1)) * 2.98023223876953125e-8;      // 2^-25
+                (fz ? frozen : live).push_back(c);
+            }
+            if (frozen.size() < 32) continue;
+            std::vector<int> pi(64);
+            while (frozen.size() > 32) {
+                live.push_back(frozen.back());
+                frozen.pop_back();
+            }
+            std::sort(live.begin(), live.end());
+            for (int p = 0; p < 32; ++p) pi[p] = live[p];
+            for (int p = 0; p < 32; ++p) pi[32 + p] = frozen[p];
+            auto perm_vec = [&](const float* src) -> const float* {
+                if (!src) return nullptr;
+                owned.emplace_back(64);
+                for (int p = 0; p < 64; ++p) owned.back()[p] = src[pi[p]];
+                return owned.back().data();
+            };
+            auto perm_kernel = [&](const float* src, int cin, int cout, bool pin, bool pout) -> const float* {
+                owned.emplace_back(static_cast<size_t>(9) * cin * cout);
+                std::vector<float>& dst = owned.back();
+                for (int tap = 0; tap < 9; ++tap)
+                    for (int ci = 0; ci < cin; ++ci)
+                        for (int co = 0; co < cout; ++co)
+                            dst[(static_cast<size_t>(tap) * cin + ci) * cout + co] = src[(static_cast<size_t>(tap) * cin + (pin ? pi[ci] : ci)) * cout + (pout ? pi[co] : co)];
+                return dst.data();
+            };
+            stg[r - 1].kernel = perm_kernel(s4.kernel, s4.cin, 64, false, true);
+            stg[r - 1].gamma = perm_vec(s4.gamma);
+            stg[r - 1].beta = perm_vec(s4.beta);
+            stg[r - 1].mean = perm_vec(s4.mean);
+            stg[r - 1].variance = perm_vec(s4.variance);
+            stg[r].kernel = perm_kernel(s5.kernel, 64, 64, true, true);
+            stg[r].gamma = perm_vec(s5.gamma);
+            stg[r].beta = perm_vec(s5.beta);
+            stg[r].mean = perm_vec(s5.mean);
+            stg[r].variance = perm_vec(s5.variance);
+            stg[r].gamma2 = perm_vec(s5.gamma2);
+            stg[r].beta2 = perm_vec(s5.beta2);
+            stg[r].mean2 = perm_vec(s5.mean2);
+            stg[r].variance2 = perm_vec(s5.variance2);
+            stg[r + 1].kernel = perm_kernel(s6.kernel, 64, s6.cout, true, false);
+            fs->fold5_stage = r;
+            fs->fold5_live_q = 2;
+            fs->node_perm[h->stages[r - 1].node_bn] = pi;
+            fs->node_perm[h->stages[r].node_bn2] = pi;
+            break;
+        }
+    }
     if (h->stages[0].cin != 3 || h->stages[0].cout != S0_CO || h->stages[0].pool_k != 3 ||
         h->stages[0].pool_s != 1 || h->stages[0].skip_stage >= 0) {
         rn_set_error("16-bit path: stage 0 must be conv(3->8) + pool 3/1 (got %d->%d pool %d/%d)", h->stages[0].cin,
@@ -1037,6 +1128,14 @@ int rn_fused_prepare(rn_handle* h, const rn_weights* w) {
     return RN_OK;
 }
 
+// channel relabelling of a tensor on this handle (position p of the stored tensor holds channel perm[p] of the reference's), or null
+const int* rn_fused_node_perm(const rn_handle* h, int node_id) {
+    const FusedState* fs = static_cast<const FusedState*>(h->fused);
+    if (!fs) return nullptr;
+    auto it = fs->node_perm.find(node_id);
+    return it == fs->node_perm.end() ? nullptr : it->second.data();
+}
+
 // true when the stage's output tensor is never written to HBM on this handle (it lives in LDS inside a fused launch)
 bool rn_fused_stage_elided(const rn_handle* h, int stage) {
     const FusedState* fs = static_cast<const FusedState*>(h->fused);
@@ -1322,6 +1421,7 @@ int rn_fused_forward(rn_handle* h, const uint8_t* d_bgr, const float* d_rgb, int
                 a.stamp_buf = rn_clock_region(what, static_cast<size_t>(a.n_bands) * a.n_cb * n);
             }
 #endif
+            a.live_q = (f.use_s5x && static_cast<int>(i) == fs->fold5_stage) ? fs->fold5_live_q : 4;
             int rc = f.use_s5x   ? rn_stage5x_launch(h->dtype, h->stream, a, n)
                      : f.use_s4x ? rn_stage4x_launch(h->dtype, h->stream, a, n)
                                  : rn_stage6x_launch(h->dtype, h->stream, a, n);

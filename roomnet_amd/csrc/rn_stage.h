@@ -264,6 +264,10 @@ struct StageArgs {
     // columns [cb_xo0[b], cb_xo0[b] + cb_wo[b]) and reads the input columns under them (+ halo).  n_cb == 1: whole rows.
     int n_cb;
     int cb_xo0[4], cb_wo[4];
+    // rn_stage5x.hip: 16-cout quarters whose convolution runs (0 or 4: all).  2: the channels of quarters 2 and 3 have a FROZEN
+    // first BN (rn_fused_prepare proves fma(H, sc1', sh1') == sh1' in float32 for every input and relabels the channels so);
+    // their waves skip the convolution and its pooling and interleave with the live quarters' waves on the SIMDs.
+    int live_q;
 };
 
 // Column-block plan of a row-blocked kernel: the fewest blocks (<= 4) of equal width +-1 whose widths lie in [wo_min, wo_max].

@@ -586,7 +586,8 @@ __global__ __launch_bounds__(512, 2) void stage23x_kernel(const Stage23Args a) {
             const float c = a.ptab[160 + 8 * (px16 >> 2) + 4 * h + (px16 & 3)];       // D'[pixel][cout]: column px16 of half h
             cinit[h] = f32x4{c, c, c, c};
         }
-        for (int i = tid; i < X_NB * X_ROWB_N / 16; i += 512) *reinterpret_cast<i32x4*>(ringB + i * 16) = i32x4{0, 0, 0, 0};
+        // (the ring's unwritten columns feed zero-weight K slots: they must be finite.  Consumer waves only: threads 256 .. 511)
+        for (int i = tid - 256; i < X_NB * X_ROWB_N / 16; i += 256) *reinterpret_cast<i32x4*>(ringB + i * 16) = i32x4{0, 0, 0, 0};
     }
     // output stores: tile k = 1024 bytes further (immediate); a lane stores while its column lies left of the wave's limit
     // for that tile: lim(k) = columns of tile k this wave owns (13 in its last tile, cut at the next wave's start / the row end)

@@ -67,7 +67,13 @@ __global__ __launch_bounds__(512, 2) void stage5x_kernel(const StageArgs a) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int cq = wave & 3, ph = wave >> 2;              // cout quarter / pixel half: waves w and w + 4 share a SIMD (4 + 3 tiles)
+    // cout quarter / pixel half.  All quarters live: waves w and w + 4 (one SIMD) are the two pixel halves of quarter w (4 + 3
+    // tiles).  Two live quarters (StageArgs::live_q): waves 0..3 = the live (quarter, half) units, one per SIMD, waves 4..7 =
+    // the frozen quarters' units, whose step is the residual epilogue only.
+    const bool fold = a.live_q == 2;
+    const int cq = fold ? (wave < 4 ? (wave >> 1) : 2 + ((wave - 4) >> 1)) : (wave & 3);
+    const int ph = fold ? (wave & 1) : (wave >> 2);
+    const bool conv_live = !fold || cq < 2;
     const int px16 = lane & 15, g = lane >> 4;
     const int cb = blockIdx.x % a.n_cb, band = blockIdx.x / a.n_cb, n = blockIdx.y;
     const int Win = a.W, Wo_full = a.Wo, Ho = a.Ho;
@@ -105,7 +111,7 @@ __global__ __launch_bounds__(512, 2) void stage5x_kernel(const StageArgs a) {
     i32x4 wf[18];
 #pragma unroll
     for (int f = 0; f < 18; ++f) {
-        const i32x4* src = a.wfrag + (f * 4 + cq) * 64 + lane;
+        const i32x4* src = a.wfrag + (f * 4 + cq) * 64 + lane;      // (frozen quarters: loaded, never used)
         asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(wf[f]) : "v"(src) : "memory");
     }
 
@@ -305,17 +311,19 @@ __global__ __launch_bounds__(512, 2) void stage5x_kernel(const StageArgs a) {
                 pp2[k][1] = n1;
             }
         };
-        reads(IC<0>{});
-        tile(IC<0>{}, IC<0>{});
-        finish(IC<0>{});
-        tile(IC<1>{}, IC<0>{});
-        finish(IC<1>{});
-        tile(IC<2>{}, IC<1>{});
-        finish(IC<2>{});
-        if (has4) {                       // (the fourth tile's first reads stay behind the branch)
-            reads(IC<6>{});
-            tile(IC<3>{}, IC<1>{});
-            finish(IC<3>{});
+        if (conv_live) {                  // (wave-uniform)
+            reads(IC<0>{});
+            tile(IC<0>{}, IC<0>{});
+            finish(IC<0>{});
+            tile(IC<1>{}, IC<0>{});
+            finish(IC<1>{});
+            tile(IC<2>{}, IC<1>{});
+            finish(IC<2>{});
+            if (has4) {                   // (the fourth tile's first reads stay behind the branch)
+                reads(IC<6>{});
+                tile(IC<3>{}, IC<1>{});
+                finish(IC<3>{});
+            }
         }
         if constexpr (PAR == 1) {
             // odd conv row j = s - 2 >= 3 completes pooled row r = (j - 3) / 2
@@ -349,9 +357,12 @@ __global__ __launch_bounds__(512, 2) void stage5x_kernel(const StageArgs a) {
                         asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(tq[0][kh][t2]) : "v"(alo));
                         asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(tq[1][kh][t2]) : "v"(ahi));
                     }
-                f32x4 H = mfma16<RN_DTYPE_F16>(op[2 * u], pmA, zero4);
-                H = mfma16<RN_DTYPE_F16>(op[2 * u + 1], pmB, H);
-                if (u == 0) H = mfma16<RN_DTYPE_F16>(op[2], pmC, H);
+                f32x4 H = zero4;           // frozen quarters: fma(H, sc1, sh1) = sh1 for every H the convolution can produce
+                if (conv_live) {
+                    H = mfma16<RN_DTYPE_F16>(op[2 * u], pmA, zero4);
+                    H = mfma16<RN_DTYPE_F16>(op[2 * u + 1], pmB, H);
+                    if (u == 0) H = mfma16<RN_DTYPE_F16>(op[2], pmC, H);
+                }
                 asm volatile("s_waitcnt lgkmcnt(0)"
                              : "+v"(tq[0][0][0]), "+v"(tq[0][0][1]), "+v"(tq[0][1][0]), "+v"(tq[0][1][1]), "+v"(tq[1][0][0]), "+v"(tq[1][0][1]),
                                "+v"(tq[1][1][0]), "+v"(tq[1][1][1]));

@@ -119,7 +119,10 @@ def _same_up_to_sum_order(a, b, dtype, what, frac=1e-4, n_ulp=6):
 
 def _downstream_same(fused, plain, names, nb, dtype, probs_f, probs_p, ids_f, ids_p):
     for name in names:
-        _same_up_to_sum_order(fused.tap(name, nb), plain.tap(name, nb), dtype, name, frac=3e-2, n_ulp=8)
+        if name.startswith("d"):              # the fp32 logits: every element moves a little, none by much
+            np.testing.assert_allclose(fused.tap(name, nb), plain.tap(name, nb), rtol=0, atol=1e-2, err_msg=name)
+            continue
+        _same_up_to_sum_order(fused.tap(name, nb), plain.tap(name, nb), dtype, name, frac=6e-2, n_ulp=8)
     np.testing.assert_allclose(probs_f, probs_p, rtol=0, atol=2e-3)
     np.testing.assert_array_equal(ids_f, ids_p)
 
@@ -829,6 +832,10 @@ def test_frozen_channels_fold_against_computing_them(weights, parity_images, dty
             a, b = fold.tap("s3.bn2", nb), full.tap("s3.bn2", nb)
             _same_up_to_sum_order(a, b, dtype, ("s3.bn2 folded vs computed", nb))
             np.testing.assert_array_equal(fold.tap("s1.bn", nb), full.tap("s1.bn", nb))      # (in front of the pair: the same kernel)
+            # stage 5's frozen quarters: its 44 frozen first-BN channels are not convolved and the channels of s4.bn / s5.bn2 are
+            # stored relabelled -- rn_tap hands them out in the reference's order (a wrong relabelling would be off by O(1))
+            _same_up_to_sum_order(fold.tap("s4.bn", nb), full.tap("s4.bn", nb), dtype, ("s4.bn folded vs computed", nb), frac=1e-2, n_ulp=8)
+            _same_up_to_sum_order(fold.tap("s5.bn2", nb), full.tap("s5.bn2", nb), dtype, ("s5.bn2 folded vs computed", nb), frac=3e-2, n_ulp=16)
             np.testing.assert_allclose(probs_a, probs_b, rtol=0, atol=2e-3)
             np.testing.assert_array_equal(ids_a, ids_b)
             if nb == 160:
