@@ -278,6 +278,7 @@ def main():
                     help="one launch per conv stage (RN_FLAG_STAGE_LAUNCHES): the unfused comparison arm")
     ap.add_argument("--compute-frozen", action="store_true",
                     help="RN_FLAG_COMPUTE_FROZEN: convolve the channels rn_create proves constant too (the comparison arm: same bits)")
+    ap.add_argument("--no-unfolded-arm", action="store_true", help="skip the RN_FLAG_COMPUTE_FROZEN comparison pass")
     ap.add_argument("--stub-engine", action="store_true", help=argparse.SUPPRESS)    # CPU tensors + gloo (tests)
     ap.add_argument("--force-collective", action="store_true",
                     help="run the N > 1 code path (RCCL process group, per-step all-gather, barriers, gathered-block check) "
@@ -481,6 +482,30 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # ---- the comparison arm of the frozen-channel folding, in the same run: a handle that convolves the provably constant
+    # channels too (RN_FLAG_COMPUTE_FROZEN), W warm-up + K timed steps, this rank only -> `folding.images_per_sec_computing_them`
+    fold_info, unfolded_rate = None, None
+    if not stub and args.dtype != "f32":
+        fold_info = eng.frozen_info()
+        folded = fold_info["pair_channels_not_convolved"] > 0 or fold_info["residual_stage_folded"] >= 0
+        if folded and not args.no_unfolded_arm and rank == 0:
+            e2 = _capi.Engine(graph, weights, device=local_rank, dtype=args.dtype, max_batch=B,
+                              stage_launches=args.stage_launches, pair32=args.pair32, compute_frozen=True)
+            e2.set_stream(stream.cuda_stream)
+            with on_stream():
+                for _ in range(args.warmup):
+                    e2.forward_u8_device(ims.data_ptr(), B, bufs[0][1].data_ptr(), bufs[0][2].data_ptr())
+                torch.cuda.synchronize()
+                t2 = time.perf_counter()
+                for _ in range(args.steps):
+                    e2.forward_u8_device(ims.data_ptr(), B, bufs[0][1].data_ptr(), bufs[0][2].data_ptr())
+                torch.cuda.synchronize()
+                unfolded_rate = B * args.steps / (time.perf_counter() - t2)
+            e2.close()
+            with on_stream():
+                forward(0)                       # (the sanity check below reads this handle's results)
+            torch.cuda.synchronize()
+
     # sanity: outputs are a distribution and an argmax of it; every rank's gathered block carries that rank's results
     if not args.no_parity_check:
         for k in range(2 if n_steps_done[0] > 1 else 1):
@@ -586,6 +611,12 @@ def main():
                        "images_per_gpu": B, "global_batch": world * B, "im_side": args.side,
                        "parallelism": "dp%d" % world},
             "parity": parity, "spinup_steps": spinup_steps, "handles": len(engs),
+            "folding": None if fold_info is None else dict(
+                fold_info, what="rn_create proves channels constant for EVERY input (BN gammas the reference's L2 regulariser drove to "
+                                "1e-20 .. 1e-30: the fma that applies them returns its addend bit for bit) and does not convolve them; "
+                                "`value` is this default handle; images_per_sec_computing_them = the same run on a handle that computes "
+                                "every channel (RN_FLAG_COMPUTE_FROZEN), one rank, W + K steps",
+                images_per_sec_computing_them=unfolded_rate),
             "untimed_steps_before_value": (args.warmup + args.steps if cold_elapsed is not None else 0) + spinup_steps + args.warmup,
         }
         if cold_elapsed is not None:

@@ -36,7 +36,7 @@ EXPORTED_SYMBOLS = (
     "rn_forward_u8", "rn_submit_u8", "rn_collect", "rn_forward_f32", "rn_forward_u8_device", "rn_forward_f32_device", "rn_sync",
     "rn_set_stream", "rn_set_stream_null", "rn_node_count", "rn_node_info_get", "rn_tap", "rn_set_profiling", "rn_timing",
     "rn_dominant_stage", "rn_stage_launch", "rn_device_malloc", "rn_device_free", "rn_memcpy_h2d", "rn_memcpy_d2h",
-    "rn_crop_resize_u8_device", "rn_classify_images_u8", "rn_host_alloc", "rn_host_free",
+    "rn_crop_resize_u8_device", "rn_classify_images_u8", "rn_host_alloc", "rn_host_free", "rn_frozen_info",
     "rn_group_create", "rn_group_destroy", "rn_group_size", "rn_group_handle", "rn_group_forward_u8",
     "rn_group_forward_u8_device", "rn_group_result_buffer", "rn_group_sync",
 )
@@ -138,6 +138,9 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.rn_device_free.restype = i32
     lib.rn_memcpy_h2d.argtypes = [vp, vp, vp, sz]
     lib.rn_memcpy_h2d.restype = i32
+    if hasattr(lib, "rn_frozen_info"):
+        lib.rn_frozen_info.argtypes = [vp, C.POINTER(C.c_int)]
+        lib.rn_frozen_info.restype = i32
     if hasattr(lib, "rn_host_alloc"):           # (absent from the older libraries tools/gpu_var.sh loads through ROOMNET_HIP_LIB as A/B arms)
         lib.rn_host_alloc.argtypes = [sz, C.POINTER(vp)]
         lib.rn_host_alloc.restype = i32
@@ -423,6 +426,15 @@ class Engine:
         if h == 1 and w == 1:
             return out.reshape(n, c)
         return out
+
+    def frozen_info(self) -> Dict[str, int]:
+        """What rn_create folded on this handle (``rn_frozen_info``): channels of the fused pair's on-chip tensor that are
+        provably constant and not convolved, how many were proven, the residual stage whose frozen first-BN channels are
+        folded and how many of its 16-cout quarters still run their convolution."""
+        info = (C.c_int * 4)()
+        _check(self.lib, self.lib.rn_frozen_info(self.handle, info), "rn_frozen_info")
+        return {"pair_channels_not_convolved": info[0], "pair_channels_proven_frozen": info[1], "residual_stage_folded": info[2],
+                "residual_stage_live_quarters": info[3]}
 
     def set_profiling(self, enable: bool) -> None:
         _check(self.lib, self.lib.rn_set_profiling(self.handle, 1 if enable else 0), "rn_set_profiling")

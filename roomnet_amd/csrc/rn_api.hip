@@ -1024,3 +1024,15 @@ extern "C" int rn_host_free(void* ptr) {
     RN_HIP(hipHostFree(ptr));
     return RN_OK;
 }
+
+extern "C" int rn_frozen_info(const rn_handle* h, int info[4]) {
+    if (!h || !info) {
+        rn_set_error("rn_frozen_info: bad argument");
+        return RN_E_INVALID;
+    }
+    info[0] = info[1] = 0;
+    info[2] = -1;
+    info[3] = 4;
+    if (fused_mode(h)) rn_fused_frozen_info(h, info);
+    return RN_OK;
+}

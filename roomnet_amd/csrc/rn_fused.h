@@ -16,6 +16,7 @@ int rn_fused_launch_rep(const rn_handle* h, int stage);
 bool rn_fused_stage_elided(const rn_handle* h, int stage);
 // channel relabelling of a node's stored tensor on this handle (position p holds the reference's channel perm[p]), or null
 const int* rn_fused_node_perm(const rn_handle* h, int node_id);
+void rn_fused_frozen_info(const rn_handle* h, int info[4]);
 // head launcher shared with the unfused path (defined in rn_api.hip)
 int rn_run_head(rn_handle* h, int n, float* d_probs, int64_t* d_ids);
 void rn_record_event(rn_handle* h, int idx);

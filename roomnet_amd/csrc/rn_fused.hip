@@ -1006,20 +1006,19 @@ int rn_fused_prepare(rn_handle* h, const rn_weights* w_in) {
             fs->pair_first = static_cast<int>(i);
             if (!(h->flags & RN_FLAG_PAIR_32X32)) {
                 // ---- frozen channels of the pair's on-chip tensor B (the first stage's output).  The epilogue stores
-                // to16(fma(H, sc, sh)) with H = a sum of 16 ReLU6 / 6 values in [0, 16]: when |sc| * 16 is so small that every
-                // value of [sh - d, sh + d] rounds to the SAME 16-bit number, the channel is that constant whatever the image --
-                // in this kernel's arithmetic bit for bit, and (d < 1e-10 of an O(1) tensor) in the reference's float32 too.
-                // The shipped checkpoint has 18 such channels of 32 (its L2 regulariser drove their BN gamma to ~1e-20): with
-                // >= 16 of them the first conv computes half of its couts.  perm[p] = the channel at B-ring position p; the
-                // positions (p & 7) >= 4 -- the second half of every 8-cout group -- take frozen channels.
+                // to16(fma(H, sc, sh)) with H = a sum of 16 ReLU6 / 6 values in [0, 16]: where |sc| * 16 < 2^-25 |sh| the fma
+                // returns sh EXACTLY in float32 for every H the convolution can produce -- the channel is the constant to16(sh)
+                // whatever the image, in this kernel's arithmetic bit for bit (and to 1e-10 of an O(1) tensor in the reference's
+                // float32, where the same product vanishes against the same addend).  The shipped checkpoint has 18 such channels
+                // of 32 (its L2 regulariser drove their BN gamma to ~1e-20): with >= 16 of them the first conv computes half of
+                // its couts.  perm[p] = the channel at B-ring position p; the positions (p & 7) >= 4 -- the second half of every
+                // 8-cout group -- take frozen channels.
                 int perm[32];
                 {
                     std::vector<int> frozen, live;
                     for (int c = 0; c < 32; ++c) {
                         const double sc = t1[c], sh = t1[32 + c];
-                        const double d = std::fabs(sc) * 16.0 * (1.0 + 1e-6);      // (fma and conversion round monotonically)
-                        const auto cv = [&](double v) { return h->dtype == RN_DTYPE_BF16 ? f32_to_bf16(static_cast<float>(v)) : f32_to_f16(static_cast<float>(v)); };
-                        const bool fz = d < 1e-10 && cv(sh - d) == cv(sh + d) && cv(sh - d) == cv(sh);
+                        const bool fz = std::fabs(sc) * 16.0 * (1.0 + 1e-6) < std::fabs(sh) * 2.98023223876953125e-8;      // 2^-25
                         (fz ? frozen : live).push_back(c);
                     }
                     fs->pair_frozen = static_cast<int>(frozen.size());
@@ -1126,6 +1125,18 @@ int rn_fused_prepare(rn_handle* h, const rn_weights* w_in) {
     if (fs->use_tail) fs->launch_rep[h->stages.size() - 2] = static_cast<int>(h->stages.size()) - 1;
     if (fs->pair_first >= 0) fs->launch_rep[fs->pair_first] = fs->pair_first + 1;
     return RN_OK;
+}
+
+void rn_fused_frozen_info(const rn_handle* h, int info[4]) {
+    const FusedState* fs = static_cast<const FusedState*>(h->fused);
+    info[0] = info[1] = 0;
+    info[2] = -1;
+    info[3] = 4;
+    if (!fs) return;
+    info[0] = fs->pair_x16 && fs->pair_producer_halves == 1 ? 16 : 0;
+    info[1] = fs->pair_frozen;
+    info[2] = fs->fold5_stage;
+    info[3] = fs->fold5_stage >= 0 ? fs->fold5_live_q : 4;
 }
 
 // channel relabelling of a tensor on this handle (position p of the stored tensor holds channel perm[p] of the reference's), or null

@@ -135,3 +135,26 @@ def test_600_variant_golden(weights):
     im = parity_set_of(600)[i:i + 1]
     rc = c_oracle.infer(w, im)
     np.testing.assert_allclose(rc["logits"], g["logits_f64"][1:2], atol=TOL_LOGITS_F32, rtol=0)
+
+
+def test_frozen_channels_are_constants_in_the_oracle_too(weights, parity_images):
+    """Round 5 folds channels that rn_create proves constant (roomnet_amd/csrc/rn_fused.hip): the first BN of stage 2 (the fused
+    pair's on-chip tensor) and of stage 5.  The proof is about the HIP kernels' own fma; this test pins the claim it rests on to
+    the ORACLE: in the float32 restatement of the reference's ops the same channels hold one value for every pixel of every
+    image -- their BN gamma (1e-20 .. 1e-30, the work of the reference's L2 regulariser, train.py) times anything a pooled ReLU6
+    can be vanishes against beta.  Criterion as in rn_fused_prepare: |gamma * rsqrt(var + eps)| * 6 < 2^-25 |beta - mean * inv|."""
+    ims = parity_images[[3, 14, 22, 37, 44, 60]]
+    ref = c_oracle.infer(weights, ims, taps=True)
+    found = {}
+    for bn_index, node in ((2, "s2.bn"), (6, "s5.bn")):
+        n = "batch_normalization_%d" % bn_index
+        inv = (1.0 / np.sqrt(weights[n + "/moving_variance"] + np.float32(1e-3))).astype(np.float32) * weights[n + "/gamma"]
+        sh = weights[n + "/beta"] - weights[n + "/moving_mean"] * inv
+        frozen = np.abs(inv.astype(np.float64)) * 6.0 * (1 + 1e-6) < np.abs(sh.astype(np.float64)) * 2.0 ** -25
+        tap = np.asarray(ref["taps"][node])
+        flat = tap.reshape(-1, tap.shape[-1])
+        spread = flat.max(0) - flat.min(0)
+        assert (spread[frozen] == 0).all(), (node, spread[frozen].max())
+        assert (spread[~frozen] > 0).any(), node            # (the criterion is conservative: more channels sit still on these images)
+        found[node] = int(frozen.sum())
+    assert found["s2.bn"] >= 16 and found["s5.bn"] >= 32, found      # what lets stage 2 compute half its couts / stage 5 two quarters
