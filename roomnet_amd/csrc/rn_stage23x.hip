@@ -893,8 +893,8 @@ int rn_stage23x_launch(int dtype, hipStream_t s, const Stage23Args& a, int n) {
         return launch(stage23x_kernel<RN_DTYPE_F16, 1, true>);
     }
     if (a.producer_halves == 1) {
-        if (dtype == RN_DTYPE_BF16) return launch(stage23x_kernel<RN_DTYPE_BF16, 1, false>);
-        return launch(stage23x_kernel<RN_DTYPE_F16, 1, false>);
+        rn_set_error("stage23x: producer_halves == 1 runs in the narrow form only");
+        return RN_E_STATE;
     }
     if (dtype == RN_DTYPE_BF16) return launch(stage23x_kernel<RN_DTYPE_BF16, 2, false>);
     return launch(stage23x_kernel<RN_DTYPE_F16, 2, false>);
