@@ -431,8 +431,9 @@ class Engine:
         """What rn_create folded on this handle (``rn_frozen_info``): channels of the fused pair's on-chip tensor that are
         provably constant and not convolved, how many were proven, the residual stage whose frozen first-BN channels are
         folded and how many of its 16-cout quarters still run their convolution."""
-        info = (C.c_int * 4)()
-        _check(self.lib, self.lib.rn_frozen_info(self.handle, info), "rn_frozen_info")
+        info = (C.c_int * 4)(0, 0, -1, 4)
+        if hasattr(self.lib, "rn_frozen_info"):      # (older libraries loaded as A/B arms fold nothing)
+            _check(self.lib, self.lib.rn_frozen_info(self.handle, info), "rn_frozen_info")
         return {"pair_channels_not_convolved": info[0], "pair_channels_proven_frozen": info[1], "residual_stage_folded": info[2],
                 "residual_stage_live_quarters": info[3]}
 

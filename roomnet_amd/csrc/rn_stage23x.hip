@@ -303,8 +303,8 @@ __global__ __launch_bounds__(512, 2) void stage23x_kernel(const Stage23Args a) {
             const int xo = xw + 16 * k + px16;
             const bool last = k == (has4 ? 3 : 2);
             const int col = (xo < Wb && !(last && px16 >= 13) && (k < 3 || has4)) ? xo : X_BDUMMY;
-            if constexpr (NB)       // 8 bytes (the lane's 4 computed couts) at 8 g of the 32-byte pixel; 16-byte chunks XOR bit 3 of the column
-                wbB[k] = ringB_lds + static_cast<unsigned>(col * 32 + ((((g >> 1) ^ ((col >> 3) & 1)) << 4) | ((g & 1) << 3)));
+            if constexpr (NB)       // 8 bytes (the lane's 4 computed couts) at 8 g of the 32-byte pixel (no swizzle: see baseN)
+                wbB[k] = ringB_lds + static_cast<unsigned>(col * 32 + 8 * g);
             else
                 wbB[k] = ringB_lds + static_cast<unsigned>(col * 64 + ((g ^ swzx(col)) << 4));
         }
@@ -579,7 +579,11 @@ __global__ __launch_bounds__(512, 2) void stage23x_kernel(const Stage23Args a) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int p = xw + px16 + 2 * j + (g >> 1);
-            baseN[j] = ringB_lds + static_cast<unsigned>(p * 32 + (((g & 1) ^ ((p >> 3) & 1)) << 4));
+            // plain layout: ds_read_b128's four lane groups ({0-3, 12-15, 20-27}, ...: MI355X_MICROARCH.md) take the even 16-byte
+            // slots of eight pixels from the g = 0 / 2 lanes and the odd slots of the other eight from g = 1 / 3 -- 16 distinct
+            // slots of the 256-byte bank row at every alignment (an XOR of the chunk with bit 3 of the pixel made it 2-way: 30 %
+            // conflict cycles, profiles/r5_b_sq_summary.txt)
+            baseN[j] = ringB_lds + static_cast<unsigned>(p * 32 + ((g & 1) << 4));
         }
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
