@@ -4,6 +4,7 @@
 #include "rn_internal.h"
 #include "rn_fused.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 #include <new>
@@ -493,7 +494,92 @@ extern "C" int rn_create(const rn_weights* w, int device, int dtype, int max_bat
         return fail(RN_E_HIP);
     }
     h->stream = h->own_stream;
+    // ---- float32 handles on the matrix-core path: frozen first-BN channels of a 64 -> 64 residual stage (stage 5).  The stage
+    // kernels form y1 = ((x * 1/16 - mean) * inv + beta) un-contracted: where |inv| * max(|mean|, |6 - mean|) < 2^-25 |beta| the
+    // product vanishes against beta and y1 IS beta for every input (the reference's float32 computes the same expression).  With
+    // >= 32 such channels the stage's channels are relabelled on a copy of the weights (stage 4's couts, stage 5's cins + couts,
+    // stage 6's cins: the residual pairs channel c of stage 4's output with channel c of stage 5's) so that the second 32-cout
+    // tile is all frozen: it is not convolved (rn_f32m_launch runs the residual for it alone).  rn_tap un-relabels.
+    std::vector<rn_conv_stage> stg_copy;
+    std::vector<std::vector<float>> owned;
+    rn_weights wp;
+    std::vector<int> fold_pi;
+    int fold_r = -1;
+    if (!fused_mode(h) && !(flags & (RN_FLAG_TAPS | RN_FLAG_COMPUTE_FROZEN))) {
+        for (int r = 2; r + 1 < w->n_stages && fold_r < 0; ++r) {
+            const rn_conv_stage& s5 = w->stages[r];
+            const rn_conv_stage& s4 = w->stages[r - 1];
+            const rn_conv_stage& s6 = w->stages[r + 1];
+            if (!(s5.cin == 64 && s5.cout == 64 && s5.pool_k == 4 && s5.pool_s == 2 && s5.skip_stage == r - 1 && s5.gamma2 && s4.cout == 64 &&
+                  s4.skip_stage < 0 && s6.cin == 64 && s6.skip_stage < 0 && s5.gamma && s5.beta && s5.mean && s5.variance))
+                continue;
+            bool other_use = false;
+            for (int k = 0; k < w->n_stages; ++k) other_use |= (k != r && w->stages[k].skip_stage == r - 1) || w->stages[k].skip_stage == r;
+            if (other_use) continue;
+            std::vector<int> frozen, live;
+            for (int c = 0; c < 64; ++c) {
+                const float inv = (1.0f / sqrtf(s5.variance[c] + w->bn_epsilon)) * s5.gamma[c];
+                const double reach = std::max(std::fabs(static_cast<double>(s5.mean[c])), std::fabs(6.0 - static_cast<double>(s5.mean[c])));
+                const bool fz = std::fabs(static_cast<double>(inv)) * reach * (1.0 + 1e-6) < std::fabs(static_cast<double>(s5.beta[c])) * 2.98023223876953125e-8;
+                (fz ? frozen : live).push_back(c);
+            }
+            if (frozen.size() < 32) continue;
+            while (frozen.size() > 32) {
+                live.push_back(frozen.back());
+                frozen.pop_back();
+            }
+            std::sort(live.begin(), live.end());
+            fold_pi.resize(64);
+            for (int p = 0; p < 32; ++p) fold_pi[p] = live[p];
+            for (int p = 0; p < 32; ++p) fold_pi[32 + p] = frozen[p];
+            fold_r = r;
+        }
+        if (fold_r >= 0) {
+            const std::vector<int>& pi = fold_pi;
+            stg_copy.assign(w->stages, w->stages + w->n_stages);
+            auto perm_vec = [&](const float* src) -> const float* {
+                owned.emplace_back(64);
+                for (int p = 0; p < 64; ++p) owned.back()[p] = src[pi[p]];
+                return owned.back().data();
+            };
+            auto perm_kernel = [&](const float* src, int cin, int cout, bool pin, bool pout) -> const float* {
+                owned.emplace_back(static_cast<size_t>(9) * cin * cout);
+                std::vector<float>& dst = owned.back();
+                for (int tap = 0; tap < 9; ++tap)
+                    for (int ci = 0; ci < cin; ++ci)
+                        for (int co = 0; co < cout; ++co)
+                            dst[(static_cast<size_t>(tap) * cin + ci) * cout + co] = src[(static_cast<size_t>(tap) * cin + (pin ? pi[ci] : ci)) * cout + (pout ? pi[co] : co)];
+                return dst.data();
+            };
+            const int r = fold_r;
+            const rn_conv_stage s4 = w->stages[r - 1], s5 = w->stages[r], s6 = w->stages[r + 1];
+            stg_copy[r - 1].kernel = perm_kernel(s4.kernel, s4.cin, 64, false, true);
+            stg_copy[r - 1].gamma = perm_vec(s4.gamma);
+            stg_copy[r - 1].beta = perm_vec(s4.beta);
+            stg_copy[r - 1].mean = perm_vec(s4.mean);
+            stg_copy[r - 1].variance = perm_vec(s4.variance);
+            stg_copy[r].kernel = perm_kernel(s5.kernel, 64, 64, true, true);
+            stg_copy[r].gamma = perm_vec(s5.gamma);
+            stg_copy[r].beta = perm_vec(s5.beta);
+            stg_copy[r].mean = perm_vec(s5.mean);
+            stg_copy[r].variance = perm_vec(s5.variance);
+            stg_copy[r].gamma2 = perm_vec(s5.gamma2);
+            stg_copy[r].beta2 = perm_vec(s5.beta2);
+            stg_copy[r].mean2 = perm_vec(s5.mean2);
+            stg_copy[r].variance2 = perm_vec(s5.variance2);
+            stg_copy[r + 1].kernel = perm_kernel(s6.kernel, 64, s6.cout, true, false);
+            wp = *w;
+            wp.stages = stg_copy.data();
+            w = &wp;
+        }
+    }
     if ((rc = build_plan(h, w)) != RN_OK) return fail(rc);
+    if (fold_r >= 0) {
+        h->f32_fold_stage = fold_r;
+        h->f32_fold_live = 32;
+        h->node_perm[h->stages[fold_r - 1].node_bn] = fold_pi;
+        h->node_perm[h->stages[fold_r].node_bn2] = fold_pi;
+    }
     // uint8 -> float32 table, evaluated in float64 like the reference's NumPy expression
     {
         float lut[256];
@@ -887,8 +973,13 @@ extern "C" int rn_tap(rn_handle* h, int node_id, float* out, size_t cap_elems, s
     }
     // a handle may store this tensor with its channels relabelled (frozen-channel folding, rn_fused_prepare): hand it out in the
     // reference's channel order
-    if (fused_mode(h)) {
-        if (const int* perm = rn_fused_node_perm(h, node_id)) {
+    {
+        const int* perm = fused_mode(h) ? rn_fused_node_perm(h, node_id) : nullptr;
+        if (!perm) {
+            auto it = h->node_perm.find(node_id);
+            if (it != h->node_perm.end()) perm = it->second.data();
+        }
+        if (perm) {
             const int c = nb.info.c;
             std::vector<float> px(static_cast<size_t>(c));
             for (size_t q = 0; q < total / static_cast<size_t>(c); ++q) {
@@ -1033,6 +1124,11 @@ extern "C" int rn_frozen_info(const rn_handle* h, int info[4]) {
     info[0] = info[1] = 0;
     info[2] = -1;
     info[3] = 4;
-    if (fused_mode(h)) rn_fused_frozen_info(h, info);
+    if (fused_mode(h)) {
+        rn_fused_frozen_info(h, info);
+    } else if (h->f32_fold_stage >= 0 && rn_f32m_covers(h, h->f32_fold_stage)) {
+        info[2] = h->f32_fold_stage;
+        info[3] = h->f32_fold_live / 16;
+    }
     return RN_OK;
 }

@@ -4,6 +4,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdarg>
+#include <map>
 #include <string>
 #include <vector>
 
@@ -114,6 +115,11 @@ struct rn_handle {
     std::vector<void*> allocs;   // everything to hipFree on destroy
     void* fused = nullptr;       // plan of the fused 16-bit path (rn_fused.hip)
     void* f32m = nullptr;        // plan of the float32 matrix-core stage kernels (rn_stage_f32m.hip)
+    // float32 handles: frozen first-BN channels of the 64 -> 64 residual stage folded (rn_create): the stage's index (or -1), the
+    // couts whose convolution still runs, and the relabelling of the tensors it touches (node id -> position p holds channel perm[p])
+    int f32_fold_stage = -1;
+    int f32_fold_live = 0;
+    std::map<int, std::vector<int>> node_perm;
     // profiling
     bool profiling = false;
     std::vector<hipEvent_t> events;   // [0]=start, [1]=after preprocess, [2+i]=after stage i, last=after head

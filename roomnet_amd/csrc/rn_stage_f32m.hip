@@ -487,6 +487,39 @@ __global__ __launch_bounds__(576) void stage_f32m16_kernel(const F32StageArgs a)
     }
 }
 
+// The residual epilogue ALONE for the couts of a residual stage whose first BN is frozen (rn_create: y1 = beta for every input):
+// out = BN2(beta + legacy-bilinear(skip)), the expressions of stage_f32m_kernel's epilogue un-contracted; one thread = 4 couts of
+// one output pixel.
+__global__ __launch_bounds__(256) void f32_frozen_residual_kernel(const float* __restrict__ skip, float* __restrict__ out, const float* bn_beta,
+                                                                  const float* bn2_mean, const float* bn2_inv, const float* bn2_beta, const int32_t* rlo,
+                                                                  const int32_t* rhi, const float* rlerp, int64_t n_pix, int Ho, int Wo, int Ss, int cout,
+                                                                  int c_begin, int c_count) {
+    const int groups = c_count / 4;
+    const int64_t idx = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+    if (idx >= n_pix * groups) return;
+    const int64_t p = idx / groups;
+    const int c0 = c_begin + 4 * static_cast<int>(idx % groups);
+    const int xo = static_cast<int>(p % Wo), yo = static_cast<int>((p / Wo) % Ho);
+    const int64_t n = p / (static_cast<int64_t>(Wo) * Ho);
+    const float xl = rlerp[xo], yl = rlerp[yo];
+    const float* skn = skip + n * Ss * Ss * cout;
+    const float* sk0 = skn + static_cast<int64_t>(rlo[yo]) * Ss * cout;
+    const float* sk1 = skn + static_cast<int64_t>(rhi[yo]) * Ss * cout;
+    const f32x4 tl = *reinterpret_cast<const f32x4*>(sk0 + rlo[xo] * cout + c0), tr = *reinterpret_cast<const f32x4*>(sk0 + rhi[xo] * cout + c0);
+    const f32x4 bl = *reinterpret_cast<const f32x4*>(sk1 + rlo[xo] * cout + c0), br = *reinterpret_cast<const f32x4*>(sk1 + rhi[xo] * cout + c0);
+    const f32x4 beta = *reinterpret_cast<const f32x4*>(bn_beta + c0), m2 = *reinterpret_cast<const f32x4*>(bn2_mean + c0),
+                i2 = *reinterpret_cast<const f32x4*>(bn2_inv + c0), b2 = *reinterpret_cast<const f32x4*>(bn2_beta + c0);
+    f32x4 y;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float top = __fadd_rn(tl[j], __fmul_rn(__fsub_rn(tr[j], tl[j]), xl));
+        const float bot = __fadd_rn(bl[j], __fmul_rn(__fsub_rn(br[j], bl[j]), xl));
+        const float rs = __fadd_rn(top, __fmul_rn(__fsub_rn(bot, top), yl));
+        y[j] = __fadd_rn(__fmul_rn(__fsub_rn(__fadd_rn(beta[j], rs), m2[j]), i2[j]), b2[j]);
+    }
+    *reinterpret_cast<f32x4*>(out + p * cout + c0) = y;
+}
+
 struct F32mStage {
     bool on = false;
     bool m16 = false;             // stage_f32m16_kernel (16 couts): ks / lpt16 below
@@ -692,9 +725,13 @@ int rn_f32m_launch(rn_handle* h, int stage, const float* in, int n) {
     a.ringcols = f.ringcols;
     a.n_colblocks = f.n_colblocks;
     a.n_ctg = f.n_ctg;
+    // frozen cout tiles of this stage (rn_create proved y1 = beta for their channels and relabelled them to the end): not convolved
+    const bool fold = !f.m16 && stage == h->f32_fold_stage && s.skip_stage >= 0 && h->f32_fold_live > 0 && h->f32_fold_live < s.cout &&
+                      h->f32_fold_live % 32 == 0;
+    if (fold) a.n_ctg = h->f32_fold_live / 32;
     // bands: whole rounds of the chip (one workgroup per CU: the weights and the ring fill most of its LDS); a band costs its
     // rows plus the rows its neighbour reads again
-    const long per_band = static_cast<long>(n) * f.n_colblocks * f.n_ctg;
+    const long per_band = static_cast<long>(n) * f.n_colblocks * a.n_ctg;
     const int rows_in = s.pool_k ? s.pool_s : 1, overlap = s.pool_k ? 5 : 2;
     const int max_bands = std::max(1, s.out_side / 4);
     int bands = 1;
@@ -715,5 +752,13 @@ int rn_f32m_launch(rn_handle* h, int stage, const float* in, int n) {
     else
         kF32Variants[f.variant].fn(a, dim3(a.n_bands * a.n_colblocks * a.n_ctg, n), dim3(64 * f.npt * kF32Variants[f.variant].ks), f.lds, h->stream);
     RN_CHECK_LAUNCH();
+    if (fold) {
+        const int c_begin = h->f32_fold_live, c_count = s.cout - c_begin;
+        const int64_t n_pix = static_cast<int64_t>(n) * s.out_side * s.out_side;
+        const int64_t threads = n_pix * (c_count / 4);
+        hipLaunchKernelGGL(f32_frozen_residual_kernel, dim3(static_cast<unsigned>((threads + 255) / 256)), dim3(256), 0, h->stream, a.skip, a.out, a.bn_beta,
+                           a.bn2_mean, a.bn2_inv, a.bn2_beta, a.rlo, a.rhi, a.rlerp, n_pix, s.out_side, s.out_side, s.skip_side, s.cout, c_begin, c_count);
+        RN_CHECK_LAUNCH();
+    }
     return RN_OK;
 }
