@@ -485,7 +485,7 @@ def main():
     # ---- the comparison arm of the frozen-channel folding, in the same run: a handle that convolves the provably constant
     # channels too (RN_FLAG_COMPUTE_FROZEN), W warm-up + K timed steps, this rank only -> `folding.images_per_sec_computing_them`
     fold_info, unfolded_rate = None, None
-    if not stub and args.dtype != "f32":
+    if not stub:
         fold_info = eng.frozen_info()
         folded = fold_info["pair_channels_not_convolved"] > 0 or fold_info["residual_stage_folded"] >= 0
         if folded and not args.no_unfolded_arm and rank == 0:

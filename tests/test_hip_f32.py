@@ -266,3 +266,29 @@ def test_matrix_core_f32_at_other_input_sides(weights, side):
     finally:
         mm.close()
         pn.close()
+
+
+def test_matrix_core_f32_folds_stage_5_frozen_channels(weights, parity_images):
+    """Round 5: 44 of the 64 first-BN channels of stage 5 are frozen on the shipped checkpoint (y1 = ((x/16 - mean) * inv + beta) IS
+    beta for every input: the reference's float32 computes the same expression); the default float32 handle relabels the
+    stage's channels so that its second 32-cout tile is all frozen and does not convolve it (rn_create, rn_f32m_launch).  Against
+    the handle that computes everything (RN_FLAG_COMPUTE_FROZEN): the frozen channels contribute the same bits, the live ones
+    differ by the order of the K sum only (the relabelling permutes the input channels)."""
+    g = build_graph(6, 224)
+    fold = _capi.Engine(g, weights, device=0, dtype="f32", max_batch=8)
+    full = _capi.Engine(g, weights, device=0, dtype="f32", max_batch=8, compute_frozen=True)
+    try:
+        assert fold.frozen_info()["residual_stage_folded"] == 5 and fold.frozen_info()["residual_stage_live_quarters"] == 2
+        assert full.frozen_info()["residual_stage_folded"] == -1
+        ims = parity_images[[3, 14, 22, 37, 44, 52, 56, 60]]
+        ids_a, probs_a = fold.forward_u8(ims)
+        ids_b, probs_b = full.forward_u8(ims)
+        np.testing.assert_array_equal(fold.tap("s4.bn", 8), full.tap("s4.bn", 8))          # (relabelled in HBM, handed out in order)
+        for name in ("s5.bn2", "s6.bn", "s9.bn2"):
+            a, b = fold.tap(name, 8), full.tap(name, 8)
+            assert float(np.abs(a - b).max()) <= 2e-5 * float(np.abs(b).max()), name
+        np.testing.assert_allclose(probs_a, probs_b, rtol=0, atol=5e-6)          # (fp32 K-sum order; the oracle tolerance is 1e-5)
+        np.testing.assert_array_equal(ids_a, ids_b)
+    finally:
+        fold.close()
+        full.close()
