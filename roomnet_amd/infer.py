@@ -21,7 +21,7 @@ import shutil
 import numpy as np
 
 from . import xls
-from .imageio import imread, imwrite, put_text
+from .imageio import decode_to_shm, imread, imwrite, put_text
 from .imageops import resize_linear_u8
 from .network import RoomNet
 
@@ -80,75 +80,22 @@ DECODE_THREADS = max(1, min(16, _usable_cores()))
 
 # Process pool for long file lists: a decode in its own interpreter holds nobody's GIL.  A worker decodes into a shared-memory
 # block and returns its name; the parent maps it (no copy, no pickle of megabytes) and unlinks it once the batch is through.
-# Workers are fresh interpreters started with subprocess (roomnet_amd/decode_worker.py): nothing of the parent's HIP state is
-# forked and the caller's __main__ is not imported a second time.
+# Workers are SPAWNED (a fresh interpreter that imports roomnet_amd.imageio only): nothing of the parent's HIP state is forked.
 DECODE_PROCESSES = max(0, min(32, _usable_cores() // 2))       # 0: threads only
 DECODE_PROCESS_MIN_FILES = 96                                   # shorter lists do not pay for starting the workers
 _POOL = None
-
-
-class _DecodeWorkers:
-    """`n` worker interpreters (`python -m roomnet_amd.decode_worker`, started with subprocess) fed round-robin; every worker
-    answers in the order it was asked, so the k-th task given to worker w is the k-th line on its stdout."""
-
-    def __init__(self, n):
-        import subprocess
-        import sys
-        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-        env = dict(os.environ)
-        env["PYTHONPATH"] = root + (os.pathsep + env["PYTHONPATH"] if env.get("PYTHONPATH") else "")
-        env.setdefault("OMP_NUM_THREADS", "1")
-        self.n = n
-        self.procs = [subprocess.Popen([sys.executable, "-m", "roomnet_amd.decode_worker"], stdin=subprocess.PIPE, stdout=subprocess.PIPE,
-                                       env=env, text=True, bufsize=1) for _ in range(n)]
-        self.next = 0
-
-    def submit(self, path):
-        import json
-        w = self.next
-        self.next = (self.next + 1) % self.n
-        p = self.procs[w]
-        p.stdin.write(json.dumps(path) + "\n")
-        p.stdin.flush()
-        return _WorkerResult(p)
-
-    def close(self):
-        for p in self.procs:
-            try:
-                p.stdin.close()
-            except Exception:
-                pass
-        for p in self.procs:
-            try:
-                p.wait(timeout=5)
-            except Exception:
-                p.kill()
-        self.procs = []
-
-
-class _WorkerResult:
-    def __init__(self, proc):
-        self.proc = proc
-
-    def result(self):
-        line = self.proc.stdout.readline()
-        if not line:
-            raise RuntimeError("a decode worker ended unexpectedly (exit code %s)" % self.proc.poll())
-        line = line.strip()
-        if line == "-":
-            return None
-        name, h, w, c = line.split()
-        return name, (int(h), int(w), int(c))
 
 
 def _process_pool(nproc):
     global _POOL
     if _POOL is None or _POOL[1] != nproc:
         import atexit
+        import multiprocessing
+        from concurrent.futures import ProcessPoolExecutor
         if _POOL is not None:
-            _POOL[0].close()
-        _POOL = (_DecodeWorkers(nproc), nproc)
-        atexit.register(lambda ex=_POOL[0]: ex.close())
+            _POOL[0].shutdown(wait=False, cancel_futures=True)
+        _POOL = (ProcessPoolExecutor(max_workers=nproc, mp_context=multiprocessing.get_context("spawn")), nproc)
+        atexit.register(lambda ex=_POOL[0]: ex.shutdown(wait=False, cancel_futures=True))
     return _POOL[0]
 
 
@@ -173,7 +120,7 @@ class _ShmImage:
 
 def _infer_files(nn, fpaths, batch_size, decode_threads=None, decode_processes=None):
     """Yield ``(index, image_bgr, idx, conf)`` per readable file, in list order.  Files are decoded ahead of the GPU (up to
-    two batches): on a process pool when the list is long (``DECODE_PROCESSES`` worker interpreters, images handed over in
+    two batches): on a process pool when the list is long (``DECODE_PROCESSES`` spawned workers, images handed over in
     shared memory), else on a small thread pool (Pillow releases the GIL while it decodes); the GPU gets the decoded images
     in batches of ``batch_size``.  A yielded image is valid until the next one is requested."""
     from collections import deque
@@ -211,7 +158,7 @@ def _infer_files(nn, fpaths, batch_size, decode_threads=None, decode_processes=N
                 nxt = next(todo, None)
                 if nxt is None:
                     return
-                inflight.append((nxt[0], nxt[1], pool.submit(nxt[1]) if use_procs else pool.submit(imread, nxt[1])))
+                inflight.append((nxt[0], nxt[1], pool.submit(decode_to_shm if use_procs else imread, nxt[1])))
         top_up()
         batch_shm = []
         while inflight:
