@@ -36,25 +36,6 @@ def imread(path: str) -> Optional[np.ndarray]:
     return np.ascontiguousarray(rgb[:, :, ::-1])
 
 
-def decode_to_shm(path):
-    """Worker of the directory drivers' process pool (roomnet_amd/infer.py): decode ``path`` into a shared-memory block ->
-    (block name, shape), or None for an unreadable file.  Lives here so that a spawned worker imports this light module only."""
-    from multiprocessing import resource_tracker, shared_memory
-    im = imread(path)
-    if im is None:
-        return None
-    shm = shared_memory.SharedMemory(create=True, size=max(1, im.nbytes))
-    np.ndarray(im.shape, np.uint8, buffer=shm.buf)[...] = im
-    name = shm.name
-    shm.close()
-    try:                       # the PARENT unlinks the block: this process's tracker must not (Python <= 3.12 registers on create)
-        resource_tracker.unregister("/" + name if not name.startswith("/") else name, "shared_memory")
-    except Exception:
-        pass
-    return name, im.shape
-
-
-
 def imwrite(path: str, im_bgr: np.ndarray) -> bool:
     """``cv2.imwrite``: format from the extension (JPEG quality 95 like OpenCV's default)."""
     from PIL import Image

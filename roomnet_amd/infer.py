@@ -21,7 +21,7 @@ import shutil
 import numpy as np
 
 from . import xls
-from .imageio import decode_to_shm, imread, imwrite, put_text
+from .imageio import imread, imwrite, put_text
 from .imageops import resize_linear_u8
 from .network import RoomNet
 
@@ -78,55 +78,13 @@ def _usable_cores():
 DECODE_THREADS = max(1, min(16, _usable_cores()))
 
 
-# Process pool for long file lists: a decode in its own interpreter holds nobody's GIL.  A worker decodes into a shared-memory
-# block and returns its name; the parent maps it (no copy, no pickle of megabytes) and unlinks it once the batch is through.
-# Workers are SPAWNED (a fresh interpreter that imports roomnet_amd.imageio only): nothing of the parent's HIP state is forked.
-DECODE_PROCESSES = max(0, min(32, _usable_cores() // 2))       # 0: threads only
-DECODE_PROCESS_MIN_FILES = 96                                   # shorter lists do not pay for starting the workers
-_POOL = None
-
-
-def _process_pool(nproc):
-    global _POOL
-    if _POOL is None or _POOL[1] != nproc:
-        import atexit
-        import multiprocessing
-        from concurrent.futures import ProcessPoolExecutor
-        if _POOL is not None:
-            _POOL[0].shutdown(wait=False, cancel_futures=True)
-        _POOL = (ProcessPoolExecutor(max_workers=nproc, mp_context=multiprocessing.get_context("spawn")), nproc)
-        atexit.register(lambda ex=_POOL[0]: ex.shutdown(wait=False, cancel_futures=True))
-    return _POOL[0]
-
-
-class _ShmImage:
-    """A decoded image living in a worker's shared-memory block; ``release()`` unmaps and unlinks it."""
-
-    def __init__(self, name, shape):
-        from multiprocessing import shared_memory
-        self.shm = shared_memory.SharedMemory(name=name)
-        self.array = np.ndarray(shape, np.uint8, buffer=self.shm.buf)
-
-    def release(self):
-        if self.shm is not None:
-            self.array = None
-            try:
-                self.shm.close()
-                self.shm.unlink()
-            except Exception:
-                pass
-            self.shm = None
-
-
-def _infer_files(nn, fpaths, batch_size, decode_threads=None, decode_processes=None):
-    """Yield ``(index, image_bgr, idx, conf)`` per readable file, in list order.  Files are decoded ahead of the GPU (up to
-    two batches): on a process pool when the list is long (``DECODE_PROCESSES`` spawned workers, images handed over in
-    shared memory), else on a small thread pool (Pillow releases the GIL while it decodes); the GPU gets the decoded images
-    in batches of ``batch_size``.  A yielded image is valid until the next one is requested."""
+def _infer_files(nn, fpaths, batch_size, decode_threads=None):
+    """Yield ``(index, image_bgr, idx, conf)`` per readable file, in list order.  Files are decoded on a small thread
+    pool (Pillow releases the GIL while it decodes) that runs up to two batches ahead of the GPU; the GPU gets the
+    decoded images in batches of ``batch_size``."""
     from collections import deque
     from concurrent.futures import ThreadPoolExecutor
     pending = []
-    held = []                # shared-memory images of the batch that is being yielded
 
     def flush():
         if not pending:
@@ -139,67 +97,32 @@ def _infer_files(nn, fpaths, batch_size, decode_threads=None, decode_processes=N
         pending.clear()
         return res
 
-    def release_held():
-        for h in held:
-            h.release()
-        held.clear()
-
-    nproc = DECODE_PROCESSES if decode_processes is None else int(decode_processes)
-    use_procs = nproc > 0 and (decode_processes is not None or len(fpaths) >= DECODE_PROCESS_MIN_FILES)
     nthreads = max(1, int(decode_threads or DECODE_THREADS))
-    window = max(2 * batch_size, nproc if use_procs else nthreads)
+    window = max(2 * batch_size, nthreads)
     todo = iter(enumerate(fpaths))
     inflight = deque()
-    pool_cm = None if use_procs else ThreadPoolExecutor(max_workers=nthreads)
-    pool = _process_pool(nproc) if use_procs else pool_cm
-    try:
+    with ThreadPoolExecutor(max_workers=nthreads) as pool:
         def top_up():
             while len(inflight) < window:
                 nxt = next(todo, None)
                 if nxt is None:
                     return
-                inflight.append((nxt[0], nxt[1], pool.submit(decode_to_shm if use_procs else imread, nxt[1])))
+                inflight.append((nxt[0], nxt[1], pool.submit(imread, nxt[1])))
         top_up()
-        batch_shm = []
         while inflight:
             i, fpath, fut = inflight.popleft()
-            got = fut.result()
+            im = fut.result()
             top_up()
-            if got is None:
+            if im is None:
                 # the reference crashes here (cv2.imread returns None, infer.py:81-82); report and go on
                 print(fpath, '---> unreadable image, skipped')
                 continue
-            if use_procs:
-                im_h = _ShmImage(*got)
-                batch_shm.append(im_h)
-                im = im_h.array
-            else:
-                im = got
             pending.append((i, im))
             if len(pending) >= batch_size:
-                out = flush()
-                release_held()
-                held.extend(batch_shm)
-                batch_shm = []
-                for r in out:
+                for r in flush():
                     yield r
-        out = flush()
-        release_held()
-        held.extend(batch_shm)
-        for r in out:
+        for r in flush():
             yield r
-    finally:
-        release_held()
-        while inflight:                                   # (generator closed early: free what the workers already produced)
-            _i, _p, fut = inflight.popleft()
-            try:
-                got = fut.result() if use_procs else None
-                if got is not None:
-                    _ShmImage(*got).release()
-            except Exception:
-                pass
-        if pool_cm is not None:
-            pool_cm.shutdown(wait=True)
 
 
 def groundtruth_validation(nn, list_fpath=None, batch_size=64):

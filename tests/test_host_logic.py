@@ -338,21 +338,7 @@ def test_infer_files_decodes_on_a_pool_and_keeps_list_order(tmp_path, capsys):
         paths.append(str(p))
     for bs, threads in ((3, 4), (64, 1)):
         Stub.batches = []
-        got = [(i, idx) for i, _im, idx, _conf in _infer_files(Stub(), paths, bs, decode_threads=threads, decode_processes=0)]
+        got = [(i, idx) for i, _im, idx, _conf in _infer_files(Stub(), paths, bs, decode_threads=threads)]
         assert got == want
         assert Stub.batches == ([3, 3, 3] if bs == 3 else [9])
     assert capsys.readouterr().out.count("unreadable image, skipped") == 4
-    # the process pool (spawned workers, images handed over in shared memory): the same results, and nothing left in /dev/shm
-    import glob
-    before = set(glob.glob("/dev/shm/psm_*"))
-    Stub.batches = []
-    seen = []
-    for i, im, idx, _conf in _infer_files(Stub(), paths, 4, decode_processes=2):
-        seen.append((i, idx))
-        assert im.dtype == np.uint8 and im.ndim == 3 and im.flags.writeable       # (the overlay draws into it)
-    assert seen == want and Stub.batches == [4, 4, 1]
-    gen = _infer_files(Stub(), paths, 4, decode_processes=2)                      # a consumer that stops early leaks nothing either
-    next(gen)
-    gen.close()
-    assert set(glob.glob("/dev/shm/psm_*")) <= before
-    assert capsys.readouterr().out.count("unreadable image, skipped") >= 2

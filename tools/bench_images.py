@@ -2,7 +2,7 @@
 
   python tools/bench_images.py [H W [N]]          N decoded images of one size (decode excluded):
         host centre-crop + resize (roomnet_amd.imageops) + rn_forward_u8   vs   rn_classify_images_u8 (crop + resize on the GPU)
-  python tools/bench_images.py --dir [--threads=T] [--procs=P] [H W [N]]    a generated directory of N JPEG files of that size through
+  python tools/bench_images.py --dir [--threads=T] [H W [N]]    a generated directory of N JPEG files of that size through
         classify_im_dir(overlay=False) and groundtruth_validation (decode on the thread pool, crop + resize + forward on
         the GPU), next to decode alone and to the one-image-at-a-time loop of the reference's caller (infer.py:79-82)
 """
@@ -22,12 +22,10 @@ from roomnet_amd.graph import build_graph
 from roomnet_amd.imageops import resize_linear_u8
 from roomnet_amd.tf_bundle import BundleReader
 
-THREADS = PROCS = None
+THREADS = None
 for _a in sys.argv[1:]:
     if _a.startswith('--threads='):
         THREADS = int(_a.split('=', 1)[1])          # decode threads of the directory drivers (default: infer.DECODE_THREADS)
-    if _a.startswith('--procs='):
-        PROCS = int(_a.split('=', 1)[1])            # decode processes (default: infer.DECODE_PROCESSES; 0 = threads only)
 args = [a for a in sys.argv[1:] if not a.startswith('--')]
 H = int(args[0]) if len(args) > 0 else 1080
 W = int(args[1]) if len(args) > 1 else 1920
@@ -64,8 +62,6 @@ def directory():
     from roomnet_amd.network import RoomNet
     if THREADS:
         infer.DECODE_THREADS = THREADS
-    if PROCS is not None:
-        infer.DECODE_PROCESSES = PROCS
     root = tempfile.mkdtemp(prefix='rn_bench_')
     d = os.path.join(root, 'images')
     os.makedirs(d)
@@ -102,9 +98,9 @@ def directory():
         for p in paths[:max(8, N // 8)]:
             nn.infer_optimized(imageio.imread(p))
         t_one = (time.perf_counter() - t0) / max(8, N // 8)
-    print('%d JPEG files %dx%d (%.0f MB), %d decode processes / %d decode threads of %d host cores: classify_im_dir(overlay=False) %.1f img/s   '
+    print('%d JPEG files %dx%d (%.0f MB), %d decode threads of %d host cores: classify_im_dir(overlay=False) %.1f img/s   '
           'groundtruth_validation %.1f img/s   decode alone, one thread %.1f img/s   one image per call (reference loop) %.1f img/s'
-          % (N, W, H, mb, infer.DECODE_PROCESSES, infer.DECODE_THREADS, os.cpu_count() or 1, N / t_dir, N / t_val, N / t_dec1, 1.0 / t_one))
+          % (N, W, H, mb, infer.DECODE_THREADS, os.cpu_count() or 1, N / t_dir, N / t_val, N / t_dec1, 1.0 / t_one))
     shutil.rmtree(root, ignore_errors=True)
 
 
