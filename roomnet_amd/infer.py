@@ -73,8 +73,9 @@ def _usable_cores():
         return os.cpu_count() or 1
 
 
-# Pillow releases the GIL inside the decoder, the array conversions around it do not: past ~64 threads the pool only queues on
-# the GIL (tools/bench_images.py --threads sweeps it; DESIGN.md section 5 has the figures of the GPU box's 256-thread host).
+# Pillow releases the GIL inside the decoder and imread's channel swap does too; past 16-32 threads the pool levels off on the
+# page faults of its fresh 6-8 MB buffers (tools/bench_images.py --threads and tools/bench_decode.py sweep it: 16 is the optimum for
+# VGA files, 32 is 13 % better for 1080p; DESIGN.md section 5 has the figures of the GPU box's 256-thread host).
 DECODE_THREADS = max(1, min(16, _usable_cores()))
 
 

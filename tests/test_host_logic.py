@@ -109,6 +109,30 @@ def test_imread_imwrite_bgr_round_trip(tmp_path):
     assert imageio.imwrite(jp, im) and imageio.imread(jp).shape == im.shape
 
 
+def test_imread_zero_copy_pixel_export_equals_the_plain_path(tmp_path, monkeypatch):
+    """imread takes the pixels through Pillow's Arrow export when it can (no GIL-held copy) and through np.asarray otherwise:
+    the same array either way, writable and contiguous (the overlay draws into it), also for an odd width."""
+    from PIL import Image
+    rng = np.random.default_rng(11)
+    for k, (h, w) in enumerate([(37, 53), (480, 640), (1, 1)]):
+        im = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        p = str(tmp_path / ("z%d.png" % k))
+        assert imageio.imwrite(p, im)
+        with Image.open(p) as pim:
+            pim.load()
+            view = imageio._pixels_zero_copy(pim)
+            if hasattr(pim, "__arrow_c_array__") and imageio._pa:
+                assert view is not None and view.shape == (h, w, 4)
+                np.testing.assert_array_equal(view[:, :, :3], np.asarray(pim))
+        fast = imageio.imread(p)
+        monkeypatch.setattr(imageio, "_pixels_zero_copy", lambda im_: None)
+        plain = imageio.imread(p)
+        monkeypatch.undo()
+        np.testing.assert_array_equal(fast, im)
+        np.testing.assert_array_equal(plain, im)
+        assert fast.flags.c_contiguous and fast.flags.writeable and fast.dtype == np.uint8
+
+
 def test_put_text_draws_in_the_requested_colour():
     im = np.zeros((720, 1280, 3), np.uint8)
     imageio.put_text(im, "Predicted Class: Kitchen", (640, 648), (720 / 720.) * .85, (0, 255, 0))
