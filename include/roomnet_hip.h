@@ -232,10 +232,12 @@ RN_API int rn_set_stream_null(rn_handle* h);
  * 16-bit handles never materialise it.  Asking for a node that was not written
  * returns RN_E_STATE.  This is the per-layer
  * debug read-out the reference gets from self.layers (network.py:30, :207). */
-/* What rn_create folded on this handle (16-bit handles; all zero / -1 otherwise): info[0] = channels of the fused pair's on-chip
- * tensor that are NOT convolved because they are provably constant (16 or 0), info[1] = how many of its 32 channels were proven
- * so, info[2] = index of the 64 -> 64 residual stage whose frozen first-BN channels are folded (or -1), info[3] = 16-cout
- * quarters of that stage whose convolution still runs (4 = all).  RN_FLAG_COMPUTE_FROZEN handles report nothing folded. */
+/* What rn_create folded on this handle (zero / -1 where nothing is): info[0] = channels of the first 32 -> 32 stage's output
+ * (16-bit handles: the fused pair's on-chip tensor) that are provably constant and therefore not convolved (16-bit) / not
+ * contracted by the next stage (float32 matrix-core handles) (16 or 0), info[1] = how many of its 32 channels were proven so,
+ * info[2] = index of the 64 -> 64 residual stage whose frozen first-BN channels are folded (or -1), info[3] = 16-cout
+ * quarters of that stage whose convolution still runs (4 = all).  RN_FLAG_COMPUTE_FROZEN and RN_FLAG_TAPS handles report
+ * nothing folded. */
 RN_API int rn_frozen_info(const rn_handle* h, int info[4]);
 RN_API int rn_node_count(const rn_handle* h);
 RN_API int rn_node_info_get(const rn_handle* h, int node_id, rn_node_info* out);

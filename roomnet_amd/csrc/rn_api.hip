@@ -503,8 +503,8 @@ extern "C" int rn_create(const rn_weights* w, int device, int dtype, int max_bat
     std::vector<rn_conv_stage> stg_copy;
     std::vector<std::vector<float>> owned;
     rn_weights wp;
-    std::vector<int> fold_pi;
-    int fold_r = -1;
+    std::vector<int> fold_pi, kfold_pi;
+    int fold_r = -1, kfold_r = -1, kfold_live = 0, kfold_proven = 0;
     if (!fused_mode(h) && !(flags & (RN_FLAG_TAPS | RN_FLAG_COMPUTE_FROZEN))) {
         for (int r = 2; r + 1 < w->n_stages && fold_r < 0; ++r) {
             const rn_conv_stage& s5 = w->stages[r];
@@ -534,43 +534,93 @@ extern "C" int rn_create(const rn_weights* w, int device, int dtype, int max_bat
             for (int p = 0; p < 32; ++p) fold_pi[32 + p] = frozen[p];
             fold_r = r;
         }
-        if (fold_r >= 0) {
-            const std::vector<int>& pi = fold_pi;
+        auto ensure_copy = [&]() {
+            if (!stg_copy.empty()) return;
             stg_copy.assign(w->stages, w->stages + w->n_stages);
-            auto perm_vec = [&](const float* src) -> const float* {
-                owned.emplace_back(64);
-                for (int p = 0; p < 64; ++p) owned.back()[p] = src[pi[p]];
-                return owned.back().data();
-            };
-            auto perm_kernel = [&](const float* src, int cin, int cout, bool pin, bool pout) -> const float* {
-                owned.emplace_back(static_cast<size_t>(9) * cin * cout);
-                std::vector<float>& dst = owned.back();
-                for (int tap = 0; tap < 9; ++tap)
-                    for (int ci = 0; ci < cin; ++ci)
-                        for (int co = 0; co < cout; ++co)
-                            dst[(static_cast<size_t>(tap) * cin + ci) * cout + co] = src[(static_cast<size_t>(tap) * cin + (pin ? pi[ci] : ci)) * cout + (pout ? pi[co] : co)];
-                return dst.data();
-            };
-            const int r = fold_r;
-            const rn_conv_stage s4 = w->stages[r - 1], s5 = w->stages[r], s6 = w->stages[r + 1];
-            stg_copy[r - 1].kernel = perm_kernel(s4.kernel, s4.cin, 64, false, true);
-            stg_copy[r - 1].gamma = perm_vec(s4.gamma);
-            stg_copy[r - 1].beta = perm_vec(s4.beta);
-            stg_copy[r - 1].mean = perm_vec(s4.mean);
-            stg_copy[r - 1].variance = perm_vec(s4.variance);
-            stg_copy[r].kernel = perm_kernel(s5.kernel, 64, 64, true, true);
-            stg_copy[r].gamma = perm_vec(s5.gamma);
-            stg_copy[r].beta = perm_vec(s5.beta);
-            stg_copy[r].mean = perm_vec(s5.mean);
-            stg_copy[r].variance = perm_vec(s5.variance);
-            stg_copy[r].gamma2 = perm_vec(s5.gamma2);
-            stg_copy[r].beta2 = perm_vec(s5.beta2);
-            stg_copy[r].mean2 = perm_vec(s5.mean2);
-            stg_copy[r].variance2 = perm_vec(s5.variance2);
-            stg_copy[r + 1].kernel = perm_kernel(s6.kernel, 64, s6.cout, true, false);
             wp = *w;
             wp.stages = stg_copy.data();
             w = &wp;
+        };
+        auto perm_vec = [&](const std::vector<int>& pi, const float* src) -> const float* {
+            owned.emplace_back(pi.size());
+            for (size_t p = 0; p < pi.size(); ++p) owned.back()[p] = src[pi[p]];
+            return owned.back().data();
+        };
+        auto perm_kernel = [&](const std::vector<int>& pi, const float* src, int cin, int cout, bool pin, bool pout) -> const float* {
+            owned.emplace_back(static_cast<size_t>(9) * cin * cout);
+            std::vector<float>& dst = owned.back();
+            for (int tap = 0; tap < 9; ++tap)
+                for (int ci = 0; ci < cin; ++ci)
+                    for (int co = 0; co < cout; ++co)
+                        dst[(static_cast<size_t>(tap) * cin + ci) * cout + co] = src[(static_cast<size_t>(tap) * cin + (pin ? pi[ci] : ci)) * cout + (pout ? pi[co] : co)];
+            return dst.data();
+        };
+        auto bn1_frozen = [&](const rn_conv_stage& st, int c) {
+            const float inv = (1.0f / sqrtf(st.variance[c] + w->bn_epsilon)) * st.gamma[c];
+            const double reach = std::max(std::fabs(static_cast<double>(st.mean[c])), std::fabs(6.0 - static_cast<double>(st.mean[c])));
+            return std::fabs(static_cast<double>(inv)) * reach * (1.0 + 1e-6) < std::fabs(static_cast<double>(st.beta[c])) * 2.98023223876953125e-8;
+        };
+        if (fold_r >= 0) {
+            const std::vector<int>& pi = fold_pi;
+            ensure_copy();
+            const int r = fold_r;
+            const rn_conv_stage s4 = stg_copy[r - 1], s5 = stg_copy[r], s6 = stg_copy[r + 1];
+            stg_copy[r - 1].kernel = perm_kernel(pi, s4.kernel, s4.cin, 64, false, true);
+            stg_copy[r - 1].gamma = perm_vec(pi, s4.gamma);
+            stg_copy[r - 1].beta = perm_vec(pi, s4.beta);
+            stg_copy[r - 1].mean = perm_vec(pi, s4.mean);
+            stg_copy[r - 1].variance = perm_vec(pi, s4.variance);
+            stg_copy[r].kernel = perm_kernel(pi, s5.kernel, 64, 64, true, true);
+            stg_copy[r].gamma = perm_vec(pi, s5.gamma);
+            stg_copy[r].beta = perm_vec(pi, s5.beta);
+            stg_copy[r].mean = perm_vec(pi, s5.mean);
+            stg_copy[r].variance = perm_vec(pi, s5.variance);
+            stg_copy[r].gamma2 = perm_vec(pi, s5.gamma2);
+            stg_copy[r].beta2 = perm_vec(pi, s5.beta2);
+            stg_copy[r].mean2 = perm_vec(pi, s5.mean2);
+            stg_copy[r].variance2 = perm_vec(pi, s5.variance2);
+            stg_copy[r + 1].kernel = perm_kernel(pi, s6.kernel, 64, s6.cout, true, false);
+        }
+        // ---- ... and frozen INPUT channels: a pooled stage p without a second BN whose output only feeds the convolution of stage
+        // p + 1 (nobody's residual) and whose BN freezes >= 8 channels (same inequality).  Its couts / the consumer's cins are
+        // relabelled so that the last 8 k channels are all frozen; the consumer contracts the others and starts its accumulators
+        // from the frozen ones' contribution (rn_f32m_prepare: a variant of the stage kernel must exist for that channel count)
+        for (int r = 1; r < w->n_stages && kfold_r < 0; ++r) {
+            const int p = r - 1;
+            const rn_conv_stage& sp = w->stages[p];
+            const rn_conv_stage& sc = w->stages[r];
+            if (fold_r >= 0 && (p == fold_r - 1 || p == fold_r)) continue;          // (those channels are relabelled already)
+            if (sp.skip_stage >= 0 || sp.gamma2 || sp.pool_k != 4 || !sp.gamma || !sp.beta || !sp.mean || !sp.variance) continue;
+            if (sc.cin != sp.cout || sp.cout % 8 != 0 || sp.cout > 64) continue;
+            bool other_use = false;
+            for (int k = 0; k < w->n_stages; ++k) other_use |= w->stages[k].skip_stage == p;
+            if (other_use) continue;
+            std::vector<int> frozen, live;
+            for (int c = 0; c < sp.cout; ++c) (bn1_frozen(sp, c) ? frozen : live).push_back(c);
+            const int proven = static_cast<int>(frozen.size()), nf = proven / 8 * 8;
+            if (nf < 8 || nf >= sp.cout) continue;
+            while (static_cast<int>(frozen.size()) > nf) {
+                live.push_back(frozen.back());
+                frozen.pop_back();
+            }
+            std::sort(live.begin(), live.end());
+            kfold_pi = live;
+            kfold_pi.insert(kfold_pi.end(), frozen.begin(), frozen.end());
+            kfold_r = r;
+            kfold_live = sp.cout - nf;
+            kfold_proven = proven;
+        }
+        if (kfold_r >= 0) {
+            const std::vector<int>& pi = kfold_pi;
+            ensure_copy();
+            const int r = kfold_r;
+            const rn_conv_stage sp = stg_copy[r - 1], sc = stg_copy[r];
+            stg_copy[r - 1].kernel = perm_kernel(pi, sp.kernel, sp.cin, sp.cout, false, true);
+            stg_copy[r - 1].gamma = perm_vec(pi, sp.gamma);
+            stg_copy[r - 1].beta = perm_vec(pi, sp.beta);
+            stg_copy[r - 1].mean = perm_vec(pi, sp.mean);
+            stg_copy[r - 1].variance = perm_vec(pi, sp.variance);
+            stg_copy[r].kernel = perm_kernel(pi, sc.kernel, sc.cin, sc.cout, true, false);
         }
     }
     if ((rc = build_plan(h, w)) != RN_OK) return fail(rc);
@@ -579,6 +629,12 @@ extern "C" int rn_create(const rn_weights* w, int device, int dtype, int max_bat
         h->f32_fold_live = 32;
         h->node_perm[h->stages[fold_r - 1].node_bn] = fold_pi;
         h->node_perm[h->stages[fold_r].node_bn2] = fold_pi;
+    }
+    if (kfold_r >= 0) {
+        h->f32_kfold_stage = kfold_r;           // (rn_f32m_prepare takes it back if no kernel variant contracts that channel count)
+        h->f32_kfold_live = kfold_live;
+        h->f32_kfold_proven = kfold_proven;
+        h->node_perm[h->stages[kfold_r - 1].node_bn] = kfold_pi;
     }
     // uint8 -> float32 table, evaluated in float64 like the reference's NumPy expression
     {
@@ -1126,9 +1182,15 @@ extern "C" int rn_frozen_info(const rn_handle* h, int info[4]) {
     info[3] = 4;
     if (fused_mode(h)) {
         rn_fused_frozen_info(h, info);
-    } else if (h->f32_fold_stage >= 0 && rn_f32m_covers(h, h->f32_fold_stage)) {
-        info[2] = h->f32_fold_stage;
-        info[3] = h->f32_fold_live / 16;
+    } else {
+        if (h->f32_fold_stage >= 0 && rn_f32m_covers(h, h->f32_fold_stage)) {
+            info[2] = h->f32_fold_stage;
+            info[3] = h->f32_fold_live / 16;
+        }
+        if (h->f32_kfold_stage >= 0 && rn_f32m_covers(h, h->f32_kfold_stage)) {
+            info[0] = h->stages[h->f32_kfold_stage].cin - h->f32_kfold_live;
+            info[1] = h->f32_kfold_proven;
+        }
     }
     return RN_OK;
 }

@@ -119,6 +119,11 @@ struct rn_handle {
     // couts whose convolution still runs, and the relabelling of the tensors it touches (node id -> position p holds channel perm[p])
     int f32_fold_stage = -1;
     int f32_fold_live = 0;
+    // ... and frozen INPUT channels of a stage (its producer's BN freezes them; relabelled to the end): the stage's index (or -1),
+    // the input channels it still contracts (a multiple of 8), how many channels were proven constant
+    int f32_kfold_stage = -1;
+    int f32_kfold_live = 0;
+    int f32_kfold_proven = 0;
     std::map<int, std::vector<int>> node_perm;
     // profiling
     bool profiling = false;

@@ -42,6 +42,7 @@ struct F32StageArgs {
     const int32_t* rlo;
     const int32_t* rhi;
     const float* rlerp;
+    const float* cinit;           // [COUT] start value of the accumulators (KQL < CIN / 8: the frozen input channels' contribution)
     int H, W, Ho, Wo, Ss;
     int rows_per_band, n_bands, n_colblocks, n_ctg, npt;
     int ringcols;                 // columns of a ring row: (npt - 1) tile strides + 34, but never more than the input row
@@ -54,10 +55,14 @@ __device__ __forceinline__ f32x16 mfma_f32(float a, float b, f32x16 c) { return 
 // LPT = 16-byte chunks of a ring row one thread fetches (the host sizes the workgroup so that ringcols * CIN / 4 <= LPT * threads)
 // KS = waves per pixel tile: 2 = the tile's K sum is split by channel halves over two waves (the 64 -> 128 stage has two tiles per
 // row: two waves would leave half the CU's matrix pipes idle); the second wave's partial accumulators cross through LDS
-template <int CIN, int COUT, int PK, int PS, bool RES, int NSL, int LPT, int KS>
+// KQL = chunk pairs (8 input channels each) per tap that are contracted: CIN / 8, or fewer where the producer's BN freezes the last
+// CIN - 8 KQL channels to constants (rn_create relabels them to the end): a VALID convolution sees every tap of every pixel, so
+// they add one constant per cout -- a.cinit, the accumulators' start value
+template <int CIN, int COUT, int PK, int PS, bool RES, int NSL, int LPT, int KS, int KQL>
 __global__ __launch_bounds__(512) void stage_f32m_kernel(const F32StageArgs a) {
     constexpr int CP = CIN / 4;                          // 16-byte chunks (4 floats) per pixel
     constexpr int KQ = CIN / 8;                          // chunk pairs per tap = ds_read_b128 per tap and lane
+    static_assert(KQL == KQ || (KQL >= 1 && KQL < KQ && KS == 1 && COUT % 32 == 0), "input-channel fold: one wave per tile");
     constexpr int KC = 9 * KQ;                           // weight fragments (1 KB each) per 32-cout tile
     constexpr int CT = (COUT + 31) / 32;
     constexpr int NG = COUT >= 32 ? 4 : COUT / 8;
@@ -103,10 +108,10 @@ __global__ __launch_bounds__(512) void stage_f32m_kernel(const F32StageArgs a) {
 
     for (int i = tid; i < KC * 64; i += nthreads) reinterpret_cast<f32x4*>(wl)[i] = a.wfrag[((i >> 6) * CT + ctg) * 64 + (i & 63)];
     // per-channel tables of the tile's couts -> LDS (in registers they cost up to 96 VGPRs per lane)
-    for (int i = tid; i < 6 * 32; i += nthreads) {
+    for (int i = tid; i < (KQL < KQ ? 7 : 6) * 32; i += nthreads) {
         const int t = i / 32, c = ctg * 32 + i % 32;
-        const float* src = t == 0 ? a.bn_mean : t == 1 ? a.bn_inv : t == 2 ? a.bn_beta : t == 3 ? a.bn2_mean : t == 4 ? a.bn2_inv : a.bn2_beta;
-        tabs[i] = (c < COUT && (RES || t < 3)) ? src[c] : 0.f;
+        const float* src = t == 0 ? a.bn_mean : t == 1 ? a.bn_inv : t == 2 ? a.bn_beta : t == 3 ? a.bn2_mean : t == 4 ? a.bn2_inv : t == 5 ? a.bn2_beta : a.cinit;
+        tabs[i] = (c < COUT && (RES || t < 3 || t == 6)) ? src[c] : 0.f;
     }
 
     // ---- input-row loader: a thread owns up to LPT_MAX 16-byte chunks of a ring row
@@ -222,6 +227,14 @@ __global__ __launch_bounds__(512) void stage_f32m_kernel(const F32StageArgs a) {
         }
 
         f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};      // (the first MFMA's inline-zero C operand)
+        if constexpr (KQL < KQ) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 c = *reinterpret_cast<const f32x4*>(tabs + 192 + 4 * hh + 8 * g);       // couts cout_lane + 8 g .. + 3
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[4 * g + j] = c[j];
+            }
+        }
         const char* rowp[3];
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky) rowp[ky] = ring + ((it + ky) % NSL) * rowbytes;
@@ -229,7 +242,7 @@ __global__ __launch_bounds__(512) void stage_f32m_kernel(const F32StageArgs a) {
         for (int tap = 0; tap < 9; ++tap) {
             const int ky = tap / 3, kx = tap % 3;
 #pragma unroll
-            for (int qi = 0; qi < KQ / KS; ++qi) {
+            for (int qi = 0; qi < (KQL < KQ ? KQL : KQ / KS); ++qi) {
                 const int q = KS == 2 ? 2 * qi + kh : qi;   // (wave-uniform: this wave's channel half)
                 const f32x4 b = *reinterpret_cast<const f32x4*>(rowp[ky] + (BQ_PRE ? bq[kx][BQ_PRE ? qi : 0] : boff[kx] + (((2 * q + hh) ^ bswz[kx]) << 4)));
                 const f32x4 wv = *reinterpret_cast<const f32x4*>(wl_lane + (tap * KQ + q) * 1024);
@@ -525,6 +538,7 @@ struct F32mStage {
     bool m16 = false;             // stage_f32m16_kernel (16 couts): ks / lpt16 below
     int ks16 = 1;
     f32x4* wfrag = nullptr;
+    float* cinit = nullptr;       // per cout: the frozen input channels' contribution (variants with live_cin < cin)
     int variant = -1, npt = 1, n_colblocks = 1, n_ctg = 1, nsl = 4, ringcols = 34;
     size_t lds = 0;
 };
@@ -535,9 +549,9 @@ struct F32mState {
 
 using F32LaunchFn = void (*)(const F32StageArgs&, dim3, dim3, size_t, hipStream_t);
 
-template <int CIN, int COUT, int PK, int PS, bool RES, int NSL, int LPT, int KS>
+template <int CIN, int COUT, int PK, int PS, bool RES, int NSL, int LPT, int KS, int KQL = CIN / 8>
 void launch_f32m(const F32StageArgs& a, dim3 grid, dim3 block, size_t lds, hipStream_t s) {
-    auto kern = stage_f32m_kernel<CIN, COUT, PK, PS, RES, NSL, LPT, KS>;
+    auto kern = stage_f32m_kernel<CIN, COUT, PK, PS, RES, NSL, LPT, KS, KQL>;
     static std::atomic<unsigned long long> attr_devices{0};
     int dev = 0;
     (void)hipGetDevice(&dev);
@@ -550,15 +564,17 @@ void launch_f32m(const F32StageArgs& a, dim3 grid, dim3 block, size_t lds, hipSt
 
 struct F32Variant {
     int cin, cout, pk, ps, res, nsl, lpt, ks;
+    int live_cin;                 // input channels contracted (== cin unless the variant folds frozen input channels)
     F32LaunchFn fn;
 };
 const F32Variant kF32Variants[] = {
-    {8, 32, 4, 1, 0, 4, 4, 1, launch_f32m<8, 32, 4, 1, false, 4, 4, 1>},        // stage 1
-    {32, 32, 4, 1, 0, 4, 4, 1, launch_f32m<32, 32, 4, 1, false, 4, 4, 1>},      // stage 2
-    {32, 32, 4, 1, 1, 4, 4, 1, launch_f32m<32, 32, 4, 1, true, 4, 4, 1>},       // stage 3
-    {32, 64, 4, 2, 0, 4, 4, 1, launch_f32m<32, 64, 4, 2, false, 4, 4, 1>},      // stage 4
-    {64, 64, 4, 2, 1, 3, 8, 1, launch_f32m<64, 64, 4, 2, true, 3, 8, 1>},       // stage 5
-    {64, 128, 0, 1, 0, 3, 8, 2, launch_f32m<64, 128, 0, 1, false, 3, 8, 2>},    // stage 6
+    {8, 32, 4, 1, 0, 4, 4, 1, 8, launch_f32m<8, 32, 4, 1, false, 4, 4, 1>},         // stage 1
+    {32, 32, 4, 1, 0, 4, 4, 1, 32, launch_f32m<32, 32, 4, 1, false, 4, 4, 1>},      // stage 2
+    {32, 32, 4, 1, 1, 4, 4, 1, 32, launch_f32m<32, 32, 4, 1, true, 4, 4, 1>},       // stage 3
+    {32, 32, 4, 1, 1, 4, 4, 1, 16, launch_f32m<32, 32, 4, 1, true, 4, 4, 1, 2>},    // stage 3, 16 of its input channels frozen
+    {32, 64, 4, 2, 0, 4, 4, 1, 32, launch_f32m<32, 64, 4, 2, false, 4, 4, 1>},      // stage 4
+    {64, 64, 4, 2, 1, 3, 8, 1, 64, launch_f32m<64, 64, 4, 2, true, 3, 8, 1>},       // stage 5
+    {64, 128, 0, 1, 0, 3, 8, 2, 64, launch_f32m<64, 128, 0, 1, false, 3, 8, 2>},    // stage 6
 };
 
 template <int CIN, int KS, int LPT>
@@ -598,11 +614,19 @@ int rn_f32m_prepare(rn_handle* h, const rn_weights* w) {
     for (size_t si = 0; si < h->stages.size(); ++si) {
         const StagePlan& s = h->stages[si];
         F32mStage& f = fs->st[si];
-        for (size_t v = 0; v < sizeof(kF32Variants) / sizeof(kF32Variants[0]); ++v) {
-            const F32Variant& k = kF32Variants[v];
-            if (k.cin == s.cin && k.cout == s.cout && k.pk == s.pool_k && (s.pool_k == 0 || k.ps == s.pool_s) &&
-                k.res == (s.skip_stage >= 0 ? 1 : 0))
-                f.variant = static_cast<int>(v);
+        // (rn_create relabelled a stage's frozen input channels to the end: the variant that contracts the others only, if there is one)
+        int want_live = static_cast<int>(si) == h->f32_kfold_stage ? h->f32_kfold_live : s.cin;
+        for (int pass = 0; pass < 2 && f.variant < 0; ++pass) {
+            for (size_t v = 0; v < sizeof(kF32Variants) / sizeof(kF32Variants[0]); ++v) {
+                const F32Variant& k = kF32Variants[v];
+                if (k.cin == s.cin && k.cout == s.cout && k.pk == s.pool_k && (s.pool_k == 0 || k.ps == s.pool_s) &&
+                    k.res == (s.skip_stage >= 0 ? 1 : 0) && k.live_cin == want_live)
+                    f.variant = static_cast<int>(v);
+            }
+            if (f.variant < 0 && want_live != s.cin) {
+                h->f32_kfold_stage = -1;          // no such variant: every channel is contracted (the relabelling alone changes nothing)
+                want_live = s.cin;
+            }
         }
         if (f.variant < 0 && s.cout == 16 && s.pool_k == 4 && s.pool_s == 2 && s.skip_stage < 0) {
             // 16-cout stages: stage_f32m16_kernel; frag[tap * CIN / 16 + q][lane][i] = W[tap][channel 16 q + 4 (lane / 16) + i][cout lane % 16]
@@ -688,8 +712,29 @@ int rn_f32m_prepare(rn_handle* h, const rn_weights* w) {
         h->allocs.push_back(d);
         RN_HIP(hipMemcpy(d, frag.data(), frag.size() * 4, hipMemcpyHostToDevice));
         f.wfrag = static_cast<f32x4*>(d);
+        if (want_live < s.cin) {
+            // the producer writes beta[c] for its frozen channel c at every pixel: sum over the nine taps, in double
+            const float* beta = w->stages[si - 1].beta;
+            std::vector<float> ci(static_cast<size_t>(ct_n) * 32, 0.f);
+            for (int co = 0; co < s.cout; ++co) {
+                double acc = 0.0;
+                for (int tap = 0; tap < 9; ++tap)
+                    for (int c = want_live; c < s.cin; ++c)
+                        acc += static_cast<double>(wsrc[(static_cast<size_t>(tap) * s.cin + c) * s.cout + co]) * static_cast<double>(beta[c]);
+                ci[co] = static_cast<float>(acc);
+            }
+            void* dc = nullptr;
+            if (hipMalloc(&dc, ci.size() * 4) != hipSuccess) {
+                rn_set_error("hipMalloc(fp32 frozen-input constants) failed");
+                return RN_E_NOMEM;
+            }
+            h->allocs.push_back(dc);
+            RN_HIP(hipMemcpy(dc, ci.data(), ci.size() * 4, hipMemcpyHostToDevice));
+            f.cinit = static_cast<float*>(dc);
+        }
         f.on = true;
     }
+    if (h->f32_kfold_stage >= 0 && !fs->st[h->f32_kfold_stage].cinit) h->f32_kfold_stage = -1;      // (the stage is not covered at all)
     return RN_OK;
 }
 
@@ -706,6 +751,7 @@ int rn_f32m_launch(rn_handle* h, int stage, const float* in, int n) {
     a.in = in;
     a.out = static_cast<float*>(h->nodes[s.node_bn2 >= 0 ? s.node_bn2 : s.node_bn].ptr);
     a.wfrag = f.wfrag;
+    a.cinit = f.cinit;
     a.bn_mean = s.bn.mean;
     a.bn_inv = s.bn.inv;
     a.bn_beta = s.bn.beta;

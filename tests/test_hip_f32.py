@@ -271,20 +271,27 @@ def test_matrix_core_f32_at_other_input_sides(weights, side):
 def test_matrix_core_f32_folds_stage_5_frozen_channels(weights, parity_images):
     """Round 5: 44 of the 64 first-BN channels of stage 5 are frozen on the shipped checkpoint (y1 = ((x/16 - mean) * inv + beta) IS
     beta for every input: the reference's float32 computes the same expression); the default float32 handle relabels the
-    stage's channels so that its second 32-cout tile is all frozen and does not convolve it (rn_create, rn_f32m_launch).  Against
-    the handle that computes everything (RN_FLAG_COMPUTE_FROZEN): the frozen channels contribute the same bits, the live ones
-    differ by the order of the K sum only (the relabelling permutes the input channels)."""
+    stage's channels so that its second 32-cout tile is all frozen and does not convolve it (rn_create, rn_f32m_launch).  Likewise
+    18 of stage 2's 32 output channels: relabelled to the end, stage 3 contracts the first 16 input channels only and starts its
+    accumulators from the other 16's contribution (one constant per cout of a VALID convolution).  Against the handle that computes
+    everything (RN_FLAG_COMPUTE_FROZEN): the frozen channels hold the same bits, the live ones differ by the order of the K sum."""
     g = build_graph(6, 224)
     fold = _capi.Engine(g, weights, device=0, dtype="f32", max_batch=8)
     full = _capi.Engine(g, weights, device=0, dtype="f32", max_batch=8, compute_frozen=True)
     try:
-        assert fold.frozen_info()["residual_stage_folded"] == 5 and fold.frozen_info()["residual_stage_live_quarters"] == 2
-        assert full.frozen_info()["residual_stage_folded"] == -1
+        info = fold.frozen_info()
+        assert info["residual_stage_folded"] == 5 and info["residual_stage_live_quarters"] == 2
+        assert info["pair_channels_not_convolved"] == 16 and info["pair_channels_proven_frozen"] == 18
+        assert full.frozen_info()["residual_stage_folded"] == -1 and full.frozen_info()["pair_channels_not_convolved"] == 0
         ims = parity_images[[3, 14, 22, 37, 44, 52, 56, 60]]
         ids_a, probs_a = fold.forward_u8(ims)
         ids_b, probs_b = full.forward_u8(ims)
-        np.testing.assert_array_equal(fold.tap("s4.bn", 8), full.tap("s4.bn", 8))          # (relabelled in HBM, handed out in order)
-        for name in ("s5.bn2", "s6.bn", "s9.bn2"):
+        for name in ("s1.bn", "s2.bn"):           # (s2.bn: relabelled in HBM, handed out in the reference's order)
+            np.testing.assert_array_equal(fold.tap(name, 8), full.tap(name, 8))
+        s2 = fold.tap("s2.bn", 8)
+        frozen = [c for c in range(32) if (s2[..., c] == s2[0, 0, 0, c]).all()]
+        assert len(frozen) >= 18, frozen
+        for name in ("s3.bn2", "s4.bn", "s5.bn2", "s6.bn", "s9.bn2"):
             a, b = fold.tap(name, 8), full.tap(name, 8)
             assert float(np.abs(a - b).max()) <= 2e-5 * float(np.abs(b).max()), name
         np.testing.assert_allclose(probs_a, probs_b, rtol=0, atol=5e-6)          # (fp32 K-sum order; the oracle tolerance is 1e-5)
