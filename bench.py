@@ -631,9 +631,23 @@ def main():
             # every stage the launch computes / its time / 8 TB/s -- a fused launch is credited with tensors that never leave
             # LDS, so this figure is NOT a bandwidth and may pass 1; `physical_frac` = what the PMC counters say the launch
             # moved (profiles/*_hbm_traffic.json of this configuration) / its time / 8 TB/s; `mfma_frac` = algorithmic conv
-            # flops / time / dense matrix peak of the dtype.
+            # flops (the reference's: every channel) / time / dense matrix peak of the dtype, `mfma_frac_executed` = without the
+            # flops of channels the handle folds.
             dom = int(np.argmax(group_ms))
             mfma_peak = MFMA_PEAK_F32 if f32 else MFMA_PEAK_16
+            # share of a stage's algorithmic flops the folded handle really issues (`mfma_frac_executed`): the first 32 -> 32
+            # stage computes its live couts only (16-bit pair), the next one contracts the live input channels (16-bit: five
+            # two-tap K = 32 chunks for nine taps of 32 channels), the folded residual stage its live cout quarters
+            share = [1.0] * n_st
+            if fold_info is not None:
+                p32 = [k for k in range(n_st - 1) if graph.stages[k].cin == 32 and graph.stages[k].cout == 32 and not graph.stages[k].residual]
+                dead = fold_info["pair_channels_not_convolved"]
+                if dead > 0 and p32:
+                    if not f32:
+                        share[p32[0]] = 1.0 - dead / 32.0
+                    share[p32[0] + 1] = (5 * 32) / (9 * 32.0) if not f32 else 1.0 - dead / 32.0
+                if fold_info["residual_stage_folded"] >= 0:
+                    share[fold_info["residual_stage_folded"]] = fold_info["residual_stage_live_quarters"] / 4.0
             launches = []
             for j, g in enumerate(groups):
                 sec = max(group_ms[j], 1e-9) * 1e-3
@@ -655,7 +669,8 @@ def main():
                 launches.append({"kernel": kname, "stages": g, "ms": group_ms[j], "algorithmic_bytes": int(gb),
                                  "credited_frac": gb / sec / HBM_PEAK, "traffic": tr,
                                  "physical_frac": None if tr is None else tr / sec / HBM_PEAK,
-                                 "mfma_frac": gf / sec / mfma_peak})
+                                 "mfma_frac": gf / sec / mfma_peak,
+                                 "mfma_frac_executed": sum(sflops[k] * share[k] for k in g) * B / sec / mfma_peak})
             traffics = [l["traffic"] for l in launches]
             path_traffic = None if any(t is None for t in traffics) else int(sum(traffics))
             bpi = graph.boundary_elements_per_image() * elem
@@ -663,7 +678,9 @@ def main():
                 ach = value * graph.flops_per_image() / world
                 out["roofline"] = {"bound": "mfma", "achieved": ach / 1e12, "peak": MFMA_PEAK_F32 / 1e12, "unit": "TFLOP/s",
                                    "frac": ach / MFMA_PEAK_F32, "traffic": path_traffic,
-                                   "scope": "whole path: images/sec x 4.4864 GFLOP per image (SURVEY 8d) / matrix-fp32 peak per GPU",
+                                   "scope": "whole path: images/sec x 4.4864 GFLOP per image (SURVEY 8d: the reference's flops, folded "
+                                            "channels included) / matrix-fp32 peak per GPU; `executed_frac` counts the flops the handle issues",
+                                   "executed_frac": value * sum(sflops[k] * share[k] for k in range(n_st)) / world / MFMA_PEAK_F32,
                                    "dominant": dom, "launches": launches}
             else:
                 ach = value * bpi / world
