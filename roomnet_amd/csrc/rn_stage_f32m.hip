@@ -358,13 +358,20 @@ __global__ __launch_bounds__(512) void stage_f32m_kernel(const F32StageArgs a) {
 // the ring each), partial sums meet in LDS and are added in a fixed order by the first.
 __device__ __forceinline__ f32x4 mfma_f32_16(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 
-template <int CIN, int KS, int LPT>
+// PS = 1, CFZ = 16: the first 32 -> 32 stage (avg-pool 4/1) of a handle whose rn_create proved 16 of its output channels constant
+// and relabelled them to the end: the 16 live couts are convolved (13 pooled columns per tile: stride 13), the other 16 channels of
+// the 32-channel output pixel are written as their constant (beta) -- the tensor in HBM is complete, the next stage does not
+// contract them (stage_f32m_kernel's KQL)
+template <int CIN, int KS, int LPT, int PS = 2, int CFZ = 0>
 __global__ __launch_bounds__(576) void stage_f32m16_kernel(const F32StageArgs a) {
-    constexpr int COUT = 16, PK = 4, PS = 2, NSL = 3;
+    constexpr int COUT = 16, PK = 4;
+    constexpr int NSL = CFZ > 0 ? 4 : 3;                 // ring slots: 4 = the next row lands behind the compute, one barrier per row
     constexpr int CP = CIN / 4;                          // 16-byte chunks per pixel
     constexpr int KG = CIN / 16;                         // 16-channel groups per tap = ds_read_b128 per tap and lane
     constexpr int KC = 9 * KG;                           // weight fragments (1 KB each)
-    constexpr int TSTRIDE = 14, NOUT_T = 7;
+    constexpr int TSTRIDE = PS == 2 ? 14 : 13, NOUT_T = PS == 2 ? 7 : 13;
+    static_assert(PS == 1 || PS == 2, "pool stride");
+    static_assert(CFZ == 0 || CFZ == 16, "frozen channels written beside the 16 live ones");
     constexpr int PIXB = CIN * 4;
     static_assert(CIN % 16 == 0 && (KS == 1 || KS == 3), "channel groups of 16; K split = one kernel row per wave");
 
@@ -392,7 +399,17 @@ __global__ __launch_bounds__(576) void stage_f32m16_kernel(const F32StageArgs a)
     const int x0c = cb * npt * TSTRIDE;
     const int xo_blk0 = x0c / PS;
 
-    for (int i = tid; i < KC * 64; i += nthreads) reinterpret_cast<f32x4*>(wl)[i] = a.wfrag[i];
+    // weights: in LDS in fragment order (read per use), or -- where the 9 KG fragments fit the register file (KS = 1, 32 channels:
+    // 72 registers) -- in registers: the B operand then is the only LDS read of the chain (per row and workgroup the weight reads
+    // were half of its LDS traffic, which ran at half of the matrix time)
+    constexpr bool WREG = KS == 1 && KC <= 18 && CFZ > 0;
+    [[maybe_unused]] f32x4 wreg[WREG ? KC : 1];
+    if constexpr (WREG) {
+#pragma unroll
+        for (int i = 0; i < KC; ++i) wreg[i] = a.wfrag[i * 64 + lane];
+    } else {
+        for (int i = tid; i < KC * 64; i += nthreads) reinterpret_cast<f32x4*>(wl)[i] = a.wfrag[i];
+    }
     for (int i = tid; i < 48; i += nthreads) tabs[i] = (i < 16 ? a.bn_mean : i < 32 ? a.bn_inv : a.bn_beta)[i & 15];
 
     const int nchunks = ringcols * CP;
@@ -441,6 +458,8 @@ __global__ __launch_bounds__(576) void stage_f32m16_kernel(const F32StageArgs a)
     const char* const wl_lane = wl + lane * 16;
     const f32x4 t_mean = *reinterpret_cast<const f32x4*>(tabs + 4 * kq), t_inv = *reinterpret_cast<const f32x4*>(tabs + 16 + 4 * kq),
                 t_beta = *reinterpret_cast<const f32x4*>(tabs + 32 + 4 * kq);
+    [[maybe_unused]] f32x4 t_frozen = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (CFZ > 0) t_frozen = *reinterpret_cast<const f32x4*>(a.bn_beta + COUT + 4 * kq);
 
     for (int it = 0; it < nconv; ++it) {
         const bool have_next = it + 3 < nin;
@@ -456,7 +475,11 @@ __global__ __launch_bounds__(576) void stage_f32m16_kernel(const F32StageArgs a)
 #pragma unroll
             for (int q = 0; q < KG; ++q) {
                 const f32x4 b = *reinterpret_cast<const f32x4*>(rowp + boff[kx] + (((4 * q + kq) ^ bswz[kx]) << 4));
-                const f32x4 wv = *reinterpret_cast<const f32x4*>(wrow + q * 1024);
+                f32x4 wv;
+                if constexpr (WREG)
+                    wv = wreg[(WREG ? t3 : 0) * KG + q];
+                else
+                    wv = *reinterpret_cast<const f32x4*>(wrow + q * 1024);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) acc = mfma_f32_16(wv[i], b[i], acc);
             }
@@ -491,11 +514,13 @@ __global__ __launch_bounds__(576) void stage_f32m16_kernel(const F32StageArgs a)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
                     y[j] = __fadd_rn(__fmul_rn(__fsub_rn(__fmul_rn(tot[j], 1.0f / 16.0f), t_mean[j]), t_inv[j]), t_beta[j]);
-                *reinterpret_cast<f32x4*>(a.out + ((static_cast<int64_t>(n) * a.Ho + yo) * a.Wo + xo) * COUT + 4 * kq) = y;
+                float* opix = a.out + ((static_cast<int64_t>(n) * a.Ho + yo) * a.Wo + xo) * (COUT + CFZ) + 4 * kq;
+                *reinterpret_cast<f32x4*>(opix) = y;
+                if constexpr (CFZ > 0) *reinterpret_cast<f32x4*>(opix + COUT) = t_frozen;
             }
         }
-        lds_barrier();            // everybody is past row `it` (and the partial tiles) before its slot is refilled
-        if (have_next) store_row(it + 3);
+        if constexpr (NSL == 3) lds_barrier();            // everybody is past row `it` (and the partial tiles) before its slot is refilled
+        if (have_next) store_row(it + 3);                 // (NSL == 4: slot (it + 3) % 4 held row it - 1, which the last barrier retired)
         lds_barrier();
     }
 }
@@ -577,9 +602,9 @@ const F32Variant kF32Variants[] = {
     {64, 128, 0, 1, 0, 3, 8, 2, 64, launch_f32m<64, 128, 0, 1, false, 3, 8, 2>},    // stage 6
 };
 
-template <int CIN, int KS, int LPT>
+template <int CIN, int KS, int LPT, int PS = 2, int CFZ = 0>
 void launch_f32m16(const F32StageArgs& a, dim3 grid, dim3 block, size_t lds, hipStream_t s) {
-    auto kern = stage_f32m16_kernel<CIN, KS, LPT>;
+    auto kern = stage_f32m16_kernel<CIN, KS, LPT, PS, CFZ>;
     static std::atomic<unsigned long long> attr_devices{0};
     int dev = 0;
     (void)hipGetDevice(&dev);
@@ -591,11 +616,16 @@ void launch_f32m16(const F32StageArgs& a, dim3 grid, dim3 block, size_t lds, hip
 }
 struct F32Variant16 {
     int cin, ks, lpt;
+    int ps, frozen;               // pool stride; frozen couts written as constants beside the 16 live ones
+    int nsl, max_tiles;           // ring slots; pixel tiles per workgroup at most
     F32LaunchFn fn;
 };
 const F32Variant16 kF32Variants16[] = {
-    {128, 3, 4, launch_f32m16<128, 3, 4>},      // stage 7 (npt = 3: 576 threads, a 46-pixel ring row = 1 472 chunks)
-    {16, 1, 2, launch_f32m16<16, 1, 2>},        // stage 8
+    {128, 3, 4, 2, 0, 3, 3, launch_f32m16<128, 3, 4>},          // stage 7 (npt = 3: 576 threads, a 46-pixel ring row = 1 472 chunks)
+    {16, 1, 2, 2, 0, 3, 9, launch_f32m16<16, 1, 2>},            // stage 8
+    // stage 2 with 16 frozen couts (weights in registers, four ring slots).  Tiles per workgroup, measured (ms): 9 1.53 | 8 1.66 |
+    // 6 1.67-1.71 | 5 2.11 | 4 1.35 (but the next stage, which reads this output, 0.07 slower) | 3 1.53 | 2 1.85
+    {32, 1, 2, 1, 16, 4, 9, launch_f32m16<32, 1, 2, 1, 16>},
 };
 
 }  // namespace
@@ -611,12 +641,27 @@ int rn_f32m_prepare(rn_handle* h, const rn_weights* w) {
     auto* fs = new F32mState();
     fs->st.resize(h->stages.size());
     h->f32m = fs;
-    for (size_t si = 0; si < h->stages.size(); ++si) {
+    auto upload = [&](const std::vector<float>& v, const char* what, float** out) -> int {
+        void* d = nullptr;
+        if (hipMalloc(&d, v.size() * 4) != hipSuccess) {
+            rn_set_error("hipMalloc(%s) failed", what);
+            return RN_E_NOMEM;
+        }
+        h->allocs.push_back(d);
+        RN_HIP(hipMemcpy(d, v.data(), v.size() * 4, hipMemcpyHostToDevice));
+        *out = static_cast<float*>(d);
+        return RN_OK;
+    };
+    auto prepare_stage = [&](size_t si) -> int {
         const StagePlan& s = h->stages[si];
         F32mStage& f = fs->st[si];
+        // the producer of a stage that does not contract its frozen input channels need not convolve them either: 16 live couts on
+        // the 16 x 16 x 4 tiles, the frozen ones written as constants (only once the consumer's variant is in place)
+        const bool live16 = static_cast<int>(si) + 1 == h->f32_kfold_stage && fs->st[si + 1].on && fs->st[si + 1].cinit && h->f32_kfold_live == 16 &&
+                            s.cout == 32 && s.pool_k == 4 && s.pool_s == 1 && s.skip_stage < 0;
         // (rn_create relabelled a stage's frozen input channels to the end: the variant that contracts the others only, if there is one)
         int want_live = static_cast<int>(si) == h->f32_kfold_stage ? h->f32_kfold_live : s.cin;
-        for (int pass = 0; pass < 2 && f.variant < 0; ++pass) {
+        for (int pass = 0; pass < 2 && f.variant < 0 && !live16; ++pass) {
             for (size_t v = 0; v < sizeof(kF32Variants) / sizeof(kF32Variants[0]); ++v) {
                 const F32Variant& k = kF32Variants[v];
                 if (k.cin == s.cin && k.cout == s.cout && k.pk == s.pool_k && (s.pool_k == 0 || k.ps == s.pool_s) &&
@@ -628,37 +673,36 @@ int rn_f32m_prepare(rn_handle* h, const rn_weights* w) {
                 want_live = s.cin;
             }
         }
-        if (f.variant < 0 && s.cout == 16 && s.pool_k == 4 && s.pool_s == 2 && s.skip_stage < 0) {
+        if (f.variant < 0 && (live16 || (s.cout == 16 && s.pool_k == 4 && s.pool_s == 2 && s.skip_stage < 0))) {
             // 16-cout stages: stage_f32m16_kernel; frag[tap * CIN / 16 + q][lane][i] = W[tap][channel 16 q + 4 (lane / 16) + i][cout lane % 16]
+            const int frozen = live16 ? 16 : 0;
             for (size_t v = 0; v < sizeof(kF32Variants16) / sizeof(kF32Variants16[0]); ++v) {
                 const F32Variant16& k = kF32Variants16[v];
-                if (k.cin != s.cin) continue;
-                const int kg = s.cin / 16, tiles = (s.out_side + 6) / 7;
-                int npt = std::min(tiles, 576 / (64 * k.ks));
+                if (k.cin != s.cin || k.ps != s.pool_s || k.frozen != frozen) continue;
+                const int tstride = k.ps == 2 ? 14 : 13, nout_t = k.ps == 2 ? 7 : 13;
+                const int kg = s.cin / 16, tiles = (s.out_side + nout_t - 1) / nout_t;
+                int npt = std::min(tiles, k.max_tiles);
+                npt = std::min(npt, (tiles + (tiles + npt - 1) / npt - 1) / ((tiles + npt - 1) / npt));      // even column blocks
                 size_t lds = 0;
                 int ringcols = 0;
                 for (; npt >= 1; --npt) {
-                    ringcols = std::min((npt - 1) * 14 + 18, s.in_side);
-                    lds = static_cast<size_t>(9 * kg) * 1024 + 256 + static_cast<size_t>(3) * ringcols * s.cin * 4 + (k.ks == 3 ? 2 * npt * 1024 : 0);
+                    ringcols = std::min((npt - 1) * tstride + 18, s.in_side);
+                    lds = static_cast<size_t>(9 * kg) * 1024 + 256 + static_cast<size_t>(k.nsl) * ringcols * s.cin * 4 + (k.ks == 3 ? 2 * npt * 1024 : 0);
                     if (lds <= 160 * 1024 && ringcols * (s.cin / 4) <= k.lpt * 64 * npt * k.ks) break;
                 }
                 if (npt < 1) continue;
                 std::vector<float> frag(static_cast<size_t>(9 * kg) * 64 * 4, 0.f);
-                const float* wsrc = w->stages[si].kernel;      // HWIO = [tap][cin][cout]
+                const float* wsrc = w->stages[si].kernel;      // HWIO = [tap][cin][cout]: the first 16 couts
                 for (int tap = 0; tap < 9; ++tap)
                     for (int q = 0; q < kg; ++q)
                         for (int l = 0; l < 64; ++l)
                             for (int i = 0; i < 4; ++i)
                                 frag[((static_cast<size_t>(tap) * kg + q) * 64 + l) * 4 + i] =
-                                    wsrc[(static_cast<size_t>(tap) * s.cin + 16 * q + 4 * (l >> 4) + i) * 16 + (l & 15)];
-                void* d = nullptr;
-                if (hipMalloc(&d, frag.size() * 4) != hipSuccess) {
-                    rn_set_error("hipMalloc(fp32 MFMA weights) failed");
-                    return RN_E_NOMEM;
-                }
-                h->allocs.push_back(d);
-                RN_HIP(hipMemcpy(d, frag.data(), frag.size() * 4, hipMemcpyHostToDevice));
-                f.wfrag = static_cast<f32x4*>(d);
+                                    wsrc[(static_cast<size_t>(tap) * s.cin + 16 * q + 4 * (l >> 4) + i) * s.cout + (l & 15)];
+                float* d = nullptr;
+                const int rc = upload(frag, "fp32 MFMA weights", &d);
+                if (rc != RN_OK) return rc;
+                f.wfrag = reinterpret_cast<f32x4*>(d);
                 f.m16 = true;
                 f.variant = static_cast<int>(v);
                 f.ks16 = k.ks;
@@ -670,10 +714,15 @@ int rn_f32m_prepare(rn_handle* h, const rn_weights* w) {
                 f.on = true;
                 break;
             }
-            continue;
+            if (f.on || !live16) return RN_OK;
+            // (no 16-cout variant for this producer: it convolves every channel like any other stage)
+            for (size_t v = 0; v < sizeof(kF32Variants) / sizeof(kF32Variants[0]); ++v) {
+                const F32Variant& k = kF32Variants[v];
+                if (k.cin == s.cin && k.cout == s.cout && k.pk == s.pool_k && k.ps == s.pool_s && k.res == 0 && k.live_cin == s.cin) f.variant = static_cast<int>(v);
+            }
         }
-        if (f.variant < 0) continue;
-        if (s.skip_stage >= 0 && h->stages[s.skip_stage].node_bn2 >= 0) continue;      // skip source = a first BN output
+        if (f.variant < 0) return RN_OK;
+        if (s.skip_stage >= 0 && h->stages[s.skip_stage].node_bn2 >= 0) return RN_OK;      // skip source = a first BN output
         const int kq = s.cin / 8, kc = 9 * kq, ct_n = (s.cout + 31) / 32;
         f.nsl = kF32Variants[f.variant].nsl;
         // pixel tiles (= waves) per workgroup: as many as fit the LDS next to the weights, at most 8
@@ -689,7 +738,7 @@ int rn_f32m_prepare(rn_handle* h, const rn_weights* w) {
             --f.npt;
         }
         if (f.lds > 160 * 1024 || f.ringcols * (s.cin / 4) > kF32Variants[f.variant].lpt * 64 * f.npt * kF32Variants[f.variant].ks)
-            continue;      // not coverable
+            return RN_OK;      // not coverable
         f.n_colblocks = (tiles + f.npt - 1) / f.npt;
         f.n_ctg = ct_n;
         std::vector<float> frag(static_cast<size_t>(kc) * ct_n * 64 * 4, 0.f);
@@ -704,14 +753,10 @@ int rn_f32m_prepare(rn_handle* h, const rn_weights* w) {
                                 frag[((static_cast<size_t>(tap * kq + q) * ct_n + t) * 64 + l) * 4 + i] =
                                     wsrc[(static_cast<size_t>(tap) * s.cin + c) * s.cout + co];
                         }
-        void* d = nullptr;
-        if (hipMalloc(&d, frag.size() * 4) != hipSuccess) {
-            rn_set_error("hipMalloc(fp32 MFMA weights) failed");
-            return RN_E_NOMEM;
-        }
-        h->allocs.push_back(d);
-        RN_HIP(hipMemcpy(d, frag.data(), frag.size() * 4, hipMemcpyHostToDevice));
-        f.wfrag = static_cast<f32x4*>(d);
+        float* d = nullptr;
+        int rc = upload(frag, "fp32 MFMA weights", &d);
+        if (rc != RN_OK) return rc;
+        f.wfrag = reinterpret_cast<f32x4*>(d);
         if (want_live < s.cin) {
             // the producer writes beta[c] for its frozen channel c at every pixel: sum over the nine taps, in double
             const float* beta = w->stages[si - 1].beta;
@@ -723,18 +768,23 @@ int rn_f32m_prepare(rn_handle* h, const rn_weights* w) {
                         acc += static_cast<double>(wsrc[(static_cast<size_t>(tap) * s.cin + c) * s.cout + co]) * static_cast<double>(beta[c]);
                 ci[co] = static_cast<float>(acc);
             }
-            void* dc = nullptr;
-            if (hipMalloc(&dc, ci.size() * 4) != hipSuccess) {
-                rn_set_error("hipMalloc(fp32 frozen-input constants) failed");
-                return RN_E_NOMEM;
-            }
-            h->allocs.push_back(dc);
-            RN_HIP(hipMemcpy(dc, ci.data(), ci.size() * 4, hipMemcpyHostToDevice));
-            f.cinit = static_cast<float*>(dc);
+            if ((rc = upload(ci, "fp32 frozen-input constants", &f.cinit)) != RN_OK) return rc;
         }
         f.on = true;
+        return RN_OK;
+    };
+    // the stage with frozen input channels first: whether its producer may leave them out depends on it
+    const int kf = h->f32_kfold_stage;
+    if (kf >= 0) {
+        const int rc = prepare_stage(static_cast<size_t>(kf));
+        if (rc != RN_OK) return rc;
+        if (!fs->st[kf].cinit) h->f32_kfold_stage = -1;      // (the stage is not covered, or has no variant for that channel count)
     }
-    if (h->f32_kfold_stage >= 0 && !fs->st[h->f32_kfold_stage].cinit) h->f32_kfold_stage = -1;      // (the stage is not covered at all)
+    for (size_t si = 0; si < h->stages.size(); ++si) {
+        if (static_cast<int>(si) == kf) continue;
+        const int rc = prepare_stage(si);
+        if (rc != RN_OK) return rc;
+    }
     return RN_OK;
 }
 

@@ -273,7 +273,8 @@ def test_matrix_core_f32_folds_stage_5_frozen_channels(weights, parity_images):
     beta for every input: the reference's float32 computes the same expression); the default float32 handle relabels the
     stage's channels so that its second 32-cout tile is all frozen and does not convolve it (rn_create, rn_f32m_launch).  Likewise
     18 of stage 2's 32 output channels: relabelled to the end, stage 3 contracts the first 16 input channels only and starts its
-    accumulators from the other 16's contribution (one constant per cout of a VALID convolution).  Against the handle that computes
+    accumulators from the other 16's contribution (one constant per cout of a VALID convolution), and stage 2 convolves its 16
+    live couts only (16 x 16 x 4 tiles) and writes the constants of the others.  Against the handle that computes
     everything (RN_FLAG_COMPUTE_FROZEN): the frozen channels hold the same bits, the live ones differ by the order of the K sum."""
     g = build_graph(6, 224)
     fold = _capi.Engine(g, weights, device=0, dtype="f32", max_batch=8)
@@ -286,11 +287,14 @@ def test_matrix_core_f32_folds_stage_5_frozen_channels(weights, parity_images):
         ims = parity_images[[3, 14, 22, 37, 44, 52, 56, 60]]
         ids_a, probs_a = fold.forward_u8(ims)
         ids_b, probs_b = full.forward_u8(ims)
-        for name in ("s1.bn", "s2.bn"):           # (s2.bn: relabelled in HBM, handed out in the reference's order)
-            np.testing.assert_array_equal(fold.tap(name, 8), full.tap(name, 8))
-        s2 = fold.tap("s2.bn", 8)
-        frozen = [c for c in range(32) if (s2[..., c] == s2[0, 0, 0, c]).all()]
+        np.testing.assert_array_equal(fold.tap("s1.bn", 8), full.tap("s1.bn", 8))
+        # s2.bn: relabelled in HBM, handed out in the reference's order; its frozen channels are the same constants on both handles
+        # (the folding handle writes them without convolving), the live ones come from another matrix tile shape (K-sum order)
+        s2a, s2b = fold.tap("s2.bn", 8), full.tap("s2.bn", 8)
+        frozen = [c for c in range(32) if (s2b[..., c] == s2b[0, 0, 0, c]).all()]
         assert len(frozen) >= 18, frozen
+        np.testing.assert_array_equal(s2a[..., frozen], s2b[..., frozen])
+        assert float(np.abs(s2a - s2b).max()) <= 2e-5 * float(np.abs(s2b).max())
         for name in ("s3.bn2", "s4.bn", "s5.bn2", "s6.bn", "s9.bn2"):
             a, b = fold.tap(name, 8), full.tap(name, 8)
             assert float(np.abs(a - b).max()) <= 2e-5 * float(np.abs(b).max()), name
