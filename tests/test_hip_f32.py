@@ -27,7 +27,7 @@ def test_library_sees_a_gpu():
     assert _capi.device_count() >= 1
 
 
-def test_logits_probs_ids_vs_golden(engine, parity_images, golden_parity):
+def test_logits_probs_ids_vs_golden(engine, parity_images, golden_parity, record):
     ids, probs, logits = [], [], []
     for i in range(0, len(parity_images), 8):               # 64 images = eight chunks of max_batch; logits tapped after each
         a, b = engine.forward_u8(parity_images[i:i + 8])
@@ -35,6 +35,9 @@ def test_logits_probs_ids_vs_golden(engine, parity_images, golden_parity):
         probs.append(b)
         logits.append(engine.tap("d3.relu", len(a)).copy())
     ids, probs, logits = np.concatenate(ids), np.concatenate(probs), np.concatenate(logits)
+    record("parity_set_64_images_224", "f32_per_node_path", {
+        "max_abs_dlogit_vs_fp64": float(np.abs(logits - golden_parity["logits_f64"]).max()), "tolerance_logits": TOL_LOGITS,
+        "max_abs_dprob_vs_fp64": float(np.abs(probs - golden_parity["probs_f64"]).max()), "tolerance_probs": TOL_PROBS})
     np.testing.assert_allclose(logits, golden_parity["logits_f64"], atol=TOL_LOGITS, rtol=0)
     np.testing.assert_allclose(probs, golden_parity["probs_f64"], atol=TOL_PROBS, rtol=0)
     safe = golden_parity["top2_margin"] > MARGIN
@@ -184,7 +187,7 @@ def engine_mm(weights):
     e.close()
 
 
-def test_matrix_core_f32_logits_probs_ids_vs_golden(engine_mm, parity_images, golden_parity):
+def test_matrix_core_f32_logits_probs_ids_vs_golden(engine_mm, parity_images, golden_parity, record):
     ids, probs, logits = [], [], []
     for i in range(0, len(parity_images), 8):
         a, b = engine_mm.forward_u8(parity_images[i:i + 8])
@@ -192,6 +195,10 @@ def test_matrix_core_f32_logits_probs_ids_vs_golden(engine_mm, parity_images, go
         probs.append(b)
         logits.append(engine_mm.tap("d3.relu", len(a)).copy())
     ids, probs, logits = np.concatenate(ids), np.concatenate(probs), np.concatenate(logits)
+    record("parity_set_64_images_224", "f32_matrix_core_path", {
+        "max_abs_dlogit_vs_fp64": float(np.abs(logits - golden_parity["logits_f64"]).max()), "tolerance_logits": TOL_LOGITS,
+        "max_abs_dprob_vs_fp64": float(np.abs(probs - golden_parity["probs_f64"]).max()), "tolerance_probs": TOL_PROBS,
+        "frozen_info": engine_mm.frozen_info()})
     np.testing.assert_allclose(logits, golden_parity["logits_f64"], atol=TOL_LOGITS, rtol=0)
     np.testing.assert_allclose(probs, golden_parity["probs_f64"], atol=TOL_PROBS, rtol=0)
     safe = golden_parity["top2_margin"] > MARGIN
