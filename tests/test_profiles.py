@@ -101,8 +101,14 @@ def test_kernel_trace_agrees_with_live_event_timing():
     tag = os.path.basename(ks)[:-len("_kernel_stats.csv")]
     b = json.load(open(os.path.join(PROF, tag + "_bench.json")))
     rows = list(csv.DictReader(open(ks)))
-    top = max((r for r in rows if "stage" in r["Name"]), key=lambda r: float(r["AverageNs"]))
-    # the profiler's own overhead and box-to-box spread stay within 12 %
     r = b["roofline"]
+    if "launches" in r:
+        # the dominant launch's kernel; of its instantiations in the trace (the run also times the arm that convolves the
+        # frozen channels: another instantiation, fewer calls) the one the timed passes ran
+        family = r["launches"][r["dominant"]]["kernel"].split()[0].rstrip(",")
+        top = max((q for q in rows if family in q["Name"]), key=lambda q: int(q["Calls"]))
+    else:
+        top = max((q for q in rows if "stage" in q["Name"]), key=lambda q: float(q["AverageNs"]))
+    # the profiler's own overhead and box-to-box spread stay within 12 %
     live_ms = r["launches"][r["dominant"]]["ms"] if "launches" in r else r["kernel_ms"]
     assert abs(float(top["AverageNs"]) * 1e-6 - live_ms) <= 0.12 * live_ms
