@@ -179,28 +179,38 @@ __global__ __launch_bounds__(512, 2) void stage23x_kernel(const Stage23Args a) {
     // ReLU6 -> fp16 pairs -> vertical pair sums; the pooling operand of the tile half = [pair sums two rows back | current]
     // Cut into six slices (per 16-cout half: pack rows 0-1, pack rows 2-3, pair sums + operand), so that the slices of tile k
     // can ride behind the MFMA pairs of tile k + 1's chain (the wave's other accumulator pair): with_finish() below.
-    auto finish_part = [&](auto PARTC, auto PRC, const f32x4 (&acc)[2], int (&hp)[2][2], int (&q0)[2][2], int (&q1)[2][2], i32x4 (&op)[2],
+    auto finish_part = [&](auto PARTC, auto PRC, const f32x4 (&acc)[2], int (&hp)[2][2], auto& q0, auto& q1, i32x4 (&op)[2],
                            int (&vt)[2][2]) __attribute__((always_inline)) {
-        constexpr int part = decltype(PARTC)::value, PR = decltype(PRC)::value;
+        constexpr int part = decltype(PARTC)::value, PQ = decltype(PRC)::value, PR = PQ & 1, HI = (PQ >> 1) & 1;      // PRC = row mod 4
         constexpr int h = part / 3, sub = part % 3;
         if constexpr (sub == 0) vt[h][0] = static_cast<int>(pack2_relu6_sixth(acc[h][0], acc[h][1]));
         if constexpr (sub == 1) vt[h][1] = static_cast<int>(pack2_relu6_sixth(acc[h][2], acc[h][3]));
         if constexpr (sub == 2) {
-            int(&qold)[2] = PR == 0 ? q0[h] : q1[h];
             const int n0 = pk_add_f16(hp[h][0], vt[h][0]), n1 = pk_add_f16(hp[h][1], vt[h][1]);
             hp[h][0] = vt[h][0];
             hp[h][1] = vt[h][1];
-            op[h] = i32x4{qold[0], qold[1], n0, n1};
-            qold[0] = n0;
-            qold[1] = n1;
+            if constexpr (NB) {
+                // the operand quad of this row parity lives in place: the pooling matrix weighs its two K halves alike (pm), so
+                // the new pair sums overwrite the half that held the pair sums of four rows ago and nothing is moved (the
+                // products are exact in fp32: the order of the halves does not change a bit)
+                auto& Q = PR == 0 ? q0[h] : q1[h];
+                Q[2 * HI] = n0;
+                Q[2 * HI + 1] = n1;
+                op[h] = Q;
+            } else {
+                auto& qold = PR == 0 ? q0[h] : q1[h];
+                op[h] = i32x4{qold[0], qold[1], n0, n1};
+                qold[0] = n0;
+                qold[1] = n1;
+            }
         }
     };
-    auto finish = [&](auto PRC, const f32x4 (&acc)[2], int (&hp)[2][2], int (&q0)[2][2], int (&q1)[2][2], i32x4 (&op)[2]) __attribute__((always_inline)) {
+    auto finish = [&](auto PRC, const f32x4 (&acc)[2], int (&hp)[2][2], auto& q0, auto& q1, i32x4 (&op)[2]) __attribute__((always_inline)) {
         int vt[2][2];
         [&]<int... I>(std::integer_sequence<int, I...>) { (finish_part(IC<I>{}, PRC, acc, hp, q0, q1, op, vt), ...); }(std::make_integer_sequence<int, 6>{});
     };
     // chain hook = `base` (DMA / bookkeeping) + slice i - 1 of the previous tile's finish behind MFMA pair i = 1 .. 6
-    auto with_finish = [&](auto&& base, auto PRC, const f32x4 (&acc)[2], int (&hp)[2][2], int (&q0)[2][2], int (&q1)[2][2], i32x4 (&op)[2],
+    auto with_finish = [&](auto&& base, auto PRC, const f32x4 (&acc)[2], int (&hp)[2][2], auto& q0, auto& q1, i32x4 (&op)[2],
                            int (&vt)[2][2]) __attribute__((always_inline)) {
         return [&, PRC](auto IC_) __attribute__((always_inline)) {
             constexpr int i = decltype(IC_)::value;
@@ -315,13 +325,21 @@ __global__ __launch_bounds__(512, 2) void stage23x_kernel(const Stage23Args a) {
             scv[h] = *reinterpret_cast<const f32x4*>(a.ptab + 8 * g + 4 * h);
             shv[h] = *reinterpret_cast<const f32x4*>(a.ptab + 32 + 8 * g + 4 * h);
         }
-        int hp[4][2][2], q0[4][2][2], q1[4][2][2];
+        int hp[4][2][2];
+        std::conditional_t<NB, i32x4[4][2], int[4][2][2]> q0, q1;      // pair sums of the last rows of either parity (NB: the operand quads)
 #pragma unroll
         for (int k = 0; k < 4; ++k)
 #pragma unroll
             for (int h = 0; h < 2; ++h)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) hp[k][h][j] = q0[k][h][j] = q1[k][h][j] = 0;
+                for (int j = 0; j < 2; ++j) {
+                    hp[k][h][j] = 0;
+                    if constexpr (NB) {
+                        q0[k][h][2 * j] = q0[k][h][2 * j + 1] = q1[k][h][2 * j] = q1[k][h][2 * j + 1] = 0;
+                    } else {
+                        q0[k][h][j] = q1[k][h][j] = 0;
+                    }
+                }
         issue_A_pieces(a_next, 0);
         int ylo_nxt = ylo_step(0);                       // lo skip row of the output row the coming step finishes
         wait_vmcnt<0>();
@@ -384,8 +402,8 @@ __global__ __launch_bounds__(512, 2) void stage23x_kernel(const Stage23Args a) {
             }(std::make_integer_sequence<int, X_KT>{});
         };
         // the first-half finish of two tiles behind MFMA pairs 1 .. 6 of the next chain
-        [[maybe_unused]] auto with_finish2 = [&](auto&& base, auto PRC, const f32x4 (&accx)[2], int (&hpx)[2][2], int (&q0x)[2][2], int (&q1x)[2][2], i32x4 (&opx)[2],
-                                const f32x4 (&accy)[2], int (&hpy)[2][2], int (&q0y)[2][2], int (&q1y)[2][2], i32x4 (&opy)[2], int (&vt)[2][2]) __attribute__((always_inline)) {
+        [[maybe_unused]] auto with_finish2 = [&](auto&& base, auto PRC, const f32x4 (&accx)[2], int (&hpx)[2][2], auto& q0x, auto& q1x, i32x4 (&opx)[2],
+                                const f32x4 (&accy)[2], int (&hpy)[2][2], auto& q0y, auto& q1y, i32x4 (&opy)[2], int (&vt)[2][2]) __attribute__((always_inline)) {
             return [&, PRC](auto IC_) __attribute__((always_inline)) {
                 constexpr int i = decltype(IC_)::value;
                 base(IC_);
@@ -393,7 +411,7 @@ __global__ __launch_bounds__(512, 2) void stage23x_kernel(const Stage23Args a) {
                 if constexpr (i >= 4 && i <= 6) finish_part(IC<(i >= 4 && i <= 6 ? i - 4 : 0)>{}, PRC, accy, hpy, q0y, q1y, opy, vt);
             };
         };
-        [[maybe_unused]] auto finish1 = [&](auto PRC, const f32x4 (&acc)[2], int (&hpx)[2][2], int (&q0x)[2][2], int (&q1x)[2][2], i32x4 (&opx)[2]) __attribute__((always_inline)) {
+        [[maybe_unused]] auto finish1 = [&](auto PRC, const f32x4 (&acc)[2], int (&hpx)[2][2], auto& q0x, auto& q1x, i32x4 (&opx)[2]) __attribute__((always_inline)) {
             int vt[2][2];
             finish_part(IC<0>{}, PRC, acc, hpx, q0x, q1x, opx, vt);
             finish_part(IC<1>{}, PRC, acc, hpx, q0x, q1x, opx, vt);
@@ -439,7 +457,7 @@ __global__ __launch_bounds__(512, 2) void stage23x_kernel(const Stage23Args a) {
         };
         auto step = [&](auto PC, int t) __attribute__((always_inline)) {
             constexpr int P = decltype(PC)::value;
-            constexpr int PR = P & 1;
+            [[maybe_unused]] constexpr int PR = P & 1;
             if (t < nrows + 9) a_next += Win * 64;
             // A row t+1: two DMA pieces behind MFMA pairs of the first tile's chain, two behind the second's.  Skip rows of the
             // partner consumer: decided behind the first chain's MFMAs, fetched behind the third tile's; when no new row is
@@ -494,18 +512,18 @@ __global__ __launch_bounds__(512, 2) void stage23x_kernel(const Stage23Args a) {
                 chain2(IC<(P + 2) % 4>{}, IC<0>{}, IC<1>{}, ac0[0], ac1[0], hookA);
                 if (has4) {
                     chain2(IC<(P + 2) % 4>{}, IC<2>{}, IC<3>{}, ac2[0], ac3[0],
-                           with_finish2(hook2, IC<PR>{}, ac0, hp[0], q0[0], q1[0], op[0], ac1, hp[1], q0[1], q1[1], op[1], vt));
+                           with_finish2(hook2, IC<(P & 3)>{}, ac0, hp[0], q0[0], q1[0], op[0], ac1, hp[1], q0[1], q1[1], op[1], vt));
                     out1(IC<0>{}, PC, op[0], op[1], true);
-                    finish1(IC<PR>{}, ac2, hp[2], q0[2], q1[2], op[2]);
+                    finish1(IC<(P & 3)>{}, ac2, hp[2], q0[2], q1[2], op[2]);
                     out1(IC<1>{}, PC, op[1], op[2], true);
-                    finish1(IC<PR>{}, ac3, hp[3], q0[3], q1[3], op[3]);
+                    finish1(IC<(P & 3)>{}, ac3, hp[3], q0[3], q1[3], op[3]);
                     out1(IC<2>{}, PC, op[2], op[3], true);
                     out1(IC<3>{}, PC, op[3], op[3], false);
                 } else {
                     chain1(IC<(P + 2) % 4>{}, IC<2>{}, ac2[0],
-                           with_finish2(hook2, IC<PR>{}, ac0, hp[0], q0[0], q1[0], op[0], ac1, hp[1], q0[1], q1[1], op[1], vt));
+                           with_finish2(hook2, IC<(P & 3)>{}, ac0, hp[0], q0[0], q1[0], op[0], ac1, hp[1], q0[1], q1[1], op[1], vt));
                     out1(IC<0>{}, PC, op[0], op[1], true);
-                    finish1(IC<PR>{}, ac2, hp[2], q0[2], q1[2], op[2]);
+                    finish1(IC<(P & 3)>{}, ac2, hp[2], q0[2], q1[2], op[2]);
                     out1(IC<1>{}, PC, op[1], op[2], true);
                     out1(IC<2>{}, PC, op[2], op[3], true);         // op[3] = 0, and columns 13..15 of the third tile go to the dummy column
                 }
@@ -520,17 +538,17 @@ __global__ __launch_bounds__(512, 2) void stage23x_kernel(const Stage23Args a) {
             i32x4 op[4][2];
             op[3][0] = op[3][1] = i32x4{0, 0, 0, 0};
             chain(IC<(P + 2) % 4>{}, IC<X_ROWA>{}, IC<0>{}, baseA, w2, accA, hook0);      // conv row t-2: A rows t-2 .. t
-            chain(IC<(P + 2) % 4>{}, IC<X_ROWA>{}, IC<1>{}, baseA, w2, accB, with_finish(hook1, IC<PR>{}, accA, hp[0], q0[0], q1[0], op[0], vt));
-            chain(IC<(P + 2) % 4>{}, IC<X_ROWA>{}, IC<2>{}, baseA, w2, accA, with_finish(hook2, IC<PR>{}, accB, hp[1], q0[1], q1[1], op[1], vt));
+            chain(IC<(P + 2) % 4>{}, IC<X_ROWA>{}, IC<1>{}, baseA, w2, accB, with_finish(hook1, IC<(P & 3)>{}, accA, hp[0], q0[0], q1[0], op[0], vt));
+            chain(IC<(P + 2) % 4>{}, IC<X_ROWA>{}, IC<2>{}, baseA, w2, accA, with_finish(hook2, IC<(P & 3)>{}, accB, hp[1], q0[1], q1[1], op[1], vt));
             out(IC<0>{}, PC, op[0], op[1], true);
             if (has4) {
-                chain(IC<(P + 2) % 4>{}, IC<X_ROWA>{}, IC<3>{}, baseA, w2, accB, with_finish(no_hook, IC<PR>{}, accA, hp[2], q0[2], q1[2], op[2], vt));
+                chain(IC<(P + 2) % 4>{}, IC<X_ROWA>{}, IC<3>{}, baseA, w2, accB, with_finish(no_hook, IC<(P & 3)>{}, accA, hp[2], q0[2], q1[2], op[2], vt));
                 out(IC<1>{}, PC, op[1], op[2], true);
-                finish(IC<PR>{}, accB, hp[3], q0[3], q1[3], op[3]);
+                finish(IC<(P & 3)>{}, accB, hp[3], q0[3], q1[3], op[3]);
                 out(IC<2>{}, PC, op[2], op[3], true);
                 out(IC<3>{}, PC, op[3], op[3], false);
             } else {
-                finish(IC<PR>{}, accA, hp[2], q0[2], q1[2], op[2]);
+                finish(IC<(P & 3)>{}, accA, hp[2], q0[2], q1[2], op[2]);
                 out(IC<1>{}, PC, op[1], op[2], true);
                 out(IC<2>{}, PC, op[2], op[3], true);         // op[3] = 0, and columns 13..15 of the third tile go to the dummy column
             }
@@ -630,13 +648,21 @@ __global__ __launch_bounds__(512, 2) void stage23x_kernel(const Stage23Args a) {
     const unsigned tabl_lds = lds_addr(tab + 64 + 8 * g);
     const int out_row_bytes = Hout * 64;
     const char* out_row = reinterpret_cast<const char*>(a.out + static_cast<int64_t>(n) * Hout * Hout * 32) + static_cast<int64_t>(yo0) * out_row_bytes;
-    int hp[4][2][2], q0[4][2][2], q1[4][2][2];
+    int hp[4][2][2];
+    std::conditional_t<NB, i32x4[4][2], int[4][2][2]> q0, q1;
 #pragma unroll
     for (int k = 0; k < 4; ++k)
 #pragma unroll
         for (int h = 0; h < 2; ++h)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) hp[k][h][j] = q0[k][h][j] = q1[k][h][j] = 0;
+            for (int j = 0; j < 2; ++j) {
+                    hp[k][h][j] = 0;
+                    if constexpr (NB) {
+                        q0[k][h][2 * j] = q0[k][h][2 * j + 1] = q1[k][h][2 * j] = q1[k][h][2 * j + 1] = 0;
+                    } else {
+                        q0[k][h][j] = q1[k][h][j] = 0;
+                    }
+                }
     struct RowCtx {
         float yl;
         unsigned sk_lo, sk_hi;
@@ -766,7 +792,7 @@ __global__ __launch_bounds__(512, 2) void stage23x_kernel(const Stage23Args a) {
     };
     auto step = [&](auto PC, int t) __attribute__((always_inline)) {
         constexpr int P = decltype(PC)::value;
-        constexpr int PR = P & 1;
+        [[maybe_unused]] constexpr int PR = P & 1;
         const int jo = t - X_LAG;
         cx.yl = vl_cur.yl;
         cx.sk_lo = static_cast<unsigned>(slot_cur * X_SKROW);
@@ -800,24 +826,24 @@ __global__ __launch_bounds__(512, 2) void stage23x_kernel(const Stage23Args a) {
             if constexpr (decltype(IC_)::value == 7) vl_pre = vlerp_of(yo0 + min(max(jo + 2, 0), nrows - 1));
         };
         cchain(IC<P>{}, IC<0>{}, accA, no_hook);           // conv row t-8: B rows t-8 .. t-6
-        cchain(IC<P>{}, IC<1>{}, accB, with_finish(no_hook, IC<PR>{}, accA, hp[0], q0[0], q1[0], op[0], vt));
+        cchain(IC<P>{}, IC<1>{}, accB, with_finish(no_hook, IC<(P & 3)>{}, accA, hp[0], q0[0], q1[0], op[0], vt));
         wait_vmcnt<0>();                                       // a skip row fetched at the top of this step has landed
         out_reads(IC<0>{}, R);
-        cchain(IC<P>{}, IC<2>{}, accA, with_finish(hook_c2, IC<PR>{}, accB, hp[1], q0[1], q1[1], op[1], vt));
+        cchain(IC<P>{}, IC<2>{}, accA, with_finish(hook_c2, IC<(P & 3)>{}, accB, hp[1], q0[1], q1[1], op[1], vt));
         out_rest(IC<0>{}, R, op[0], op[1], true);
         if (has4) {
             out_reads(IC<1>{}, R);
-            cchain(IC<P>{}, IC<3>{}, accB, with_finish(no_hook, IC<PR>{}, accA, hp[2], q0[2], q1[2], op[2], vt));
+            cchain(IC<P>{}, IC<3>{}, accB, with_finish(no_hook, IC<(P & 3)>{}, accA, hp[2], q0[2], q1[2], op[2], vt));
             out_rest(IC<1>{}, R, op[1], op[2], true);
             out_reads(IC<2>{}, R);
-            finish(IC<PR>{}, accB, hp[3], q0[3], q1[3], op[3]);
+            finish(IC<(P & 3)>{}, accB, hp[3], q0[3], q1[3], op[3]);
             __builtin_amdgcn_sched_barrier(0);
             out_rest(IC<2>{}, R, op[2], op[3], true);
             out_reads(IC<3>{}, R);
             out_rest(IC<3>{}, R, op[3], op[3], false);
         } else {
             out_reads(IC<1>{}, R);
-            finish(IC<PR>{}, accA, hp[2], q0[2], q1[2], op[2]);
+            finish(IC<(P & 3)>{}, accA, hp[2], q0[2], q1[2], op[2]);
             __builtin_amdgcn_sched_barrier(0);
             out_rest(IC<1>{}, R, op[1], op[2], true);
             out_reads(IC<2>{}, R);
