@@ -1,7 +1,7 @@
 #!/bin/bash
-# GPU box: throughput / latency over the batch size for the three handle types (bench.py, inputs resident in HBM) -> gpurun_out/r4/batch_sweep.txt
+# GPU box: throughput / latency over the batch size for the three handle types (bench.py, inputs resident in HBM) -> gpurun_out/r5/batch_sweep.txt
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/r4
+mkdir -p gpurun_out/r5
 {
 echo "# bench.py --batch B --dtype D --steps K --warmup 5 (one MI355X, 224 x 224, inputs resident in HBM): ms per forward pass = latency of one call"
 echo "# dtype batch   img/s     ms/pass   launch groups"
@@ -12,4 +12,4 @@ import sys,json
 d=json.loads(sys.stdin.readline())
 print('%-5s %4d %9.0f   %8.4f   %s' % ('$dt', $b, d['value'], d['ms_per_step'], d['path']['launch_groups']))"
 done; done
-} 2>&1 | tee gpurun_out/r4/batch_sweep.txt
+} 2>&1 | tee gpurun_out/r5/batch_sweep.txt
