@@ -428,9 +428,10 @@ class Engine:
         return out
 
     def frozen_info(self) -> Dict[str, int]:
-        """What rn_create folded on this handle (``rn_frozen_info``): channels of the fused pair's on-chip tensor that are
-        provably constant and not convolved, how many were proven, the residual stage whose frozen first-BN channels are
-        folded and how many of its 16-cout quarters still run their convolution."""
+        """What rn_create folded on this handle (``rn_frozen_info``): channels of the first 32 -> 32 stage's output (16-bit
+        handles: the fused pair's on-chip tensor) that are provably constant and not convolved / not contracted by the next
+        stage, how many were proven, the residual stage whose frozen first-BN channels are folded and how many of its 16-cout
+        quarters still run their convolution."""
         info = (C.c_int * 4)(0, 0, -1, 4)
         if hasattr(self.lib, "rn_frozen_info"):      # (older libraries loaded as A/B arms fold nothing)
             _check(self.lib, self.lib.rn_frozen_info(self.handle, info), "rn_frozen_info")
