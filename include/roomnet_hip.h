@@ -86,11 +86,13 @@ extern "C" {
                                as one launch per image, rn_backend.hip; rn_tap refuses them) */
 #define RN_FLAG_GENERIC_KERNELS 4u /* 16-bit handles: every stage on the generic
                                stage_mfma_kernel (diagnostic cross-check of the tuned kernels) */
-#define RN_FLAG_COMPUTE_FROZEN 16u /* 16-bit handles: compute every channel of the fused pair's on-chip tensor.  By default
-                                    * channels that rn_create PROVES constant (the stored 16-bit value is the same number
-                                    * for every possible input: BN gammas the reference's L2 regulariser drove to ~1e-20)
-                                    * are written from a table instead of being convolved -- the same bits; this flag is
-                                    * the comparison arm that shows it. */
+#define RN_FLAG_COMPUTE_FROZEN 16u /* convolve every channel.  By default channels that rn_create PROVES constant (the stored
+                                    * value is the same number for every possible input: BN gammas the reference's L2
+                                    * regulariser drove to ~1e-20) are written from a table instead of being convolved and
+                                    * enter the next convolution as one constant per cout -- 16-bit handles (the fused
+                                    * pair's on-chip tensor, the 64 -> 64 residual stage) and float32 matrix-core handles
+                                    * (the same stages) alike; this flag is the comparison arm that shows it.  See
+                                    * rn_frozen_info. */
 #define RN_FLAG_PAIR_32X32 8u /* 16-bit handles: the round-2 kernels instead of the round-3 ones (comparison
                                arm, bench.py --pair32): the cross-stage fused pair of the 32-channel block
                                (network.py:183-203: rn_stage23.hip instead of rn_stage23x.hip; equal up to the fp32 order of

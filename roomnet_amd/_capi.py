@@ -19,7 +19,7 @@ RN_FLAG_TAPS = 1
 RN_FLAG_STAGE_LAUNCHES = 2      # 16-bit handles: one launch per conv stage (no cross-stage fusion)
 RN_FLAG_GENERIC_KERNELS = 4     # 16-bit handles: generic stage kernel everywhere (diagnostic cross-check)
 RN_FLAG_PAIR_32X32 = 8          # 16-bit handles: the fused stage pair on the round-2 32x32x16 kernel (comparison arm)
-RN_FLAG_COMPUTE_FROZEN = 16     # 16-bit handles: convolve the provably constant channels too (comparison arm: same bits)
+RN_FLAG_COMPUTE_FROZEN = 16     # convolve the provably constant channels too (comparison arm of the frozen-channel folding)
 RN_MAX_STAGES = 16
 RN_MAX_DENSE = 8
 RN_NAME_LEN = 32
