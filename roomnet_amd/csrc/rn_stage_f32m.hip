@@ -358,6 +358,18 @@ __global__ __launch_bounds__(512) void stage_f32m_kernel(const F32StageArgs a) {
 // the ring each), partial sums meet in LDS and are added in a fixed order by the first.
 __device__ __forceinline__ f32x4 mfma_f32_16(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 
+// chunk swizzle of the 16-column kernel's ring: a ds_read_b128 lane group mixes two k groups here (lanes {0-3, 12-15} of k group 0 with
+// {20-27} of k group 1, ...), so the 32-channel ring (8 chunks per pixel) takes ((pixel >> 1) & 3) << 1 -- every group reads 16 distinct
+// 16-byte slots of the bank row at every tile offset (chunk_swz<8>, made for 32 pixels reading one chunk index, left 1.7 LDS cycles per
+// read: 38 % conflict cycles, profiles/r5_c_f32_mfma_busy.txt)
+template <int CP>
+__device__ __forceinline__ int m16_swz(int pix) {
+    if constexpr (CP == 8)
+        return ((pix >> 1) & 3) << 1;
+    else
+        return chunk_swz<CP>(pix);
+}
+
 // PS = 1, CFZ = 16: the first 32 -> 32 stage (avg-pool 4/1) of a handle whose rn_create proved 16 of its output channels constant
 // and relabelled them to the end: the 16 live couts are convolved (13 pooled columns per tile: stride 13), the other 16 channels of
 // the 32-channel output pixel are written as their constant (beta) -- the tensor in HBM is complete, the next stage does not
@@ -419,7 +431,7 @@ __global__ __launch_bounds__(576) void stage_f32m16_kernel(const F32StageArgs a)
     for (int i = 0; i < LPT; ++i) {
         const int q = tid + i * nthreads;
         const int p = q / CP, c4 = q % CP;
-        ld_loff[i] = q < nchunks ? (p * CP + (c4 ^ chunk_swz<CP>(p))) * 16 : -1;
+        ld_loff[i] = q < nchunks ? (p * CP + (c4 ^ m16_swz<CP>(p))) * 16 : -1;
         ld_goff[i] = (q < nchunks ? min(x0c + p, a.W - 1) : 0) * CIN + c4 * 4;
     }
     f32x4 pre[LPT];
@@ -445,7 +457,7 @@ __global__ __launch_bounds__(576) void stage_f32m16_kernel(const F32StageArgs a)
 #pragma unroll
     for (int kx = 0; kx < 3; ++kx) {
         boff[kx] = (xrel0 + kx) * PIXB;
-        bswz[kx] = chunk_swz<CP>(xrel0 + kx);
+        bswz[kx] = m16_swz<CP>(xrel0 + kx);
     }
     const int xc = x0c + xrel0;
     const int xo = xc / PS;
