@@ -84,3 +84,21 @@ def pytest_sessionfinish(session, exitstatus):
     doc.update(_PARITY)
     with open(path, "w") as f:
         json.dump(doc, f, indent=1, sort_keys=True)
+
+
+def with_gammas(weights, bn2_frozen, bn6_frozen, seed):
+    """The shipped checkpoint with OTHER frozen channels: every gamma of batch_normalization_2 (stage 2's BN) and _6 (stage 5's
+    first BN) set to a trained-looking value, the listed channels to 1e-24 (their betas to a visible constant)."""
+    rng = np.random.default_rng(seed)
+    w = dict(weights)
+    for name, frozen in (("batch_normalization_2", bn2_frozen), ("batch_normalization_6", bn6_frozen)):
+        n = len(w[name + "/gamma"])
+        g = rng.uniform(0.05, 0.4, n).astype(np.float32) * rng.choice([-1.0, 1.0], n).astype(np.float32)
+        b = w[name + "/beta"].copy()
+        for c in frozen:
+            g[c] = np.float32(1e-24)
+            b[c] = np.float32(rng.uniform(0.002, 0.02))
+        w[name + "/gamma"] = g
+        w[name + "/beta"] = b
+        w[name + "/moving_variance"] = np.maximum(w[name + "/moving_variance"], np.float32(0.05))
+    return w

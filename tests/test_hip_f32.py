@@ -6,7 +6,7 @@ probs abs <= 1e-5, ids identical where the top-2 margin > 1e-3; per-node max err
 import numpy as np
 import pytest
 
-from conftest import sample_positions
+from conftest import sample_positions, with_gammas
 from oracle import c_oracle, roomnet_ref as R
 from roomnet_amd import _capi
 from roomnet_amd.graph import build_graph
@@ -310,3 +310,35 @@ def test_matrix_core_f32_folds_stage_5_frozen_channels(weights, parity_images):
     finally:
         fold.close()
         full.close()
+
+
+@pytest.mark.parametrize("case", ["none", "nine_and_31", "other_sets", "everything"])
+def test_matrix_core_f32_fold_on_other_checkpoints(weights, parity_images, case):
+    """The float32 folds are a property of the CHECKPOINT too: frozen channels elsewhere, too few of them for a kernel variant
+    (9 in stage 2: the relabelling happens, every channel is still contracted), or all of them (a stage needs live input
+    channels) -- the handle folds what it can and agrees with the oracle on every stage output."""
+    g = build_graph(6, 224)
+    rng = np.random.default_rng(6)
+    if case == "none":
+        w, want = with_gammas(weights, [], [], 1), {"pair_channels_not_convolved": 0, "residual_stage_folded": -1}
+    elif case == "nine_and_31":
+        w, want = with_gammas(weights, rng.choice(32, 9, replace=False), rng.choice(64, 31, replace=False), 2), {"pair_channels_not_convolved": 0, "residual_stage_folded": -1}
+    elif case == "other_sets":
+        w, want = with_gammas(weights, rng.choice(32, 17, replace=False), rng.choice(64, 40, replace=False), 3), {
+            "pair_channels_not_convolved": 16, "pair_channels_proven_frozen": 17, "residual_stage_folded": 5, "residual_stage_live_quarters": 2}
+    else:
+        w, want = with_gammas(weights, range(32), range(64), 4), {"pair_channels_not_convolved": 0, "residual_stage_folded": 5}
+    ims = parity_images[[14, 30, 2, 52]]
+    ref = c_oracle.infer(w, ims, taps=True)
+    e = _capi.Engine(g, w, device=0, dtype="f32", max_batch=4)
+    try:
+        info = e.frozen_info()
+        for k, v in want.items():
+            assert info[k] == v, (case, info)
+        ids, probs = e.forward_u8(ims)
+        for name in ("s1.bn", "s2.bn", "s3.bn2", "s4.bn", "s5.bn2", "s6.bn", "s8.bn", "s9.bn2"):
+            got, ref_t = e.tap(name, 4), np.asarray(ref["taps"][name])
+            assert float(np.abs(got - ref_t).max()) <= 1e-4 * max(float(np.abs(ref_t).max()), 1e-3), (case, name)
+        np.testing.assert_allclose(probs, ref["probs"], atol=2e-5, rtol=0)
+    finally:
+        e.close()

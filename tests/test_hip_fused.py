@@ -8,6 +8,7 @@ the error compounds over ten stages)."""
 import numpy as np
 import pytest
 
+from conftest import with_gammas
 from oracle import c_oracle
 from roomnet_amd import _capi
 from roomnet_amd.graph import build_graph
@@ -847,24 +848,6 @@ def test_frozen_channels_fold_against_computing_them(weights, parity_images, dty
             full.close()
 
 
-def _with_gammas(weights, bn2_frozen, bn6_frozen, seed):
-    """The shipped checkpoint with OTHER frozen channels: every gamma of batch_normalization_2 (stage 2's BN) and _6 (stage 5's
-    first BN) set to a trained-looking value, the listed channels to 1e-24 (their betas to a visible constant)."""
-    rng = np.random.default_rng(seed)
-    w = dict(weights)
-    for name, frozen in (("batch_normalization_2", bn2_frozen), ("batch_normalization_6", bn6_frozen)):
-        n = len(w[name + "/gamma"])
-        g = rng.uniform(0.05, 0.4, n).astype(np.float32) * rng.choice([-1.0, 1.0], n).astype(np.float32)
-        b = w[name + "/beta"].copy()
-        for c in frozen:
-            g[c] = np.float32(1e-24)
-            b[c] = np.float32(rng.uniform(0.002, 0.02))
-        w[name + "/gamma"] = g
-        w[name + "/beta"] = b
-        w[name + "/moving_variance"] = np.maximum(w[name + "/moving_variance"], np.float32(0.05))
-    return w
-
-
 @pytest.mark.parametrize("case", ["none", "stage2_only_15_and_17", "both_other_sets", "everything_of_stage2"])
 def test_frozen_channel_fold_on_other_checkpoints(weights, parity_images, case):
     """The fold is a property of the CHECKPOINT, proven at rn_create: checkpoints whose frozen channels sit elsewhere (or nowhere)
@@ -872,14 +855,14 @@ def test_frozen_channel_fold_on_other_checkpoints(weights, parity_images, case):
     g = build_graph(6, 224)
     rng = np.random.default_rng(5)
     if case == "none":
-        w, want = _with_gammas(weights, [], [], 1), {"pair_channels_not_convolved": 0, "residual_stage_folded": -1}
+        w, want = with_gammas(weights, [], [], 1), {"pair_channels_not_convolved": 0, "residual_stage_folded": -1}
     elif case == "stage2_only_15_and_17":
         # 15 frozen channels: one short of a half -> nothing folded in the pair; 31 in stage 5: one short of two quarters
-        w, want = _with_gammas(weights, rng.choice(32, 15, replace=False), rng.choice(64, 31, replace=False), 2), {"pair_channels_not_convolved": 0, "residual_stage_folded": -1}
+        w, want = with_gammas(weights, rng.choice(32, 15, replace=False), rng.choice(64, 31, replace=False), 2), {"pair_channels_not_convolved": 0, "residual_stage_folded": -1}
     elif case == "both_other_sets":
-        w, want = _with_gammas(weights, rng.choice(32, 17, replace=False), rng.choice(64, 40, replace=False), 3), {"pair_channels_not_convolved": 16, "residual_stage_folded": 5, "residual_stage_live_quarters": 2}
+        w, want = with_gammas(weights, rng.choice(32, 17, replace=False), rng.choice(64, 40, replace=False), 3), {"pair_channels_not_convolved": 16, "residual_stage_folded": 5, "residual_stage_live_quarters": 2}
     else:
-        w, want = _with_gammas(weights, range(32), range(64), 4), {"pair_channels_not_convolved": 16, "pair_channels_proven_frozen": 32, "residual_stage_folded": 5}
+        w, want = with_gammas(weights, range(32), range(64), 4), {"pair_channels_not_convolved": 16, "pair_channels_proven_frozen": 32, "residual_stage_folded": 5}
     ims = parity_images[[14, 30, 2, 52]]
     ref = c_oracle.infer(w, ims, taps=True)
     for dtype in ("bf16", "f16"):
