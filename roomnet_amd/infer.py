@@ -153,8 +153,21 @@ def force_makedir(dir):
         os.makedirs(dir)
 
 
+def _overlay_and_write(im, pred_label, pred_conf, out_fpath):
+    """infer.py:87-93 for one image: the two overlay lines, then the file."""
+    h, w, _ = im.shape
+    put_text(im, "Predicted Class: " + pred_label, (int(.5 * w), int(.90 * h)), (h / 720.) * .85, (0, 255, 0))
+    put_text(im, "Confidence: " + str(round(pred_conf * 100, 2)) + " %", (int(.5 * w), int(.95 * h)),
+             (h / 720.) * .85, (255, 0, 0))
+    return imwrite(out_fpath, im)
+
+
 def classify_im_dir(nn, imgs_dir, overlay=True, batch_size=64):
-    """infer.py:65-100."""
+    """infer.py:65-100.  The overlay and the encoding of the output file (the reference does both between two ``sess.run`` calls)
+    run on a second thread pool behind the loop -- per 1920 x 1080 image they cost what decoding it cost -- and the function
+    returns when every file is written; printed lines, workbook rows and file names are the loop's, in list order."""
+    from collections import deque
+    from concurrent.futures import ThreadPoolExecutor
     print('Classifying images in', imgs_dir)
     all_im_paths = glob(imgs_dir + '/*')
     out_dir = imgs_dir + '_classified'
@@ -168,23 +181,30 @@ def classify_im_dir(nn, imgs_dir, overlay=True, batch_size=64):
     sheet.write(0, 0, 'IMAGE_NAME')
     sheet.write(0, 1, 'PREDICTED_LABEL')
     row = 0      # unreadable files are skipped (the reference crashes on them): rows stay contiguous
-    for i, im, idx, pred_conf in _infer_files(nn, all_im_paths, batch_size):
-        fpath = all_im_paths[i]
-        row += 1
-        pred_label = CLASS_LABELS[idx]
-        out_fpath_dir = out_dir + os.sep + pred_label
-        print(fpath, '--->', pred_label, pred_conf)
-        if overlay:
-            h, w, _ = im.shape
-            put_text(im, "Predicted Class: " + pred_label, (int(.5 * w), int(.90 * h)), (h / 720.) * .85, (0, 255, 0))
-            put_text(im, "Confidence: " + str(round(pred_conf * 100, 2)) + " %", (int(.5 * w), int(.95 * h)),
-                     (h / 720.) * .85, (255, 0, 0))
-            imwrite(out_fpath_dir + os.sep + fpath.split(os.sep)[-1], im)
-        else:
-            shutil.copy(fpath, out_fpath_dir)
-        sheet.write(row, 0, fpath.split(os.sep)[-1])
-        sheet.write(row, 1, pred_label)
-        sheet.write(row, 2, str(pred_conf))
+    writers = ThreadPoolExecutor(max_workers=DECODE_THREADS) if overlay else None
+    writing = deque()
+    try:
+        for i, im, idx, pred_conf in _infer_files(nn, all_im_paths, batch_size):
+            fpath = all_im_paths[i]
+            row += 1
+            pred_label = CLASS_LABELS[idx]
+            out_fpath_dir = out_dir + os.sep + pred_label
+            print(fpath, '--->', pred_label, pred_conf)
+            if overlay:
+                writing.append(writers.submit(_overlay_and_write, im, pred_label, pred_conf,
+                                              out_fpath_dir + os.sep + fpath.split(os.sep)[-1]))
+                while len(writing) > 4 * DECODE_THREADS:      # (a bound on the decoded images held for the writers)
+                    writing.popleft().result()
+            else:
+                shutil.copy(fpath, out_fpath_dir)
+            sheet.write(row, 0, fpath.split(os.sep)[-1])
+            sheet.write(row, 1, pred_label)
+            sheet.write(row, 2, str(pred_conf))
+        while writing:
+            writing.popleft().result()
+    finally:
+        if writers is not None:
+            writers.shutdown(wait=True)
     excel_file.save(xl_fpath)
     return xl_fpath
 

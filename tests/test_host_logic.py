@@ -366,3 +366,53 @@ def test_infer_files_decodes_on_a_pool_and_keeps_list_order(tmp_path, capsys):
         assert got == want
         assert Stub.batches == ([3, 3, 3] if bs == 3 else [9])
     assert capsys.readouterr().out.count("unreadable image, skipped") == 4
+
+
+def test_classify_im_dir_writes_overlays_on_the_writer_pool(tmp_path, capsys):
+    """infer.py:65-100 without a GPU (a model object with the reference's ``infer`` only): every readable image lands in its
+    class directory with the two overlay lines drawn into it, the workbook rows follow the loop's order, and the function
+    returns after the writer pool has written the last file."""
+    import glob as _glob
+    from roomnet_amd import imageio
+    from roomnet_amd.infer import CLASS_LABELS, classify_im_dir
+
+    class Stub:
+        im_side = 8
+
+        def center_crop(self, x):
+            h, w, _ = x.shape
+            o = abs((w - h) // 2)
+            return x[:, o:o + h, :] if h < w else (x[o:o + w, :, :] if w < h else x.copy())
+
+        def infer(self, batch):
+            ids = batch[:, 0, 0, 0].astype(np.int64) % 6
+            probs = np.full((len(batch), 6), 0.1, np.float32)
+            probs[np.arange(len(batch)), ids] = 0.5
+            return ids, probs
+
+    d = tmp_path / "imgs"
+    d.mkdir()
+    rng = np.random.default_rng(8)
+    for k in range(23):
+        im = np.full((120, 200, 3), int(rng.integers(20, 60)), np.uint8)       # flat and dark: the overlay is what stands out
+        im[:8, :, :] = rng.integers(0, 256, (8, 200, 3), dtype=np.uint8)
+        assert imageio.imwrite(str(d / ("p_%02d.png" % k)), im)
+    (d / "junk.png").write_bytes(b"no image")
+    xl = classify_im_dir(Stub(), str(d), overlay=True, batch_size=4)
+    out = capsys.readouterr().out
+    listed = [ln.split(" ---> ")[0] for ln in out.splitlines() if " ---> " in ln and "unreadable" not in ln]
+    assert len(listed) == 23 and "unreadable" in out
+    written = sorted(_glob.glob(str(tmp_path / "imgs_classified" / "*" / "*.png")))
+    assert sorted(os.path.basename(p) for p in written) == sorted(os.path.basename(p) for p in listed)
+    for p in written:
+        label = os.path.basename(os.path.dirname(p))
+        assert label in CLASS_LABELS
+        got, src = imageio.imread(p), imageio.imread(str(d / os.path.basename(p)))
+        assert got.shape == src.shape
+        changed = np.abs(got.astype(int) - src.astype(int)).max(axis=2) > 40
+        assert changed[90:, 90:].sum() > 30 and not changed[:60].any()             # text in the lower right half only
+        green, blue = got[..., 1].astype(int) - got[..., 0], got[..., 0].astype(int) - got[..., 1]
+        assert (green[changed] > 100).any() and (blue[changed] > 100).any()         # cv2 colours (0, 255, 0) and (255, 0, 0): B, G, R
+    cells = read_xls(xl)["classification_results"]
+    assert [cells[(r + 1, 0)] for r in range(len(listed))] == [os.path.basename(p) for p in listed]
+    assert all(cells[(r + 1, 1)] in CLASS_LABELS for r in range(len(listed))) and (len(listed) + 1, 0) not in cells

@@ -88,6 +88,9 @@ def directory():
         t0 = time.perf_counter()
         infer.classify_im_dir(nn, d, overlay=False, batch_size=64)
         t_dir = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        infer.classify_im_dir(nn, d, overlay=True, batch_size=64)          # the reference's default: overlay + re-encoded files
+        t_ovl = time.perf_counter() - t0
         lst = os.path.join(root, 'list.txt')
         with open(lst, 'w') as f:
             f.writelines('%s %d\n' % (p, 0) for p in paths)
@@ -99,9 +102,16 @@ def directory():
         for p in paths[:max(8, N // 8)]:
             nn.infer_optimized(imageio.imread(p))
         t_one = (time.perf_counter() - t0) / max(8, N // 8)
+    # what the overlay path cost per image while it ran inside the loop (two put_text + imwrite, one thread)
+    ims = [imageio.imread(p) for p in paths[:max(8, N // 16)]]
+    t0 = time.perf_counter()
+    for k, im in enumerate(ims):
+        infer._overlay_and_write(im, 'LivingRoom', np.float32(0.9987), os.path.join(root, 'ovl_%d.jpg' % k))
+    t_ow = (time.perf_counter() - t0) / len(ims)
     print('%d JPEG files %dx%d (%.0f MB), %d decode threads of %d host cores: classify_im_dir(overlay=False) %.1f img/s   '
+          'classify_im_dir(overlay=True) %.1f img/s (overlay + write alone, one thread: %.1f img/s)   '
           'groundtruth_validation %.1f img/s   decode alone, one thread %.1f img/s   one image per call (reference loop) %.1f img/s'
-          % (N, W, H, mb, infer.DECODE_THREADS, os.cpu_count() or 1, N / t_dir, N / t_val, N / t_dec1, 1.0 / t_one))
+          % (N, W, H, mb, infer.DECODE_THREADS, os.cpu_count() or 1, N / t_dir, N / t_ovl, 1.0 / t_ow, N / t_val, N / t_dec1, 1.0 / t_one))
     shutil.rmtree(root, ignore_errors=True)
 
 
