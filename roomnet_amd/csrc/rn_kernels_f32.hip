@@ -151,7 +151,7 @@ __global__ __launch_bounds__(256) void stage0_fused_f32_kernel(const float* __re
     constexpr int TX = 30, TY = 14, CX = TX + 2, CY = TY + 2, IX = TX + 4, IY = TY + 4, CO = 8;
     static_assert(CX * CY == 512, "two passes of 256 threads");
     __shared__ float tin[IY * IX * 3];
-    __shared__ float tconv[CY * CX * CO];
+    __shared__ __attribute__((aligned(16))) float tconv[CY * CX * CO];
     const int n = blockIdx.z, ox0 = blockIdx.x * TX, oy0 = blockIdx.y * TY;
     const int So = S - 4;                                      // conv S - 2, pool 3/1: S - 4
     const float* img = in + static_cast<int64_t>(n) * S * S * 3;
@@ -178,8 +178,10 @@ __global__ __launch_bounds__(256) void stage0_fused_f32_kernel(const float* __re
 #pragma unroll
                     for (int o = 0; o < CO; ++o) acc[o] = fmaf(v, w[((ky * 3 + kx) * 3 + c) * CO + o], acc[o]);
                 }
-#pragma unroll
-        for (int o = 0; o < CO; ++o) tconv[p * CO + o] = relu6f(acc[o]);
+        // (two 16-byte writes per pixel: as eight scalar writes at a stride of eight floats they were 8-way bank conflicts)
+        float4* tp = reinterpret_cast<float4*>(tconv + p * CO);
+        tp[0] = make_float4(relu6f(acc[0]), relu6f(acc[1]), relu6f(acc[2]), relu6f(acc[3]));
+        tp[1] = make_float4(relu6f(acc[4]), relu6f(acc[5]), relu6f(acc[6]), relu6f(acc[7]));
     }
     __syncthreads();
     for (int q = threadIdx.x; q < TX * TY; q += 256) {
@@ -187,15 +189,28 @@ __global__ __launch_bounds__(256) void stage0_fused_f32_kernel(const float* __re
         const int ox = ox0 + tx, oy = oy0 + ty;
         if (ox >= So || oy >= So) continue;
         float* op = out + ((static_cast<int64_t>(n) * So + oy) * So + ox) * CO;
-        float y[CO];
+        float y[CO], acc[CO];
+#pragma unroll
+        for (int o = 0; o < CO; ++o) acc[o] = 0.f;
+        // window sum in the per-node kernel's order (ky, then kx) for every cout; the nine pixels come as 16-byte reads
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const float4* tp = reinterpret_cast<const float4*>(tconv + ((ty + ky) * CX + tx + kx) * CO);
+                const float4 a0 = tp[0], a1 = tp[1];
+                acc[0] += a0.x;
+                acc[1] += a0.y;
+                acc[2] += a0.z;
+                acc[3] += a0.w;
+                acc[4] += a1.x;
+                acc[5] += a1.y;
+                acc[6] += a1.z;
+                acc[7] += a1.w;
+            }
 #pragma unroll
         for (int o = 0; o < CO; ++o) {
-            float acc = 0.f;
-#pragma unroll
-            for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-                for (int kx = 0; kx < 3; ++kx) acc += tconv[((ty + ky) * CX + tx + kx) * CO + o];
-            const float pooled = acc / 9.0f;
+            const float pooled = acc[o] / 9.0f;
             y[o] = __fadd_rn(__fmul_rn(__fsub_rn(pooled, mean[o]), inv[o]), beta[o]);
         }
         *reinterpret_cast<float4*>(op) = make_float4(y[0], y[1], y[2], y[3]);
