@@ -636,15 +636,14 @@ def main():
             dom = int(np.argmax(group_ms))
             mfma_peak = MFMA_PEAK_F32 if f32 else MFMA_PEAK_16
             # share of a stage's algorithmic flops the folded handle really issues (`mfma_frac_executed`): the first 32 -> 32
-            # stage computes its live couts only (16-bit pair), the next one contracts the live input channels (16-bit: five
+            # stage computes its live couts only, the next one contracts the live input channels (16-bit: five
             # two-tap K = 32 chunks for nine taps of 32 channels), the folded residual stage its live cout quarters
             share = [1.0] * n_st
             if fold_info is not None:
                 p32 = [k for k in range(n_st - 1) if graph.stages[k].cin == 32 and graph.stages[k].cout == 32 and not graph.stages[k].residual]
                 dead = fold_info["pair_channels_not_convolved"]
                 if dead > 0 and p32:
-                    if not f32:
-                        share[p32[0]] = 1.0 - dead / 32.0
+                    share[p32[0]] = 1.0 - dead / 32.0
                     share[p32[0] + 1] = (5 * 32) / (9 * 32.0) if not f32 else 1.0 - dead / 32.0
                 if fold_info["residual_stage_folded"] >= 0:
                     share[fold_info["residual_stage_folded"]] = fold_info["residual_stage_live_quarters"] / 4.0
