@@ -635,9 +635,10 @@ struct F32Variant16 {
 const F32Variant16 kF32Variants16[] = {
     {128, 3, 4, 2, 0, 3, 3, launch_f32m16<128, 3, 4>},          // stage 7 (npt = 3: 576 threads, a 46-pixel ring row = 1 472 chunks)
     {16, 1, 2, 2, 0, 3, 9, launch_f32m16<16, 1, 2>},            // stage 8
-    // stage 2 with 16 frozen couts (weights in registers, four ring slots).  Tiles per workgroup, measured (ms): 9 1.53 | 8 1.66 |
-    // 6 1.67-1.71 | 5 2.11 | 4 1.35 (but the next stage, which reads this output, 0.07 slower) | 3 1.53 | 2 1.85
-    {32, 1, 2, 1, 16, 4, 9, launch_f32m16<32, 1, 2, 1, 16>},
+    // stage 2 with 16 frozen couts (weights in registers, four ring slots).  Tiles per workgroup, measured twice (ms): 9 1.53-1.57 |
+    // 8 (blocks of 8, 8, 1) 1.75 | 6 1.66-1.71 | 5 2.11 | 4 (4, 4, 4, 4, 1: three workgroups per CU) 1.35-1.39, the next stage 0.06
+    // slower, the pass +1.4 % | 3 1.53 | 2 1.85
+    {32, 1, 2, 1, 16, 4, 4, launch_f32m16<32, 1, 2, 1, 16>},
 };
 
 }  // namespace
