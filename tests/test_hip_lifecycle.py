@@ -44,3 +44,38 @@ def test_create_forward_destroy_returns_the_device_memory(weights, parity_images
         np.testing.assert_array_equal(cycle(), first)
     lost = base - _free_bytes()
     assert lost <= 8 << 20, "six create / forward / destroy cycles kept %.1f MB of device memory" % (lost / 1e6)
+
+
+def test_distinct_handles_run_concurrently_from_two_host_threads(weights, parity_images):
+    """include/roomnet_hip.h: "distinct handles are independent".  Three host threads, each with a handle of its own (bf16, f16 and
+    float32: three kernel families, first launches -- and their one-off function attributes -- racing), classify different
+    batches at the same time; every result equals the one the same handle gives alone."""
+    import threading
+    g = build_graph(6, 224)
+    specs = [("bf16", parity_images[0:16]), ("f16", parity_images[16:32]), ("f32", parity_images[32:48])]
+    engines = [_capi.Engine(g, weights, device=0, dtype=d, max_batch=16) for d, _ in specs]
+    try:
+        alone = [e.forward_u8(ims) for e, (_, ims) in zip(engines, specs)]
+        errors, start = [], threading.Barrier(len(specs))
+
+        def work(k):
+            try:
+                e, ims = engines[k], specs[k][1]
+                start.wait()
+                for _ in range(40):
+                    ids, probs = e.forward_u8(ims)
+                    np.testing.assert_array_equal(ids, alone[k][0])
+                    np.testing.assert_array_equal(probs, alone[k][1])
+            except BaseException as exc:       # noqa: BLE001 (reported by the main thread)
+                errors.append((k, repr(exc)))
+
+        threads = [threading.Thread(target=work, args=(k,)) for k in range(len(specs))]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join(timeout=300)
+        assert not errors, errors
+        assert not any(t.is_alive() for t in threads)
+    finally:
+        for e in engines:
+            e.close()
