@@ -48,8 +48,8 @@ def test_create_forward_destroy_returns_the_device_memory(weights, parity_images
 
 def test_distinct_handles_run_concurrently_from_two_host_threads(weights, parity_images):
     """include/roomnet_hip.h: "distinct handles are independent".  Three host threads, each with a handle of its own (bf16, f16 and
-    float32: three kernel families, first launches -- and their one-off function attributes -- racing), classify different
-    batches at the same time; every result equals the one the same handle gives alone."""
+    float32: three kernel families on three streams), classify different batches at the same time; every result equals the one
+    the same handle gives alone."""
     import threading
     g = build_graph(6, 224)
     specs = [("bf16", parity_images[0:16]), ("f16", parity_images[16:32]), ("f32", parity_images[32:48])]
