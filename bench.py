@@ -28,11 +28,18 @@ the last launch of step k overlaps the first of step k + 1 (+0.3 % since the bac
 `python3 bench.py --gpus N` without a launcher (no WORLD_SIZE in the environment) starts the N ranks itself (`self_launch`)
 before torch / HIP are touched; under torch.distributed.run it is one of the ranks.
 
+The default single-GPU invocation of the headline configuration also measures, in the same process and parity-gated the same
+way, BASELINE's other single-GPU shards: 64 x 600 x 600 fp16 (config 5's per-GPU shard), 256 x 224 x 224 float32 (config 2's
+arithmetic at the headline batch) and the latency of a batch-1 call (network.py:148-156's shape) -> `other_configs`
+(`--no-other-configs` skips them).
+
 Rank 0 prints ONE JSON line.  Extra objects:
   roofline      `frac` = the whole path against the roof the target is stated in (images/sec x 27.309 MB
                 / (n_gpu x 8 TB/s)); `launches[]` = every launch of a step timed live with HIP events on the launch stream, each
                 with `credited_frac` (algorithmic stage-boundary bytes of the stages it computes / time: a fused launch is
-                credited with tensors that stay in LDS), `physical_frac` (PMC HBM bytes / time) and `mfma_frac`
+                credited with tensors that stay in LDS), `physical_frac` (PMC HBM bytes / time) and `mfma_frac`;
+                `bound_frac` = max(physical HBM bytes of a step / 8 TB/s, matrix flops the handle issues / dense peak) / step time:
+                the distance to what THIS fusion structure must move or multiply -- it cannot pass 1
   cpu_baseline  the CPU restatements (oracle/) timed on this host's cores on a bounded sample: batch-1 loop
                 (infer.py:79-82) and batch 8, all cores and 1 thread, median of 3 -- a reported baseline, not the target
 """
@@ -183,6 +190,95 @@ def cpu_baseline(weights, side):
                       % (side, side, many, avail, c_threads, el)}
 
 
+def measure_other_config(_capi, torch, graph_of, weights224, dev, side, batch, dtype, warmup, steps):
+    """One more single-GPU configuration in the same process: its own handle, the parity gate against its golden file, W + K
+    untimed steps (the cold pass of the headline), W warm-up + K timed steps -> value, then the RN_FLAG_COMPUTE_FROZEN arm under
+    the same conditions.  Inputs resident in HBM; wall clock between torch.cuda.synchronize() calls."""
+    from roomnet_amd.synth import perf_batch
+    graph = graph_of(side)
+    w = weights224
+    if side != 224:
+        w = dict(weights224)
+        w["dense/kernel"] = np.random.default_rng(600).uniform(-0.04, 0.04, (graph.flat_len, 32)).astype(np.float32)
+    ims = torch.from_numpy(perf_batch(batch, side, seed=0)).to(dev)
+    probs = torch.empty((batch, graph.num_classes), dtype=torch.float32, device=dev)
+    ids = torch.empty((batch,), dtype=torch.int64, device=dev)
+    stream = torch.cuda.Stream(dev)
+    res = {"config": "%d x %dx%d %s" % (batch, side, side, dtype), "batch": batch, "im_side": side, "dtype": dtype,
+           "steps": steps, "warmup": warmup}
+    rates = {}
+    for arm, cf in (("value", False), ("computing_frozen", True)):
+        e = _capi.Engine(graph, w, device=dev.index, dtype=dtype, max_batch=batch, compute_frozen=cf)
+        e.set_stream(stream.cuda_stream)
+        try:
+            if arm == "value":
+                def fwd_host(b):
+                    t = torch.from_numpy(np.ascontiguousarray(b)).to(dev)
+                    p = torch.empty((len(b), graph.num_classes), dtype=torch.float32, device=dev)
+                    i = torch.empty((len(b),), dtype=torch.int64, device=dev)
+                    torch.cuda.synchronize()
+                    with torch.cuda.stream(stream):
+                        e.forward_u8_device(t.data_ptr(), len(b), p.data_ptr(), i.data_ptr())
+                    torch.cuda.synchronize()
+                    return i.cpu().numpy(), p.cpu().numpy()
+                res["parity"] = check_parity(fwd_host, side, dtype, batch)
+                res["folding"] = dict(e.frozen_info(), constant_channels=e.const_info())
+            with torch.cuda.stream(stream):
+                for _ in range(2 * warmup + steps):
+                    e.forward_u8_device(ims.data_ptr(), batch, probs.data_ptr(), ids.data_ptr())
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(steps):
+                    e.forward_u8_device(ims.data_ptr(), batch, probs.data_ptr(), ids.data_ptr())
+                torch.cuda.synchronize()
+                rates[arm] = batch * steps / (time.perf_counter() - t0)
+        finally:
+            e.close()
+    elem = 4 if dtype == "f32" else 2
+    res["value"] = rates["value"]
+    res["unit"] = "images/sec"
+    res["ms_per_step"] = batch / rates["value"] * 1e3
+    res["images_per_sec_computing_them"] = rates["computing_frozen"]
+    if dtype == "f32":
+        res["roofline"] = {"bound": "mfma", "frac": rates["value"] * graph.flops_per_image() / MFMA_PEAK_F32,
+                           "frac_computing_them": rates["computing_frozen"] * graph.flops_per_image() / MFMA_PEAK_F32,
+                           "scope": "images/sec x algorithmic conv flops per image / matrix-fp32 peak (BASELINE.md section 3)"}
+    else:
+        bpi = graph.boundary_elements_per_image() * elem
+        res["roofline"] = {"bound": "hbm", "frac": rates["value"] * bpi / HBM_PEAK,
+                           "frac_computing_them": rates["computing_frozen"] * bpi / HBM_PEAK,
+                           "scope": "images/sec x algorithmic stage-boundary bytes per image / 8 TB/s (BASELINE.md section 3)"}
+    return res
+
+
+def measure_latency(torch, eng, graph, dev, stream, side, calls=200):
+    """Latency of ONE batch-1 call (network.py:148-156: one image per sess.run), image resident in HBM: wall clock from the call
+    to the synchronised result, median / minimum over `calls` calls behind 20 untimed ones."""
+    from roomnet_amd.synth import perf_batch
+    im = torch.from_numpy(perf_batch(1, side, seed=3)).to(dev)
+    p = torch.empty((1, graph.num_classes), dtype=torch.float32, device=dev)
+    i = torch.empty((1,), dtype=torch.int64, device=dev)
+    ts = []
+    with torch.cuda.stream(stream):
+        for k in range(calls + 20):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            eng.forward_u8_device(im.data_ptr(), 1, p.data_ptr(), i.data_ptr())
+            stream.synchronize()
+            if k >= 20:
+                ts.append(time.perf_counter() - t0)
+        # the same calls back to back (device time per call without the host round trip)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(calls):
+            eng.forward_u8_device(im.data_ptr(), 1, p.data_ptr(), i.data_ptr())
+        torch.cuda.synchronize()
+        b2b = (time.perf_counter() - t0) / calls
+    return {"config": "batch 1, %dx%d" % (side, side), "calls": calls, "median_ms": float(np.median(ts)) * 1e3, "min_ms": float(np.min(ts)) * 1e3,
+            "back_to_back_ms_per_call": b2b * 1e3,
+            "what": "one image per call (network.py:148-156), resident in HBM; wall clock call -> synchronised result"}
+
+
 class StubEngine:
     """CPU stand-in for the GPU engine (tests only, `--stub-engine`): lets the world_size-2 gloo test drive THIS
     file's N > 1 code path -- process group, packed all-gather, barriers, max-over-ranks timing, rank-0 JSON."""
@@ -279,6 +375,8 @@ def main():
     ap.add_argument("--compute-frozen", action="store_true",
                     help="RN_FLAG_COMPUTE_FROZEN: convolve the channels rn_create proves constant too (the comparison arm: same bits)")
     ap.add_argument("--no-unfolded-arm", action="store_true", help="skip the RN_FLAG_COMPUTE_FROZEN comparison pass")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip `other_configs` (64 x 600 x 600 fp16, 256 x 224 x 224 float32, batch-1 latency) of the default run")
     ap.add_argument("--stub-engine", action="store_true", help=argparse.SUPPRESS)    # CPU tensors + gloo (tests)
     ap.add_argument("--force-collective", action="store_true",
                     help="run the N > 1 code path (RCCL process group, per-step all-gather, barriers, gathered-block check) "
@@ -484,16 +582,19 @@ def main():
 
     # ---- the comparison arm of the frozen-channel folding, in the same run: a handle that convolves the provably constant
     # channels too (RN_FLAG_COMPUTE_FROZEN), W warm-up + K timed steps, this rank only -> `folding.images_per_sec_computing_them`
-    fold_info, unfolded_rate = None, None
+    fold_info, unfolded_rate, unfolded_untimed = None, None, 0
     if not stub:
         fold_info = eng.frozen_info()
+        fold_info["constant_channels"] = eng.const_info()
         folded = fold_info["pair_channels_not_convolved"] > 0 or fold_info["residual_stage_folded"] >= 0
         if folded and not args.no_unfolded_arm and rank == 0:
             e2 = _capi.Engine(graph, weights, device=local_rank, dtype=args.dtype, max_batch=B,
                               stage_launches=args.stage_launches, pair32=args.pair32, compute_frozen=True)
             e2.set_stream(stream.cuda_stream)
+            # the conditions of `value`: the same untimed steps in front of the timed ones (the chip idled while the handle was built)
+            unfolded_untimed = (args.warmup + args.steps if cold_elapsed is not None else 0) + spinup_steps + args.warmup
             with on_stream():
-                for _ in range(args.warmup):
+                for _ in range(unfolded_untimed):
                     e2.forward_u8_device(ims.data_ptr(), B, bufs[0][1].data_ptr(), bufs[0][2].data_ptr())
                 torch.cuda.synchronize()
                 t2 = time.perf_counter()
@@ -521,6 +622,18 @@ def main():
                     gp = gp.cpu().numpy()
                     assert np.allclose(gp.sum(1), 1.0, atol=1e-4) and (gp.argmax(1) == gi.cpu().numpy()).all(), \
                         "rank %d: block %d of the all-gather is not a result" % (rank, r)
+
+    if stub and multi:
+        # stub engine: every rank knows every rank's input (perf_batch(seed = rank)), so every block of the gathered buffer is
+        # checked against what that rank must have produced -- on every rank (tests/test_bench_multi.py, world 8)
+        from roomnet_amd.parallel import shard_counts
+        assert shard_counts(world * B, world) == [B] * world
+        for k in range(2 if n_steps_done[0] > 1 else 1):
+            rows = g_bufs[k].view(world, bufs[k][0].numel())
+            for r in range(world):
+                exp_combo, exp_probs, exp_ids = result_buffers(B, graph.num_classes, dev)
+                eng.forward_into(torch.from_numpy(perf_batch(B, args.side, seed=r)).to(dev), exp_probs, exp_ids)
+                assert torch.equal(rows[r], exp_combo), "rank %d: block %d of the all-gather is not rank %d's result" % (rank, r, r)
 
     n_st = len(graph.stages)
     stage_ms = np.zeros(n_st)
@@ -615,8 +728,10 @@ def main():
                 fold_info, what="rn_create proves channels constant for EVERY input (BN gammas the reference's L2 regulariser drove to "
                                 "1e-20 .. 1e-30: the fma that applies them returns its addend bit for bit) and does not convolve them; "
                                 "`value` is this default handle; images_per_sec_computing_them = the same run on a handle that computes "
-                                "every channel (RN_FLAG_COMPUTE_FROZEN), one rank, W + K steps",
-                images_per_sec_computing_them=unfolded_rate),
+                                "every channel (RN_FLAG_COMPUTE_FROZEN), one rank, K timed steps behind the same number of untimed "
+                                "steps `value` has in front of it (untimed_steps_before_computing_them); constant_channels = "
+                                "rn_const_info: output channels whose 16-bit store is provably one number, written once at rn_create",
+                images_per_sec_computing_them=unfolded_rate, untimed_steps_before_computing_them=unfolded_untimed),
             "untimed_steps_before_value": (args.warmup + args.steps if cold_elapsed is not None else 0) + spinup_steps + args.warmup,
         }
         if cold_elapsed is not None:
@@ -647,6 +762,11 @@ def main():
                     share[p32[0] + 1] = (5 * 32) / (9 * 32.0) if not f32 else 1.0 - dead / 32.0
                 if fold_info["residual_stage_folded"] >= 0:
                     share[fold_info["residual_stage_folded"]] = fold_info["residual_stage_live_quarters"] / 4.0
+                cc = fold_info.get("constant_channels") or {}
+                if cc.get("stage", -1) >= 0:
+                    # 16 constant couts not convolved; the stage behind contracts five K = 32 fragments per kernel row instead of six
+                    share[cc["stage"]] = 1.0 - cc["channels_not_convolved"] / float(graph.stages[cc["stage"]].cout)
+                    share[cc["stage"] + 1] *= 5.0 / 6.0
             launches = []
             for j, g in enumerate(groups):
                 sec = max(group_ms[j], 1e-9) * 1e-3
@@ -690,6 +810,16 @@ def main():
                                    "algorithmic_bytes_per_step": int(bpi * B),
                                    "physical_frac": None if path_traffic is None else path_traffic / (elapsed / args.steps) / HBM_PEAK,
                                    "dominant": dom, "launches": launches}
+                # the bound of THIS fusion structure: a step cannot take less than its physical HBM bytes at 8 TB/s, nor less than
+                # the matrix flops the handle issues at the dense peak (never above 1; traffic from the committed PMC profile)
+                issued = sum(sflops[k] * share[k] for k in range(n_st)) * B
+                t_step = elapsed / args.steps
+                t_hbm = None if path_traffic is None else path_traffic / HBM_PEAK
+                t_mfma = issued / MFMA_PEAK_16
+                out["roofline"]["bound_frac"] = max(t_mfma, t_hbm or 0.0) / t_step
+                out["roofline"]["bound_terms"] = {"hbm_ms": None if t_hbm is None else t_hbm * 1e3, "mfma_ms": t_mfma * 1e3,
+                                                  "issued_flops_per_step": issued, "step_ms": t_step * 1e3,
+                                                  "what": "max(physical HBM bytes of a step / 8 TB/s, matrix flops issued / 2.5 PFLOP/s) / ms_per_step"}
             med = float(np.median(event_ms))
             out["path"] = {"algorithmic_bytes_per_image": int(bytes_per_img),
                            "hbm_frac": value * bytes_per_img / (world * HBM_PEAK),
@@ -705,6 +835,16 @@ def main():
                 out["path"]["pcie_inclusive_images_per_sec"] = pcie_rate
                 out["path"]["pcie_pipelined_images_per_sec"] = pcie_pipe_rate
                 out["path"]["pcie_pipelined_pinned_images_per_sec"] = pcie_pinned_rate
+            headline = world == 1 and not multi and args.side == 224 and B == 256 and args.dtype == "bf16" and not (
+                args.stage_launches or args.pair32 or args.compute_frozen)
+            if headline and not args.no_other_configs:
+                # BASELINE's other single-GPU shards, same process, parity-gated (profiles/r6_*: the same numbers from own runs)
+                others = [measure_latency(torch, eng, graph, dev, stream, args.side)]
+                w224 = BundleReader(os.path.join(ROOT, "roomnet_amd", "final_model", "roomnet")).load_all()
+                for side_o, batch_o, dt_o in ((600, 64, "f16"), (224, 256, "f32")):
+                    others.append(measure_other_config(_capi, torch, lambda sd: build_graph(6, sd), w224, dev, side_o, batch_o, dt_o,
+                                                       args.warmup, min(args.steps, 100)))
+                out["other_configs"] = others
             if world == 1 and not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline(weights, args.side)
         print(json.dumps(out), flush=True)

@@ -241,6 +241,14 @@ RN_API int rn_set_stream_null(rn_handle* h);
  * quarters of that stage whose convolution still runs (4 = all).  RN_FLAG_COMPUTE_FROZEN and RN_FLAG_TAPS handles report
  * nothing folded. */
 RN_API int rn_frozen_info(const rn_handle* h, int info[4]);
+/* Constant channels nobody computes (16-bit handles; zero / -1 where nothing is): info[0] = index of the conv stage whose last 16
+ * output channels are CONSTANTS in this handle's 16-bit store -- rn_create proves per channel that the store of fma(H, sc, sh) is
+ * one 16-bit number for every pooled sum H the stage can produce -- and are therefore not convolved but written once, at
+ * rn_create (or -1), info[1] = how many channels of that stage were proven so, info[2] = channels folded (16 or 0), info[3] =
+ * input channels the stage behind it still contracts (48; its own last 16 output channels are constants as well).  The shipped
+ * checkpoint: stage 4 (network.py:228, first step), 26 channels in bf16, 23 in fp16.  RN_FLAG_COMPUTE_FROZEN handles and
+ * float32 handles report nothing. */
+RN_API int rn_const_info(const rn_handle* h, int info[4]);
 RN_API int rn_node_count(const rn_handle* h);
 RN_API int rn_node_info_get(const rn_handle* h, int node_id, rn_node_info* out);
 RN_API int rn_tap(rn_handle* h, int node_id, float* out, size_t cap_elems, size_t* n_elems);
@@ -300,6 +308,12 @@ RN_API int rn_group_forward_u8(rn_group* g, const uint8_t* bgr_nhwc, int n, floa
 RN_API int rn_group_forward_u8_device(rn_group* g, const uint8_t* const* d_shards, const int* counts);
 RN_API int rn_group_result_buffer(rn_group* g, int index, void** d_gathered, size_t* slot_bytes);
 RN_API int rn_group_sync(rn_group* g);
+/* The shard / slot plan rn_group_forward_u8 applies, as a pure function (no group, no device -- testable on any host): device d
+ * of ndev takes the images [offsets[d], offsets[d] + counts[d]) of an n-image batch -- contiguous shards, the first n % ndev
+ * devices one image more (network.py:128-135 split over devices; the same rule as roomnet_amd/parallel.py: shard_bounds) --
+ * and *slot_bytes (may be null) = the size of one device's slot in the gathered buffer: probs [max_batch_per_device, C] float32
+ * followed by ids [max_batch_per_device] int64.  n > ndev * max_batch_per_device is RN_E_RANGE. */
+RN_API int rn_group_plan(int n, int ndev, int max_batch_per_device, int num_classes, int* counts, int* offsets, size_t* slot_bytes);
 
 /* ---- simple device memory helpers (so a host language without a HIP binding
  * can keep batches resident in HBM) ---------------------------------------- */

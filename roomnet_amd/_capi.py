@@ -36,9 +36,9 @@ EXPORTED_SYMBOLS = (
     "rn_forward_u8", "rn_submit_u8", "rn_collect", "rn_forward_f32", "rn_forward_u8_device", "rn_forward_f32_device", "rn_sync",
     "rn_set_stream", "rn_set_stream_null", "rn_node_count", "rn_node_info_get", "rn_tap", "rn_set_profiling", "rn_timing",
     "rn_dominant_stage", "rn_stage_launch", "rn_device_malloc", "rn_device_free", "rn_memcpy_h2d", "rn_memcpy_d2h",
-    "rn_crop_resize_u8_device", "rn_classify_images_u8", "rn_host_alloc", "rn_host_free", "rn_frozen_info",
+    "rn_crop_resize_u8_device", "rn_classify_images_u8", "rn_host_alloc", "rn_host_free", "rn_frozen_info", "rn_const_info",
     "rn_group_create", "rn_group_destroy", "rn_group_size", "rn_group_handle", "rn_group_forward_u8",
-    "rn_group_forward_u8_device", "rn_group_result_buffer", "rn_group_sync",
+    "rn_group_forward_u8_device", "rn_group_result_buffer", "rn_group_sync", "rn_group_plan",
 )
 
 
@@ -138,6 +138,9 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.rn_device_free.restype = i32
     lib.rn_memcpy_h2d.argtypes = [vp, vp, vp, sz]
     lib.rn_memcpy_h2d.restype = i32
+    if hasattr(lib, "rn_const_info"):
+        lib.rn_const_info.argtypes = [vp, C.POINTER(C.c_int)]
+        lib.rn_const_info.restype = i32
     if hasattr(lib, "rn_frozen_info"):
         lib.rn_frozen_info.argtypes = [vp, C.POINTER(C.c_int)]
         lib.rn_frozen_info.restype = i32
@@ -168,6 +171,9 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.rn_group_result_buffer.restype = i32
     lib.rn_group_sync.argtypes = [vp]
     lib.rn_group_sync.restype = i32
+    if hasattr(lib, "rn_group_plan"):
+        lib.rn_group_plan.argtypes = [i32, i32, i32, i32, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(sz)]
+        lib.rn_group_plan.restype = i32
     if path is None:
         _lib = lib
     return lib
@@ -438,6 +444,16 @@ class Engine:
         return {"pair_channels_not_convolved": info[0], "pair_channels_proven_frozen": info[1], "residual_stage_folded": info[2],
                 "residual_stage_live_quarters": info[3]}
 
+    def const_info(self) -> Dict[str, int]:
+        """Constant channels nobody computes on this handle (``rn_const_info``): the conv stage whose last 16 output channels
+        are constants in the handle's 16-bit store (written once at rn_create), how many of its channels were proven so, how
+        many are folded, and how many input channels the stage behind it still contracts."""
+        info = (C.c_int * 4)(-1, 0, 0, 0)
+        if hasattr(self.lib, "rn_const_info"):       # (older libraries loaded as A/B arms fold nothing)
+            _check(self.lib, self.lib.rn_const_info(self.handle, info), "rn_const_info")
+        return {"stage": info[0], "channels_proven_constant": info[1], "channels_not_convolved": info[2],
+                "next_stage_input_channels": info[3]}
+
     def set_profiling(self, enable: bool) -> None:
         _check(self.lib, self.lib.rn_set_profiling(self.handle, 1 if enable else 0), "rn_set_profiling")
 
@@ -487,6 +503,14 @@ class PinnedArray:
             self.close()
         except Exception:
             pass
+
+
+def group_plan(n: int, ndev: int, max_batch_per_device: int, num_classes: int = 6, lib_path: Optional[str] = None):
+    """``rn_group_plan``: (counts, offsets, slot_bytes) of an n-image call on ndev devices -- no GPU needed."""
+    lib = load_library(lib_path)
+    counts, offsets, slot = (C.c_int * ndev)(), (C.c_int * ndev)(), C.c_size_t(0)
+    _check(lib, lib.rn_group_plan(n, ndev, max_batch_per_device, num_classes, counts, offsets, C.byref(slot)), "rn_group_plan")
+    return list(counts), list(offsets), int(slot.value)
 
 
 class Group:

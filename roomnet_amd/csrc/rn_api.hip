@@ -646,6 +646,7 @@ extern "C" int rn_create(const rn_weights* w, int device, int dtype, int max_bat
     // float32 handles without per-node taps run their conv stages on the matrix cores (rn_stage_f32m.hip)
     if (!fused_mode(h) && !(h->flags & RN_FLAG_TAPS) && (rc = rn_f32m_prepare(h, w)) != RN_OK) return fail(rc);
     if ((rc = alloc_buffers(h)) != RN_OK) return fail(rc);
+    if (fused_mode(h) && (rc = rn_fused_post_alloc(h)) != RN_OK) return fail(rc);
     h->events.resize(3 + h->stages.size());
     for (auto& e : h->events)
         if (hipEventCreate(&e) != hipSuccess) {
@@ -1169,6 +1170,17 @@ extern "C" int rn_host_alloc(size_t bytes, void** ptr) {
 extern "C" int rn_host_free(void* ptr) {
     if (!ptr) return RN_OK;
     RN_HIP(hipHostFree(ptr));
+    return RN_OK;
+}
+
+extern "C" int rn_const_info(const rn_handle* h, int info[4]) {
+    if (!h || !info) {
+        rn_set_error("rn_const_info: bad argument");
+        return RN_E_INVALID;
+    }
+    info[0] = -1;
+    info[1] = info[2] = info[3] = 0;
+    if (fused_mode(h)) rn_fused_const_info(h, info);
     return RN_OK;
 }
 

@@ -17,6 +17,11 @@ bool rn_fused_stage_elided(const rn_handle* h, int stage);
 // channel relabelling of a node's stored tensor on this handle (position p holds the reference's channel perm[p]), or null
 const int* rn_fused_node_perm(const rn_handle* h, int node_id);
 void rn_fused_frozen_info(const rn_handle* h, int info[4]);
+// constant channels nobody computes (round 6): info = {stage whose last cout quarter is constant in the handle's 16-bit store or -1,
+// channels of it proven constant, channels folded (16), input channels the stage behind it still contracts (48)}
+void rn_fused_const_info(const rn_handle* h, int info[4]);
+// after the activation buffers exist: fill the constant channels once
+int rn_fused_post_alloc(rn_handle* h);
 // head launcher shared with the unfused path (defined in rn_api.hip)
 int rn_run_head(rn_handle* h, int n, float* d_probs, int64_t* d_ids);
 void rn_record_event(rn_handle* h, int idx);
@@ -77,6 +82,9 @@ bool rn_stage5x_plan(int out_side, int* n_cb, int* xo0, int* wo);
 void rn_stage5x_pack(const float* w_hwio, int dtype, unsigned short (*cvt_bf16)(float), unsigned short (*cvt_f16)(float),
                      std::vector<unsigned short>* out);
 int rn_stage5x_launch(int dtype, hipStream_t s, const rnk::StageArgs& a, int n);
+// ... without its input channels 48..63 (constants on the handle): 15 fragments per cout quarter (StageArgs::cstart carries their sum)
+void rn_stage5x_pack48(const float* w_hwio, int dtype, unsigned short (*cvt_bf16)(float), unsigned short (*cvt_f16)(float),
+                       std::vector<unsigned short>* out);
 // the same pair on 16x16x32 tiles (rn_stage23x.hip): own weight fragment order, same launch arguments and column blocks
 void rn_stage23x_pack(const float* w_hwio, int dtype, unsigned short (*cvt_bf16)(float), unsigned short (*cvt_f16)(float),
                       std::vector<unsigned short>* out);

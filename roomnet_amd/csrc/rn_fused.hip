@@ -466,6 +466,13 @@ unsigned short f32_to_f16(float f) {
     return static_cast<unsigned short>(sign | out);
 }
 
+float bf16_bits_to_f32(unsigned short u) {
+    const unsigned bits = static_cast<unsigned>(u) << 16;
+    float f;
+    std::memcpy(&f, &bits, 4);
+    return f;
+}
+
 float f16_to_f32(unsigned short h) {
     const uint32_t sign = static_cast<uint32_t>(h & 0x8000u) << 16;
     const int e = (h >> 10) & 0x1f;
@@ -628,6 +635,17 @@ struct FusedState {
     // convolution still runs, and the channel relabelling of the tensors it touches (node id -> position p holds channel perm[p])
     int fold5_stage = -1;
     int fold5_live_q = 4;
+    // constant channels of the stage in front of it (round 6; rn_fused_prepare): the relabelling puts 16 channels whose 16-BIT
+    // STORE is one number for every input into the last cout quarter of that stage -- all of them frozen channels of the residual
+    // stage too, so the same positions of the residual stage's output are constants as well.  Neither kernel computes them: both
+    // tensors are filled once (rn_fused_post_alloc), the residual stage contracts 48 input channels and starts its accumulators
+    // from the constants' contribution.
+    int const4_proven = 0;           // channels of that stage with a constant 16-bit store on this handle
+    bool const4 = false;             // 16 of them sit in positions 48..63 and are not computed
+    unsigned short const4_val[16] = {};   // their stored values (s4.bn positions 48..63)
+    unsigned short const5_val[16] = {};   // ... and of the residual stage's output (s5.bn2 positions 48..63)
+    float* s5_cstart = nullptr;      // [64] what the 16 constant input channels add to every conv output of the residual stage
+    i32x4* s5_wfrag48 = nullptr;     // the residual stage's fragments without them (rn_stage5x_pack48)
     std::map<int, std::vector<int>> node_perm;
     float* pair_ptab_x = nullptr;    // rn_stage23x.hip's table: pair_ptab with the first stage's channels in the B ring's order
     int pair_producer_halves = 2;    // 1: 16 channels of the pair's on-chip tensor are frozen and not computed (Stage23Args)
@@ -691,14 +709,44 @@ int rn_fused_prepare(rn_handle* h, const rn_weights* w_in) {
                 (fz ? frozen : live).push_back(c);
             }
             if (frozen.size() < 32) continue;
+            // ---- constant channels of the stage in front (round 6).  Its kernel (rn_stage4x.hip) stores
+            // pack2<DT>(fma(H, sc, sh)) with H = a pooled sum of ReLU6 / 6 values in [0, 16]; fma and the 16-bit conversion are
+            // monotone in H, so where the two ends H = 0 and H = 16 convert to the same 16-bit number every input does: the
+            // stored channel is that number at every pixel of every image, bit for bit what the kernel that computes it stores
+            // (the shipped checkpoint: 26 channels in bf16, 23 in fp16 -- its L2 regulariser left their BN scale below half an
+            // ulp of the shift -- all of them among this stage's frozen channels).  Table values as the stage loop below builds them.
+            std::vector<int> cst;
+            std::vector<unsigned short> cst_val(64, 0);
+            const bool s4x_ok = rn_stage4x_supported(s4.cin, s4.cout, s4.pool_k, s4.pool_s, false, h->stages[r - 1].in_side);
+            for (int c = 0; c < 64 && s4x_ok; ++c) {
+                const float inv = (1.0f / sqrtf(s4.variance[c] + w_in->bn_epsilon)) * s4.gamma[c];
+                float sc = inv / 16.0f;
+                const float sh = s4.beta[c] - s4.mean[c] * inv;
+                sc *= 6.0f;
+                const auto cv = [&](float v) { return h->dtype == RN_DTYPE_BF16 ? f32_to_bf16(v) : f32_to_f16(v); };
+                const unsigned short v0 = cv(std::fmaf(0.0f, sc, sh)), v16 = cv(std::fmaf(16.0f, sc, sh));
+                cst_val[c] = v0;
+                if (v0 == v16 && std::isfinite(sh)) cst.push_back(c);
+            }
+            fs->const4_proven = static_cast<int>(cst.size());
+            {
+                // frozen channels that are constants of the stage in front go LAST (positions 48..63 when there are 16 of them)
+                std::vector<int> both, only;
+                for (int c : frozen) (std::find(cst.begin(), cst.end(), c) != cst.end() ? both : only).push_back(c);
+                fs->const4 = both.size() >= 16;
+                frozen = only;
+                frozen.insert(frozen.end(), both.begin(), both.end());
+            }
             std::vector<int> pi(64);
-            while (frozen.size() > 32) {
-                live.push_back(frozen.back());
-                frozen.pop_back();
+            while (frozen.size() > 32) {             // (the spare frozen channels -- taken from the front -- are computed like live ones)
+                live.push_back(frozen.front());
+                frozen.erase(frozen.begin());
             }
             std::sort(live.begin(), live.end());
             for (int p = 0; p < 32; ++p) pi[p] = live[p];
             for (int p = 0; p < 32; ++p) pi[32 + p] = frozen[p];
+            if (fs->const4)
+                for (int p = 0; p < 16; ++p) fs->const4_val[p] = cst_val[pi[48 + p]];
             auto perm_vec = [&](const float* src) -> const float* {
                 if (!src) return nullptr;
                 owned.emplace_back(64);
@@ -855,6 +903,16 @@ int rn_fused_prepare(rn_handle* h, const rn_weights* w_in) {
             h->allocs.push_back(dt);
             RN_HIP(hipMemcpy(dt, tab.data(), tab.size() * 4, hipMemcpyHostToDevice));
             f.ptab = static_cast<float*>(dt);
+            if (fs->const4 && static_cast<int>(i) == fs->fold5_stage && s.cout == 64) {
+                // the residual stage's output at the positions of the constant channels: y1 = fma(0, sc1', sh1') = sh1' (frozen first
+                // BN), the bilinear resize of a constant channel is the constant (its two weights are exact 16-bit numbers that
+                // sum to 1, the products are exact in float32), y = fma(v, sc2, y1) -- what rn_stage5x.hip computes for them
+                const auto cv = [&](float v) { return h->dtype == RN_DTYPE_BF16 ? f32_to_bf16(v) : f32_to_f16(v); };
+                for (int p = 0; p < 16; ++p) {
+                    const float v = h->dtype == RN_DTYPE_BF16 ? bf16_bits_to_f32(fs->const4_val[p]) : f16_to_f32(fs->const4_val[p]);
+                    fs->const5_val[p] = cv(std::fmaf(v, tab[2 * 64 + 48 + p], tab[64 + 48 + p]));
+                }
+            }
         }
         const Variant& k = kVariants[f.variant];
         f.ctw = k.ctw;
@@ -961,6 +1019,38 @@ int rn_fused_prepare(rn_handle* h, const rn_weights* w_in) {
             RN_HIP(hipMemcpy(d16, f16.data(), f16.size() * 2, hipMemcpyHostToDevice));
             f.wfrag16 = static_cast<i32x4*>(d16);
             f.use_s5x = true;
+            if (fs->const4 && static_cast<int>(i) == fs->fold5_stage) {
+                // without the 16 constant input channels (positions 48..63): 15 fragments per cout quarter instead of 18, and what
+                // those channels add to every conv output -- sum over the nine taps of (16-bit weight / 6) x (stored 16-bit value),
+                // the products the matrix cores would form, summed here in double
+                rn_stage5x_pack48(wsrc, h->dtype, f32_to_bf16, f32_to_f16, &f16);
+                void* d48 = nullptr;
+                if (hipMalloc(&d48, f16.size() * 2) != hipSuccess) {
+                    rn_set_error("hipMalloc(stage5x weights) failed");
+                    return RN_E_NOMEM;
+                }
+                h->allocs.push_back(d48);
+                RN_HIP(hipMemcpy(d48, f16.data(), f16.size() * 2, hipMemcpyHostToDevice));
+                fs->s5_wfrag48 = static_cast<i32x4*>(d48);
+                const auto cv = [&](float v) { return h->dtype == RN_DTYPE_BF16 ? f32_to_bf16(v) : f32_to_f16(v); };
+                const auto bk = [&](unsigned short u) { return h->dtype == RN_DTYPE_BF16 ? bf16_bits_to_f32(u) : f16_to_f32(u); };
+                std::vector<float> cst(64);
+                for (int co = 0; co < 64; ++co) {
+                    double sum = 0.0;
+                    for (int tap = 0; tap < 9; ++tap)
+                        for (int p = 48; p < 64; ++p)
+                            sum += static_cast<double>(bk(cv(wsrc[(static_cast<size_t>(tap) * 64 + p) * 64 + co]))) * static_cast<double>(bk(fs->const4_val[p - 48]));
+                    cst[co] = static_cast<float>(sum);
+                }
+                void* dc = nullptr;
+                if (hipMalloc(&dc, cst.size() * 4) != hipSuccess) {
+                    rn_set_error("hipMalloc(stage5x constants) failed");
+                    return RN_E_NOMEM;
+                }
+                h->allocs.push_back(dc);
+                RN_HIP(hipMemcpy(dc, cst.data(), cst.size() * 4, hipMemcpyHostToDevice));
+                fs->s5_cstart = static_cast<float*>(dc);
+            }
         }
         if (f.use_rw && f.ptab && rn_conv16p_supported(s.cin, s.cout, s.pool_k, s.pool_s, s.skip_stage >= 0) &&
             !(h->flags & RN_FLAG_GENERIC_KERNELS)) {
@@ -977,6 +1067,8 @@ int rn_fused_prepare(rn_handle* h, const rn_weights* w_in) {
             f.use_c16p = true;
         }
     }
+    if (fs->const4 && !(fs->fold5_stage >= 1 && fs->st[fs->fold5_stage - 1].use_s4x && fs->st[fs->fold5_stage].use_s5x && fs->s5_wfrag48 && fs->s5_cstart))
+        fs->const4 = false;          // (another kernel family runs one of the two stages: every channel is computed)
     // ---- cross-stage fusion: the last two steps of a depth-3 block (network.py:183-203 with block_depth = 3):
     // stage i (32->32, pool 4/1) feeds only stage i+1 (32->32, pool 4/1 + residual), whose skip tensor is stage i's
     // INPUT.  One kernel runs both; stage i's output never reaches HBM.
@@ -1137,6 +1229,55 @@ void rn_fused_frozen_info(const rn_handle* h, int info[4]) {
     info[1] = fs->pair_frozen;
     info[2] = fs->fold5_stage;
     info[3] = fs->fold5_stage >= 0 ? fs->fold5_live_q : 4;
+}
+
+void rn_fused_const_info(const rn_handle* h, int info[4]) {
+    const FusedState* fs = static_cast<const FusedState*>(h->fused);
+    info[0] = -1;
+    info[1] = info[2] = info[3] = 0;
+    if (!fs || fs->fold5_stage < 1) return;
+    info[1] = fs->const4_proven;
+    if (!fs->const4) return;
+    info[0] = fs->fold5_stage - 1;
+    info[2] = 16;
+    info[3] = 48;
+}
+
+namespace {
+// channels c0 .. c0 + 15 of a [npix, 64] 16-bit tensor <- vals[0..15]
+__global__ void fill_channels16_kernel(unsigned short* base, int64_t npix, int c0, const i32x4 v0, const i32x4 v1) {
+    const int64_t p = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (p >= npix) return;
+    i32x4* dst = reinterpret_cast<i32x4*>(base + p * 64 + c0);
+    dst[0] = v0;
+    dst[1] = v1;
+}
+}  // namespace
+
+// After alloc_buffers: the constant channels of the two tensors nobody computes (const4) are written once, for every image slot
+// of the handle; the kernels never touch these positions again, rn_tap and the consumers read complete tensors.
+int rn_fused_post_alloc(rn_handle* h) {
+    FusedState* fs = static_cast<FusedState*>(h->fused);
+    if (!fs || !fs->const4) return RN_OK;
+    const int r = fs->fold5_stage;
+    const StagePlan& s4 = h->stages[r - 1];
+    const StagePlan& s5 = h->stages[r];
+    struct Job { int node; int side; const unsigned short* vals; };
+    const Job jobs[2] = {{s4.node_bn, s4.out_side, fs->const4_val}, {s5.node_bn2, s5.out_side, fs->const5_val}};
+    for (const Job& j : jobs) {
+        unsigned short* base = static_cast<unsigned short*>(h->nodes[j.node].ptr);
+        if (!base) {
+            rn_set_error("constant channels: node %d has no buffer", j.node);
+            return RN_E_STATE;
+        }
+        i32x4 v[2];
+        std::memcpy(v, j.vals, 32);
+        const int64_t npix = static_cast<int64_t>(h->max_batch) * j.side * j.side;
+        hipLaunchKernelGGL(fill_channels16_kernel, dim3(static_cast<unsigned>((npix + 255) / 256)), dim3(256), 0, h->stream, base, npix, 48, v[0], v[1]);
+        RN_CHECK_LAUNCH();
+    }
+    RN_HIP(hipStreamSynchronize(h->stream));
+    return RN_OK;
 }
 
 // channel relabelling of a tensor on this handle (position p of the stored tensor holds channel perm[p] of the reference's), or null
@@ -1433,6 +1574,11 @@ int rn_fused_forward(rn_handle* h, const uint8_t* d_bgr, const float* d_rgb, int
             }
 #endif
             a.live_q = (f.use_s5x && static_cast<int>(i) == fs->fold5_stage) ? fs->fold5_live_q : 4;
+            if (fs->const4 && f.use_s4x && static_cast<int>(i) + 1 == fs->fold5_stage) a.live_q = 3;      // its last cout quarter is constant
+            if (fs->const4 && f.use_s5x && static_cast<int>(i) == fs->fold5_stage) {
+                a.wfrag = fs->s5_wfrag48;
+                a.cstart = fs->s5_cstart;
+            }
             int rc = f.use_s5x   ? rn_stage5x_launch(h->dtype, h->stream, a, n)
                      : f.use_s4x ? rn_stage4x_launch(h->dtype, h->stream, a, n)
                                  : rn_stage6x_launch(h->dtype, h->stream, a, n);

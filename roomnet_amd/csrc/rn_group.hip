@@ -294,6 +294,21 @@ static void shard(int n, int ndev, int d, int* lo, int* cnt) {
     *cnt = base + (d < rem ? 1 : 0);
 }
 
+// The shard / slot plan of rn_group_forward_u8 as a function of (n, ndev) alone: no group, no device.
+extern "C" int rn_group_plan(int n, int ndev, int max_batch_per_device, int num_classes, int* counts, int* offsets, size_t* slot_bytes) {
+    if (ndev < 1 || n < 0 || max_batch_per_device < 1 || num_classes < 1 || !counts || !offsets) {
+        rn_set_error("rn_group_plan: bad argument (n %d, ndev %d, max_batch_per_device %d, num_classes %d)", n, ndev, max_batch_per_device, num_classes);
+        return RN_E_INVALID;
+    }
+    if (static_cast<long long>(n) > static_cast<long long>(ndev) * max_batch_per_device) {
+        rn_set_error("rn_group_plan: n = %d out of range (0..%lld)", n, static_cast<long long>(ndev) * max_batch_per_device);
+        return RN_E_RANGE;
+    }
+    for (int d = 0; d < ndev; ++d) shard(n, ndev, d, &offsets[d], &counts[d]);
+    if (slot_bytes) *slot_bytes = static_cast<size_t>(max_batch_per_device) * (static_cast<size_t>(num_classes) * 4 + 8);
+    return RN_OK;
+}
+
 static int group_run(rn_group* g, const uint8_t* const* d_shards, const int* counts) {
     // forward pass per device into its packed send buffer, then ONE all-gather bracket.  A device with counts[d] == 0 still
     // takes part in the collective (every rank must): it contributes its slot as it stands -- the results of its last

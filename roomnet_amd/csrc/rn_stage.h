@@ -267,7 +267,13 @@ struct StageArgs {
     // rn_stage5x.hip: 16-cout quarters whose convolution runs (0 or 4: all).  2: the channels of quarters 2 and 3 have a FROZEN
     // first BN (rn_fused_prepare proves fma(H, sc1', sh1') == sh1' in float32 for every input and relabels the channels so);
     // their waves skip the convolution and its pooling and interleave with the live quarters' waves on the SIMDs.
+    // rn_stage4x.hip: 3 = the channels of the last quarter are constants in the handle's 16-bit store, filled once at rn_create
+    // (rn_fused_post_alloc) and not computed (twelve-wave form).
     int live_q;
+    // rn_stage5x.hip (with live_q == 2): non-null = the input channels 48..63 are such constants; wfrag = rn_stage5x_pack48's
+    // fragments, cstart[cout] = what the constants add to every conv output (the accumulators' start value), and the waves of the
+    // last quarter -- whose output channels are constants too -- do nothing.
+    const float* cstart;
 };
 
 // Column-block plan of a row-blocked kernel: the fewest blocks (<= 4) of equal width +-1 whose widths lie in [wo_min, wo_max].

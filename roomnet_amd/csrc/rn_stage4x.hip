@@ -13,6 +13,10 @@
 // The most matrix-dense launch of the pass held the lowest clock at the board's power cap (1.64 GHz, profiles/r3_clock.txt):
 // the 16x16x32 shape costs less energy per FLOP (profiles/r2_power_cap.txt), and one workgroup per CU x 256 images is one
 // round of the chip (the 2-wave workgroups of the row-streaming kernel ran 3.5 rounds).
+// NQ = 3 (round 6): the channels of the last cout quarter are CONSTANTS on this handle (rn_fused_prepare proves per channel that the
+// 16-bit store of fma(H, sc, sh) is one number for every H in [0, 16], relabels the channels so and fills them into the output
+// tensor once, at rn_create): twelve waves = 3 live quarters x 4 pixel runs (4 + 3 + 3 + 3 tiles = 31 + 23 + 23 + 23 pooled
+// columns), rotated over the SIMDs so that each carries 10 (one: 9) tile rows per step instead of 13.
 // One workgroup = one image x one band of output rows x one COLUMN BLOCK of 95..101 pooled columns (194..206 input columns:
 // the whole row of the 224 x 224 network, two blocks at 420, three at 600; rn_colblock_plan).  Blocks do not overlap in the
 // output; the 4 halo columns of a block's input are read by both neighbours.
@@ -34,7 +38,6 @@ constexpr int U_TAB_BYTES = 4 * 64 * 4;
 constexpr int U_RING_OFF = U_TAB_BYTES;
 constexpr int U_LDS = U_RING_OFF + U_NS * U_ROW;
 constexpr int U_WMIN = 193, U_WMAX = 206;
-constexpr int U_NT = 7;                           // tiles of the longer run
 
 __device__ __forceinline__ unsigned lds_addr(const void* p) {
     return static_cast<unsigned>(reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) const char*)p));
@@ -51,8 +54,12 @@ __device__ __forceinline__ f32x4 mfma16(i32x4 a, i32x4 b, f32x4 c) {
         return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
 }
 
-template <int DT>
-__global__ __launch_bounds__(512, 2) void stage4x_kernel(const StageArgs a) {
+template <int DT, int NQ>
+__global__ __launch_bounds__(NQ == 4 ? 512 : 768, NQ == 4 ? 2 : 3) void stage4x_kernel(const StageArgs a) {
+    constexpr int U_NW = NQ == 4 ? 8 : 12;            // waves
+    constexpr int U_NTH = U_NW * 64;
+    constexpr int U_NT = NQ == 4 ? 7 : 4;             // tiles of the longest run
+    constexpr int U_NU = (U_NT + 1) / 2;              // tile pairs (output stores per odd step) of the longest run
 #ifdef RN_CLOCK
     unsigned long long ck_t0, ck_r0;
     clock_pair(ck_t0, ck_r0);
@@ -61,7 +68,10 @@ __global__ __launch_bounds__(512, 2) void stage4x_kernel(const StageArgs a) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int cq = wave & 3, ph = wave >> 2;              // cout quarter / pixel half: waves w and w + 4 share a SIMD (7 + 6 tiles)
+    // cout quarter / pixel run.  NQ = 4: waves w and w + 4 share a SIMD (7 + 6 tiles).  NQ = 3: waves w, w + 4, w + 8 share a
+    // SIMD and take the runs w, w + 1, w + 2 (mod 4) of the quarters 0, 1, 2
+    const int cq = NQ == 4 ? (wave & 3) : (wave >> 2);
+    const int run = NQ == 4 ? (wave >> 2) : (((wave & 3) + (wave >> 2)) & 3);
     const int px16 = lane & 15, g = lane >> 4;
     const int cb = blockIdx.x % a.n_cb, band = blockIdx.x / a.n_cb, n = blockIdx.y;
     const int Win = a.W, Wo_full = a.Wo, Ho = a.Ho;
@@ -79,18 +89,19 @@ __global__ __launch_bounds__(512, 2) void stage4x_kernel(const StageArgs a) {
     char* const ring = smem + U_RING_OFF;
     const unsigned ring_lds = lds_addr(ring);
     // pixels W .. 207 of every slot are never written by the row DMA: zero them once
-    for (int i = tid; i < U_NS * (U_RINGPX - U_WMIN) * 4; i += 512) {
+    for (int i = tid; i < U_NS * (U_RINGPX - U_WMIN) * 4; i += U_NTH) {
         const int slot = i / ((U_RINGPX - U_WMIN) * 4), rest = i % ((U_RINGPX - U_WMIN) * 4);
         const int p = U_WMIN + rest / 4, c = rest % 4;
         if (p >= W) *reinterpret_cast<i32x4*>(ring + slot * U_ROW + p * 64 + c * 16) = i32x4{0, 0, 0, 0};
     }
 
-    // ---- this wave's tiles: pixel half 0 = 7 tiles from column 0 (55 pooled columns), half 1 = 6 tiles from column 110
-    // (47 pooled columns from 55)
-    const bool has7 = ph == 0;
-    const int xw = ph ? 110 : 0;
-    const int xo_run = ph ? 55 : 0;
-    const int nout_run = has7 ? 55 : 47;
+    // ---- this wave's tiles.  NQ = 4: run 0 = 7 tiles from column 0 (55 pooled columns), run 1 = 6 tiles from column 110 (47
+    // pooled columns from 55).  NQ = 3: run 0 = 4 tiles (31 pooled columns), runs 1..3 = 3 tiles (23 each, from 31 / 54 / 77).
+    // A run of t tiles pools 8 t - 1 columns; the next run starts 2 x that many conv columns further (2 columns of overlap).
+    const bool has7 = run == 0;                           // (the longest run: U_NT tiles; the others one fewer)
+    const int xo_run = NQ == 4 ? (run ? 55 : 0) : (run ? 8 + 23 * run : 0);
+    const int xw = 2 * xo_run;
+    const int nout_run = NQ == 4 ? (has7 ? 55 : 47) : (has7 ? 31 : 23);
 
     // ---- weights: fragment f = ky * 3 + kx (all 32 channels of the tap), B operand of D'[pixel][cout]
     i32x4 wf[9];
@@ -105,12 +116,15 @@ __global__ __launch_bounds__(512, 2) void stage4x_kernel(const StageArgs a) {
     const char* const in_img = reinterpret_cast<const char*>(a.in + static_cast<int64_t>(n) * Win * Win * 32) + x0 * 64;
     const int row_bytes = Win * 64;
     const unsigned goff0 = static_cast<unsigned>((tid >> 2) * 64 + (((tid & 3) ^ swz4x(tid >> 2)) << 4));
-    const int tailn = ((W - 128) * 4 + 7) / 8;
-    const int tail_cnt = min(W * 4 - (512 + wave * tailn), tailn);
+    // (a wave whose share of a short tail is empty loads the row's last chunk once more: the same bytes to the same place)
+    const int tail_total = W * 4 - U_NTH;
+    const int tailn = (tail_total + U_NW - 1) / U_NW;
+    const int tail_start = min(wave * tailn, tail_total - 1);
+    const int tail_cnt = max(1, min(tail_total - wave * tailn, tailn));
     const unsigned long long tail_mask = (1ull << tail_cnt) - 1ull;
     unsigned goff1;
     {
-        const int q = 512 + wave * tailn + min(lane, tail_cnt - 1);
+        const int q = U_NTH + tail_start + min(lane, tail_cnt - 1);
         const int p = q >> 2, c = q & 3;
         goff1 = static_cast<unsigned>(p * 64 + ((c ^ swz4x(p)) << 4));
     }
@@ -119,7 +133,7 @@ __global__ __launch_bounds__(512, 2) void stage4x_kernel(const StageArgs a) {
         unsigned o0 = goff0, o1 = goff1;
         asm volatile("" : "+v"(o0), "+v"(o1));
         dma16(row + o0, ring + slot * U_ROW + wave * 1024);
-        dma16_masked(row + o1, ring + slot * U_ROW + (512 + wave * tailn) * 16, tail_mask);
+        dma16_masked(row + o1, ring + slot * U_ROW + (U_NTH + tail_start) * 16, tail_mask);
     };
 
     // ---- operand read bases (slot 0): tap column kx; tile k adds 16 pixels = 1024 bytes (same swizzle)
@@ -154,9 +168,9 @@ __global__ __launch_bounds__(512, 2) void stage4x_kernel(const StageArgs a) {
     asm volatile("" : "+v"(pmA), "+v"(pmB), "+v"(pmC));
 
     // ---- output stores: tile pair u = 16 pooled columns (pair 3 of the longer run: its 7th tile alone, 7 columns)
-    int voff[4];
+    int voff[U_NU];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < U_NU; ++u) {
         const int xo = xo_run + 16 * u + px16;
         const bool valid = 16 * u + px16 < nout_run && xo < Wo;
         voff[u] = valid ? ((xo0 + xo) * 64 + 16 * cq + 4 * g) * 2 : OOB;
@@ -209,7 +223,8 @@ __global__ __launch_bounds__(512, 2) void stage4x_kernel(const StageArgs a) {
         // retires in order: a step issues two DMA pieces behind its first MFMAs and, on odd rows, 3 (or 4: has7) stores at its
         // end.  Younger than the DMA of row s + 1 (issued at step s - 2): even s: DMA + stores of step s - 1 = 2 + 3; odd s:
         // stores of step s - 2, DMA of step s - 1 = 3 + 2 (one more with four stores: those waves wait for one piece more).
-        wait_vmcnt<5>();
+        // (NQ = 3: two stores per odd step)
+        wait_vmcnt<(NQ == 4 ? 5 : 4)>();
         raw_barrier();
         const unsigned so = static_cast<unsigned>(slot_cur * U_ROW);
         unsigned bc[3];
@@ -253,15 +268,12 @@ __global__ __launch_bounds__(512, 2) void stage4x_kernel(const StageArgs a) {
                 pp2[k][1] = n1;
             }
         };
-        tile(IC<0>{}, IC<1>{});
-        tile(IC<1>{}, IC<1>{});
-        tile(IC<2>{}, IC<1>{});
-        tile(IC<3>{}, IC<1>{});
-        tile(IC<4>{}, IC<1>{});
-        tile(IC<5>{}, IC<0>{});
-        if (has7) {                       // (the seventh tile's reads stay behind the branch: its tile code exists once)
-            reads(IC<6>{});
-            tile(IC<6>{}, IC<0>{});
+        [&]<int... K>(std::integer_sequence<int, K...>) {
+            (tile(IC<K>{}, IC<(K + 2 < U_NT ? 1 : 0)>{}), ...);
+        }(std::make_integer_sequence<int, U_NT - 1>{});
+        if (has7) {                       // (the last tile's reads stay behind the branch: its tile code exists once)
+            reads(IC<U_NT - 1>{});
+            tile(IC<U_NT - 1>{}, IC<0>{});
         }
         if constexpr (PAR == 1) {
             // odd conv row j = s - 2 >= 3 completes pooled row r = (j - 3) / 2
@@ -275,17 +287,22 @@ __global__ __launch_bounds__(512, 2) void stage4x_kernel(const StageArgs a) {
                 constexpr int u = decltype(UC)::value;
                 f32x4 H = mfma16<RN_DTYPE_F16>(op[2 * u], pmA, zero4);
                 H = mfma16<RN_DTYPE_F16>(op[2 * u + 1], pmB, H);
-                if constexpr (u < 3) H = mfma16<RN_DTYPE_F16>(op[2 * u + 2], pmC, H);
+                if constexpr (2 * u + 2 < U_NT) H = mfma16<RN_DTYPE_F16>(op[2 * u + 2], pmC, H);
                 float y[4];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) y[i] = __builtin_fmaf(H[i], sc[i], sh[i]);
                 const i32x2 d = {static_cast<int>(pack2<DT>(y[0], y[1])), static_cast<int>(pack2<DT>(y[2], y[3]))};
                 __builtin_amdgcn_raw_buffer_store_b64(d, rs, voff[u] | emask, 0, 0);
             };
-            out(IC<0>{});
-            out(IC<1>{});
-            out(IC<2>{});
-            if (has7) out(IC<3>{});
+            if constexpr (NQ == 4) {
+                out(IC<0>{});
+                out(IC<1>{});
+                out(IC<2>{});
+                if (has7) out(IC<3>{});
+            } else {
+                out(IC<0>{});
+                out(IC<1>{});         // (the shorter runs' second pair is their third tile alone: op[3] = 0)
+            }
         }
         slot_cur = slot_cur == U_NS - 1 ? 0 : slot_cur + 1;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -353,6 +370,7 @@ void rn_stage4x_pack(const float* w_hwio, int dtype, unsigned short (*cvt_bf16)(
 }
 
 int rn_stage4x_launch(int dtype, hipStream_t s, const StageArgs& a, int n) {
+    int nthreads = 512;
     auto launch = [&](auto kern) -> int {
         static std::atomic<unsigned long long> attr_devices{0};
         int dev = 0;
@@ -361,10 +379,18 @@ int rn_stage4x_launch(int dtype, hipStream_t s, const StageArgs& a, int n) {
             RN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             attr_devices.fetch_or(1ull << (dev & 63), std::memory_order_release);
         }
-        hipLaunchKernelGGL(kern, dim3(a.n_bands * a.n_cb, n), dim3(512), U_LDS, s, a);
+        hipLaunchKernelGGL(kern, dim3(a.n_bands * a.n_cb, n), dim3(nthreads), U_LDS, s, a);
         RN_CHECK_LAUNCH();
         return RN_OK;
     };
-    if (dtype == RN_DTYPE_BF16) return launch(stage4x_kernel<RN_DTYPE_BF16>);
-    return launch(stage4x_kernel<RN_DTYPE_F16>);
+    // three live quarters (StageArgs::live_q == 3): the twelve-wave form pools 100 columns per block at most
+    bool q3 = a.live_q == 3;
+    for (int b = 0; b < a.n_cb; ++b) q3 = q3 && a.cb_wo[b] <= 100;
+    if (q3) {
+        nthreads = 768;
+        if (dtype == RN_DTYPE_BF16) return launch(stage4x_kernel<RN_DTYPE_BF16, 3>);
+        return launch(stage4x_kernel<RN_DTYPE_F16, 3>);
+    }
+    if (dtype == RN_DTYPE_BF16) return launch(stage4x_kernel<RN_DTYPE_BF16, 4>);
+    return launch(stage4x_kernel<RN_DTYPE_F16, 4>);
 }

@@ -18,6 +18,11 @@
 //    transposed (ds_read_b64_tr_b16) and interpolated horizontally on the matrix cores (K = 64 source columns per tile pair);
 //    the lerp fraction is quantised like in the fused stage pair (res_quant_lerp) so that its two weights are one exact
 //    16-bit operand.
+// K48 (round 6): the input channels 48..63 are CONSTANTS on the handle (StageArgs::cstart; rn_fused_prepare): a row step reads
+// five fragments per tile instead of six -- (kx, channels 0..31) for kx = 0, 1, 2, then [kx 0 | kx 1] and [kx 2 | zero weights] of
+// channels 32..47 (lane groups 0, 1 take one tap's two chunks, groups 2, 3 the next tap's) -- for 15 MFMAs instead of 18; the
+// accumulators start from the constants' contribution, and the waves of the last cout quarter, whose output channels are
+// constants as well (frozen first BN + constant skip channel), idle.
 // One workgroup = one image x one band of output rows x one COLUMN BLOCK of 31..53 pooled columns (66..110 input columns:
 // the whole row of the 224 x 224 network, three blocks at 600; rn_stage5x_plan checks that every block's skip columns lie
 // inside the input columns it stages).
@@ -57,8 +62,9 @@ __device__ __forceinline__ f32x4 mfma16(i32x4 a, i32x4 b, f32x4 c) {
         return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
 }
 
-template <int DT>
+template <int DT, bool K48>
 __global__ __launch_bounds__(512, 2) void stage5x_kernel(const StageArgs a) {
+    constexpr int NF = K48 ? 5 : 6;                   // operand fragments per tile and row step
 #ifdef RN_CLOCK
     unsigned long long ck_t0, ck_r0;
     clock_pair(ck_t0, ck_r0);
@@ -74,6 +80,7 @@ __global__ __launch_bounds__(512, 2) void stage5x_kernel(const StageArgs a) {
     const int cq = fold ? (wave < 4 ? (wave >> 1) : 2 + ((wave - 4) >> 1)) : (wave & 3);
     const int ph = fold ? (wave & 1) : (wave >> 2);
     const bool conv_live = !fold || cq < 2;
+    const bool epi_live = !K48 || cq < 3;                 // (K48: the last quarter's output channels are constants, written at rn_create)
     const int px16 = lane & 15, g = lane >> 4;
     const int cb = blockIdx.x % a.n_cb, band = blockIdx.x / a.n_cb, n = blockIdx.y;
     const int Win = a.W, Wo_full = a.Wo, Ho = a.Ho;
@@ -107,10 +114,10 @@ __global__ __launch_bounds__(512, 2) void stage5x_kernel(const StageArgs a) {
     const int xo_run = ph ? 31 : 0;
     const int nout_run = has4 ? 31 : 23;
 
-    // ---- weights: fragment f = (ky * 3 + kx) * 2 + ch, B operand of D'[pixel][cout]
-    i32x4 wf[18];
+    // ---- weights: fragment f = (ky * 3 + kx) * 2 + ch (K48: ky * 5 + j, rn_stage5x_pack48), B operand of D'[pixel][cout]
+    i32x4 wf[3 * NF];
 #pragma unroll
-    for (int f = 0; f < 18; ++f) {
+    for (int f = 0; f < 3 * NF; ++f) {
         const i32x4* src = a.wfrag + (f * 4 + cq) * 64 + lane;      // (frozen quarters: loaded, never used)
         asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(wf[f]) : "v"(src) : "memory");
     }
@@ -145,6 +152,15 @@ __global__ __launch_bounds__(512, 2) void stage5x_kernel(const StageArgs a) {
             const int p = xw + px16 + kx;
             base[kx][ch] = ring_lds + static_cast<unsigned>(p * 128 + (((4 * ch + g) ^ swz8(p)) << 4));
         }
+    if constexpr (K48) {
+        // fragments 3, 4: channels 32..47 of two taps -- lane groups 0, 1 read chunks 4, 5 of tap column 0 (fragment 4: column 2),
+        // groups 2, 3 those of column 1 (fragment 4: zero weights; they read what groups 0, 1 read)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int p = xw + px16 + (j == 0 ? (g >> 1) : 2);
+            base[j][1] = ring_lds + static_cast<unsigned>(p * 128 + (((4 + (g & 1)) ^ swz8(p)) << 4));
+        }
+    }
 
     // ---- pooling band matrices (stride 2).  The 16 pooled columns n of a tile PAIR: n < 8 start in the pair's first tile
     // (window = its columns 2n .. 2n+3; n = 7 ends in the second tile), n >= 8 in the second (n = 15 ends in the tile after).
@@ -236,7 +252,13 @@ __global__ __launch_bounds__(512, 2) void stage5x_kernel(const StageArgs a) {
     for (int j = 0; j < V_AHEAD; ++j) issue_row(j, j);
     wait_vmcnt<0>();
 #pragma unroll
-    for (int f = 0; f < 18; ++f) asm volatile("" : "+v"(wf[f]));
+    for (int f = 0; f < 3 * NF; ++f) asm volatile("" : "+v"(wf[f]));
+    // K48: what the constant input channels add to every conv output of the lane's cout (D'[pixel][cout]: cout = lane % 16)
+    f32x4 cst4 = zero4;
+    if constexpr (K48) {
+        const float c0 = a.cstart[16 * cq + px16];
+        cst4 = f32x4{c0, c0, c0, c0};
+    }
     lds_barrier();
 
     int slot_cur = 0;             // ring slot of input row s
@@ -264,27 +286,32 @@ __global__ __launch_bounds__(512, 2) void stage5x_kernel(const StageArgs a) {
         // batches AND tiles: batch b + 1's reads go out before batch b's nine MFMAs, so the LDS round trip never stands at
         // the head of a chain (a batch is only 9 MFMAs long)
         i32x4 fq[2][3];
+        // reads of batch b: three fragments (channel half 0), then three (half 1) -- K48: two (the merged fragments)
         auto reads = [&](auto BC) __attribute__((always_inline)) {
             constexpr int b = decltype(BC)::value, k = b >> 1, ch = b & 1;
+            constexpr int NR = (K48 && ch) ? 2 : 3;
             auto& dst = fq[b & 1];
             auto& bcr = bc;                                            // (named outside the asm: implicit capture)
 #pragma unroll
-            for (int kx = 0; kx < 3; ++kx) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst[kx]) : "v"(bcr[kx][ch]), "n"(k * 2048));
+            for (int kx = 0; kx < NR; ++kx) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst[kx]) : "v"(bcr[kx][ch]), "n"(k * 2048));
         };
         auto batch = [&](auto BC, auto NEXTC) __attribute__((always_inline)) {
             constexpr int b = decltype(BC)::value, k = b >> 1, ch = b & 1;
-            constexpr bool NEXT = decltype(NEXTC)::value != 0;        // batch b + 1's reads are issued here (3 more in flight)
+            constexpr bool NEXT = decltype(NEXTC)::value != 0;        // batch b + 1's reads are issued here
+            constexpr int NR = (K48 && ch) ? 2 : 3;                    // this batch's fragments
+            constexpr int NRN = NEXT ? ((K48 && !ch) ? 2 : 3) : 0;     // the next batch's, in flight behind them
             if constexpr (NEXT) reads(IC<b + 1>{});
             auto& cur = fq[b & 1];
             [&]<int... KX>(std::integer_sequence<int, KX...>) {
                 (([&] {
-                     asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(cur[KX]) : "n"((NEXT ? 3 : 0) + 2 - KX));
-                     acc[iN][k] = mfma16<DT>(cur[KX], wf[(0 * 3 + KX) * 2 + ch], (ch == 0 && KX == 0) ? zero4 : acc[iN][k]);
-                     acc[iM][k] = mfma16<DT>(cur[KX], wf[(1 * 3 + KX) * 2 + ch], acc[iM][k]);
-                     acc[iO][k] = mfma16<DT>(cur[KX], wf[(2 * 3 + KX) * 2 + ch], acc[iO][k]);
+                     constexpr int fi = K48 ? (ch ? 3 + KX : KX) : KX * 2 + ch;      // fragment index inside a kernel row
+                     asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(cur[KX]) : "n"(NRN + NR - 1 - KX));
+                     acc[iN][k] = mfma16<DT>(cur[KX], wf[0 * NF + fi], (ch == 0 && KX == 0) ? cst4 : acc[iN][k]);
+                     acc[iM][k] = mfma16<DT>(cur[KX], wf[1 * NF + fi], acc[iM][k]);
+                     acc[iO][k] = mfma16<DT>(cur[KX], wf[2 * NF + fi], acc[iO][k]);
                  }()),
                  ...);
-            }(std::make_integer_sequence<int, 3>{});
+            }(std::make_integer_sequence<int, NR>{});
         };
         auto tile = [&](auto KC, auto LASTC) __attribute__((always_inline)) {
             constexpr int k = decltype(KC)::value;
@@ -346,6 +373,12 @@ __global__ __launch_bounds__(512, 2) void stage5x_kernel(const StageArgs a) {
             const char* orow = out_img + static_cast<int64_t>(yo0 + rr) * out_row_bytes;
             const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(orow), 0, out_row_bytes, 0x00020000);
             const int emask = emit ? 0 : OOB;
+            if (!epi_live) {
+                // (K48, last quarter: nothing to compute -- but VM_CNT counts two stores per odd step in every wave: the counted wait
+                //  at the top of a step is the same immediate for all of them)
+                __builtin_amdgcn_raw_buffer_store_b64(i32x2{0, 0}, rs, OOB, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b64(i32x2{0, 0}, rs, OOB, 0, 0);
+            } else
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 i32x2 tq[2][2][2];          // [lo / hi][K half][block]
@@ -447,6 +480,35 @@ void rn_stage5x_pack(const float* w_hwio, int dtype, unsigned short (*cvt_bf16)(
                 }
 }
 
+// K48 fragments: frag[f = ky * 5 + j][cout quarter q][lane][e]: j < 3 = W[tap (ky, kx = j)][channel 8 (lane / 16) + e]; j = 3: lane groups
+// 0, 1 = W[tap (ky, 0)][channel 32 + 8 g + e], groups 2, 3 = W[tap (ky, 1)][channel 32 + 8 (g - 2) + e]; j = 4: groups 0, 1 =
+// W[tap (ky, 2)][channel 32 + 8 g + e], groups 2, 3 = 0.  Channels 48..63 (constants on the handle) do not appear.
+void rn_stage5x_pack48(const float* w_hwio, int dtype, unsigned short (*cvt_bf16)(float), unsigned short (*cvt_f16)(float),
+                       std::vector<unsigned short>* out) {
+    out->assign(static_cast<size_t>(15) * 4 * 64 * 8, 0);
+    for (int ky = 0; ky < 3; ++ky)
+        for (int j = 0; j < 5; ++j)
+            for (int q = 0; q < 4; ++q)
+                for (int l = 0; l < 64; ++l)
+                    for (int e = 0; e < 8; ++e) {
+                        const int g = l >> 4, co = 16 * q + (l & 15);
+                        int kx, ch;
+                        if (j < 3) {
+                            kx = j;
+                            ch = 8 * g + e;
+                        } else if (j == 3) {
+                            kx = g >> 1;
+                            ch = 32 + 8 * (g & 1) + e;
+                        } else {
+                            if (g >= 2) continue;
+                            kx = 2;
+                            ch = 32 + 8 * g + e;
+                        }
+                        const float v = w_hwio[(static_cast<size_t>(ky * 3 + kx) * 64 + ch) * 64 + co];
+                        (*out)[((static_cast<size_t>(ky * 5 + j) * 4 + q) * 64 + l) * 8 + e] = dtype == RN_DTYPE_BF16 ? cvt_bf16(v) : cvt_f16(v);
+                    }
+}
+
 int rn_stage5x_launch(int dtype, hipStream_t s, const StageArgs& a, int n) {
     auto launch = [&](auto kern) -> int {
         static std::atomic<unsigned long long> attr_devices{0};
@@ -460,6 +522,10 @@ int rn_stage5x_launch(int dtype, hipStream_t s, const StageArgs& a, int n) {
         RN_CHECK_LAUNCH();
         return RN_OK;
     };
-    if (dtype == RN_DTYPE_BF16) return launch(stage5x_kernel<RN_DTYPE_BF16>);
-    return launch(stage5x_kernel<RN_DTYPE_F16>);
+    if (a.cstart && a.live_q == 2) {
+        if (dtype == RN_DTYPE_BF16) return launch(stage5x_kernel<RN_DTYPE_BF16, true>);
+        return launch(stage5x_kernel<RN_DTYPE_F16, true>);
+    }
+    if (dtype == RN_DTYPE_BF16) return launch(stage5x_kernel<RN_DTYPE_BF16, false>);
+    return launch(stage5x_kernel<RN_DTYPE_F16, false>);
 }

@@ -36,6 +36,25 @@ def test_bench_two_ranks_gloo_stub_engine():
     assert d["unit"] == "images/sec" and d["higher_is_better"] is True and d["vs_baseline"] is None
 
 
+@pytest.mark.timeout(600)
+def test_bench_eight_ranks_gloo_stub_engine_every_gathered_block():
+    """World size 8 -- the node BASELINE config 4 names -- as the driver launches it (torch.distributed.run, one rank per GPU),
+    on the stub engine: eight process groups members, the packed all-gather on every step, and on EVERY rank every one of the
+    eight gathered blocks compared with what that block's rank must have produced from its own input (bench.py asserts it;
+    a rank whose check fails exits non-zero and the launcher reports it)."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "3", "--warmup", "1",
+           "--batch", "5", "--stub-engine", "--no-cpu-baseline"]
+    env = dict(os.environ, OMP_NUM_THREADS="1", MKL_NUM_THREADS="1")
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=560)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["config"]["global_batch"] == 40 and d["config"]["parallelism"] == "dp8" and d["scaling"] == "weak"
+    assert d["value"] > 0 and abs(d["value"] - 40 * 3 / (d["ms_per_step"] * 3e-3)) < 1e-6 * d["value"]
+
+
 @pytest.mark.timeout(300)
 def test_bench_gpus_2_without_a_launcher_starts_two_ranks():
     """`python3 bench.py --gpus 2` as the driver types it -- no torch.distributed.run, no WORLD_SIZE: bench.py starts the
@@ -104,3 +123,23 @@ def test_bench_rccl_path_on_one_gpu():
     d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
     assert d["n_gpus"] == 1 and d["parity"]["checked"] and "all-gather" in d["config"]["workload"]
     assert d["value"] > 50000          # the collective must not serialise the pass (HBM-resident 150 k img/s without it)
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
+def test_forced_collective_line_agrees_with_the_plain_line(record=None):
+    """SCALE's N = 1 point must match BENCH: the same command with and without the distributed code path (one-rank RCCL group, the
+    per-step all-gather, barriers) on the same box.  Alternated A B A B, best of each arm (the pool's run-to-run spread is ~1 %)."""
+    def line(extra):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "200", "--warmup", "20", "--no-cpu-baseline",
+                            "--no-other-configs", "--no-unfolded-arm", "--profile-steps", "1", "--event-steps", "3"] + extra,
+                           cwd=ROOT, capture_output=True, text=True, timeout=400)
+        assert r.returncode == 0, r.stderr[-3000:]
+        return json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    plain, coll = [], []
+    for _ in range(2):
+        plain.append(line([])["value"])
+        coll.append(line(["--force-collective"])["value"])
+    ratio = max(coll) / max(plain)
+    print("plain %s forced-collective %s ratio %.4f" % (plain, coll, ratio))
+    assert 0.98 <= ratio <= 1.02, (plain, coll)

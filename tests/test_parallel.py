@@ -66,3 +66,24 @@ def test_two_rank_gloo_all_gather_matches_single_process(n):
             got = np.load(os.path.join(d, "rank%d.npz" % r))
             np.testing.assert_array_equal(got["ids"], ref_ids)        # every rank holds the whole result
             np.testing.assert_array_equal(got["probs"], ref_probs)
+
+
+def test_group_plan_matches_shard_counts_for_2_to_8_devices():
+    """rn_group_plan -- the shard / slot plan rn_group_forward_u8 applies, exported as a pure function -- against the Python side's
+    shard_bounds for ndev 2..8: n < ndev (empty shards), ragged n, full batches; offsets contiguous; the slot size; the range error."""
+    from roomnet_amd import _capi
+    from roomnet_amd.parallel import shard_bounds, shard_counts
+    for ndev in range(1, 9):
+        for n in (0, 1, 2, ndev - 1, ndev, ndev + 1, 7, 63, 255, 256, 257, 2047, 2048, ndev * 256):
+            if n < 0 or n > ndev * 256:
+                continue
+            counts, offsets, slot = _capi.group_plan(n, ndev, 256, 6)
+            assert counts == shard_counts(n, ndev), (n, ndev)
+            assert offsets == [shard_bounds(n, ndev, r)[0] for r in range(ndev)], (n, ndev)
+            assert sum(counts) == n and max(counts) - min(counts) <= 1 and all(c <= 256 for c in counts)
+            assert slot == 256 * (6 * 4 + 8)
+    import pytest
+    with pytest.raises(ValueError, match="out of range"):        # RN_E_RANGE
+        _capi.group_plan(2049, 8, 256, 6)
+    with pytest.raises(ValueError, match="bad argument"):        # RN_E_INVALID
+        _capi.group_plan(8, 0, 256, 6)
