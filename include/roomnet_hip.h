@@ -92,7 +92,8 @@ extern "C" {
                                     * enter the next convolution as one constant per cout -- 16-bit handles (the fused
                                     * pair's on-chip tensor, the 64 -> 64 residual stage) and float32 matrix-core handles
                                     * (the same stages) alike; this flag is the comparison arm that shows it.  See
-                                    * rn_frozen_info. */
+                                    * rn_frozen_info, rn_const_info (the 16 constant output channels of the first step of
+                                    * the 64-channel block, round 6, are computed under this flag too). */
 #define RN_FLAG_PAIR_32X32 8u /* 16-bit handles: the round-2 kernels instead of the round-3 ones (comparison
                                arm, bench.py --pair32): the cross-stage fused pair of the 32-channel block
                                (network.py:183-203: rn_stage23.hip instead of rn_stage23x.hip; equal up to the fp32 order of
@@ -101,7 +102,10 @@ extern "C" {
                                step (network.py:216-235: rn_stage_rw.hip / rn_conv16.hip instead of
                                rn_stage4x/5x/6x.hip; these differ in the last 16-bit place: other
                                accumulation order, pooling of stride-2 steps as fp16 band-matrix MFMAs); the
-                               stage-0 fusion with wave-private rings instead of the shared ring (bit-identical) */
+                               stage-0 fusion with wave-private rings instead of the shared ring (bit-identical).
+                               TEST / A-B LIBRARY ONLY (round 6): the round-2 pair kernel is linked into
+                               roomnet_amd/lib/libroomnet_hip_ab.so (same exports, csrc/build.sh builds both); the
+                               product library answers this flag with RN_E_INVALID */
 
 #define RN_MAX_STAGES 16
 #define RN_MAX_DENSE 8

@@ -29,6 +29,8 @@ DTYPES = {"f32": RN_DTYPE_F32, "fp32": RN_DTYPE_F32, "float32": RN_DTYPE_F32,
           "f16": RN_DTYPE_F16, "fp16": RN_DTYPE_F16, "float16": RN_DTYPE_F16}
 
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libroomnet_hip.so")
+# the test / A-B library: the product library's objects + the round-2 comparison kernels behind RN_FLAG_PAIR_32X32
+AB_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libroomnet_hip_ab.so")
 
 # every symbol include/roomnet_hip.h declares (tests check the .so exports all of them)
 EXPORTED_SYMBOLS = (
@@ -251,6 +253,8 @@ class Engine:
                  max_batch: int = 64, taps: bool = False, lib_path: Optional[str] = None,
                  stage_launches: bool = False, generic_kernels: bool = False, pair32: bool = False,
                  compute_frozen: bool = False):
+        if pair32 and lib_path is None and "ROOMNET_HIP_LIB" not in os.environ:
+            lib_path = AB_LIB_PATH           # (the round-2 comparison kernels are not in the product library)
         self.lib = load_library(lib_path)
         self.graph = graph
         self.dtype = DTYPES[dtype] if isinstance(dtype, str) else int(dtype)

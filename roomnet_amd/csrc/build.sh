@@ -41,9 +41,22 @@ rm -f "$OBJ/rn_stage6x.o"
 "$HIPCC" "${CFLAGS[@]}" ${RN_RW_FLAGS:--mllvm -amdgpu-mfma-vgpr-form} -c "$HERE/rn_stage6x.hip" -o "$OBJ/rn_stage6x.o" &
 PIDS+=($!)
 for p in "${PIDS[@]}"; do wait "$p"; done
-"$HIPCC" --offload-arch=gfx950 -shared -fPIC "$OBJ"/rn_api.o "$OBJ"/rn_kernels_f32.o "$OBJ"/rn_fused.o "$OBJ"/rn_imageops.o "$OBJ"/rn_group.o "$OBJ"/rn_tail.o "$OBJ"/rn_conv16.o "$OBJ"/rn_stage_rw.o "$OBJ"/rn_stage23.o "$OBJ"/rn_stage23x.o "$OBJ"/rn_stage5x.o "$OBJ"/rn_stage4x.o "$OBJ"/rn_stage6x.o "$OBJ"/rn_stage_f32m.o "$OBJ"/rn_backend.o -ldl -lpthread \
+"$HIPCC" --offload-arch=gfx950 -shared -fPIC "$OBJ"/rn_api.o "$OBJ"/rn_kernels_f32.o "$OBJ"/rn_fused.o "$OBJ"/rn_imageops.o "$OBJ"/rn_group.o "$OBJ"/rn_tail.o "$OBJ"/rn_conv16.o "$OBJ"/rn_stage_rw.o "$OBJ"/rn_stage23x.o "$OBJ"/rn_stage5x.o "$OBJ"/rn_stage4x.o "$OBJ"/rn_stage6x.o "$OBJ"/rn_stage_f32m.o "$OBJ"/rn_backend.o -ldl -lpthread \
     ${RN_EXTRA_FLAGS:-} -o "$OUT/libroomnet_hip.so"
 echo "built $OUT/libroomnet_hip.so"
+# the test / A-B library: the same objects + the round-2 comparison kernels (RN_FLAG_PAIR_32X32: rn_stage23.hip), which the
+# product library does not carry
+AB="$OBJ/ab"
+mkdir -p "$AB"
+rm -f "$AB"/rn_api.o "$AB"/rn_fused.o
+"$HIPCC" "${CFLAGS[@]}" -DRN_ROUND2_ARMS -c "$HERE/rn_api.hip" -o "$AB/rn_api.o" &
+P1=$!
+"$HIPCC" "${CFLAGS[@]}" -DRN_ROUND2_ARMS -c "$HERE/rn_fused.hip" -o "$AB/rn_fused.o" &
+P2=$!
+wait "$P1"; wait "$P2"
+"$HIPCC" --offload-arch=gfx950 -shared -fPIC "$AB"/rn_api.o "$OBJ"/rn_kernels_f32.o "$AB"/rn_fused.o "$OBJ"/rn_imageops.o "$OBJ"/rn_group.o "$OBJ"/rn_tail.o "$OBJ"/rn_conv16.o "$OBJ"/rn_stage_rw.o "$OBJ"/rn_stage23.o "$OBJ"/rn_stage23x.o "$OBJ"/rn_stage5x.o "$OBJ"/rn_stage4x.o "$OBJ"/rn_stage6x.o "$OBJ"/rn_stage_f32m.o "$OBJ"/rn_backend.o -ldl -lpthread \
+    -o "$OUT/libroomnet_hip_ab.so"
+echo "built $OUT/libroomnet_hip_ab.so"
 # register report of the hot kernels: a spill in one of them costs ~25 % of its time (seen on the fused stage pair) and
 # hipcc does not warn about it
 if [ -x "$ROOT/tools/spills.sh" ]; then

@@ -133,6 +133,13 @@ int validate(const rn_weights* w, int dtype, int max_batch, unsigned flags) {
         rn_set_error("rn_create: unknown flag bits 0x%x", flags);
         return RN_E_INVALID;
     }
+#ifndef RN_ROUND2_ARMS
+    if (flags & RN_FLAG_PAIR_32X32) {
+        rn_set_error("rn_create: RN_FLAG_PAIR_32X32 selects the round-2 comparison kernels, which are built into libroomnet_hip_ab.so "
+                     "(tests and A/B runs; roomnet_amd/csrc/build.sh) and not into this library");
+        return RN_E_INVALID;
+    }
+#endif
     if ((flags & RN_FLAG_TAPS) && dtype != RN_DTYPE_F32) {
         rn_set_error("rn_create: RN_FLAG_TAPS needs RN_DTYPE_F32 (the unfused per-node path)");
         return RN_E_INVALID;

@@ -644,6 +644,7 @@ struct FusedState {
     bool const4 = false;             // 16 of them sit in positions 48..63 and are not computed
     unsigned short const4_val[16] = {};   // their stored values (s4.bn positions 48..63)
     unsigned short const5_val[16] = {};   // ... and of the residual stage's output (s5.bn2 positions 48..63)
+    unsigned short* const_vals_dev = nullptr;   // [2][16] on the device: const4_val | const5_val (StageArgs::cvals)
     float* s5_cstart = nullptr;      // [64] what the 16 constant input channels add to every conv output of the residual stage
     i32x4* s5_wfrag48 = nullptr;     // the residual stage's fragments without them (rn_stage5x_pack48)
     std::map<int, std::vector<int>> node_perm;
@@ -1069,6 +1070,19 @@ int rn_fused_prepare(rn_handle* h, const rn_weights* w_in) {
     }
     if (fs->const4 && !(fs->fold5_stage >= 1 && fs->st[fs->fold5_stage - 1].use_s4x && fs->st[fs->fold5_stage].use_s5x && fs->s5_wfrag48 && fs->s5_cstart))
         fs->const4 = false;          // (another kernel family runs one of the two stages: every channel is computed)
+    if (fs->const4) {
+        unsigned short both[32];
+        std::memcpy(both, fs->const4_val, 32);
+        std::memcpy(both + 16, fs->const5_val, 32);
+        void* dv = nullptr;
+        if (hipMalloc(&dv, sizeof both) != hipSuccess) {
+            rn_set_error("hipMalloc(constant channel values) failed");
+            return RN_E_NOMEM;
+        }
+        h->allocs.push_back(dv);
+        RN_HIP(hipMemcpy(dv, both, sizeof both, hipMemcpyHostToDevice));
+        fs->const_vals_dev = static_cast<unsigned short*>(dv);
+    }
     // ---- cross-stage fusion: the last two steps of a depth-3 block (network.py:183-203 with block_depth = 3):
     // stage i (32->32, pool 4/1) feeds only stage i+1 (32->32, pool 4/1 + residual), whose skip tensor is stage i's
     // INPUT.  One kernel runs both; stage i's output never reaches HBM.
@@ -1442,7 +1456,12 @@ int rn_fused_forward(rn_handle* h, const uint8_t* d_bgr, const float* d_rgb, int
 #ifdef RN_CLOCK
             if (fs->pair_x16) fa.stamp_buf = rn_clock_region("stages 2+3", static_cast<size_t>(fa.n_bands) * fa.n_cblocks * n);
 #endif
+#ifdef RN_ROUND2_ARMS
             int rc = fs->pair_x16 ? rn_stage23x_launch(h->dtype, h->stream, fa, n) : rn_stage23_launch(h->dtype, h->stream, fa, n);
+#else
+            // (the round-2 pair kernel, rn_stage23.hip, is part of the test / A-B library only: rn_create refuses RN_FLAG_PAIR_32X32 here)
+            int rc = rn_stage23x_launch(h->dtype, h->stream, fa, n);
+#endif
             if (rc != RN_OK) return rc;
 #ifdef RN_STAMPS
             (void)hipStreamSynchronize(h->stream);
@@ -1574,10 +1593,14 @@ int rn_fused_forward(rn_handle* h, const uint8_t* d_bgr, const float* d_rgb, int
             }
 #endif
             a.live_q = (f.use_s5x && static_cast<int>(i) == fs->fold5_stage) ? fs->fold5_live_q : 4;
-            if (fs->const4 && f.use_s4x && static_cast<int>(i) + 1 == fs->fold5_stage) a.live_q = 3;      // its last cout quarter is constant
+            if (fs->const4 && f.use_s4x && static_cast<int>(i) + 1 == fs->fold5_stage) {      // its last cout quarter is constant
+                a.live_q = 3;
+                a.cvals = fs->const_vals_dev;
+            }
             if (fs->const4 && f.use_s5x && static_cast<int>(i) == fs->fold5_stage) {
                 a.wfrag = fs->s5_wfrag48;
                 a.cstart = fs->s5_cstart;
+                a.cvals = fs->const_vals_dev + 16;
             }
             int rc = f.use_s5x   ? rn_stage5x_launch(h->dtype, h->stream, a, n)
                      : f.use_s4x ? rn_stage4x_launch(h->dtype, h->stream, a, n)

@@ -274,6 +274,10 @@ struct StageArgs {
     // fragments, cstart[cout] = what the constants add to every conv output (the accumulators' start value), and the waves of the
     // last quarter -- whose output channels are constants too -- do nothing.
     const float* cstart;
+    // the 16 constant output channels (positions 48..63) of a stage that does not compute them, as stored 16-bit values: the
+    // kernels write them next to the computed channels so that every 128-byte pixel of the output leaves as a FULL line (lines
+    // with a quarter missing are read-modify-write cycles of the ECC memory: measured 10-20 % on both launches, box by box)
+    const unsigned short* cvals;
 };
 
 // Column-block plan of a row-blocked kernel: the fewest blocks (<= 4) of equal width +-1 whose widths lie in [wo_min, wo_max].

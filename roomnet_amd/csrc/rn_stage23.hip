@@ -707,28 +707,6 @@ __global__ __launch_bounds__(512, 2) void stage23pc_kernel(const Stage23Args a) 
 
 }  // namespace
 
-// Column blocks of the output side (= in_side - 10): as few as fit the rings, of equal width +-1.  Every block's input
-// width (its output width + 10) must lie in [F_WMIN, F_WMAX].  224 x 224: one block of 205; 600 x 600: 194 + 194 + 193.
-bool rn_stage23_plan(int in_side, int* n_cblocks, int* x0, int* wo) {
-    const int out = in_side - 10;
-    if (out < F_WMIN - 10) return false;
-    const int nb = (out + (F_WMAX - 10) - 1) / (F_WMAX - 10);
-    if (nb > 4) return false;
-    const int base = out / nb, rem = out % nb;
-    if (base + 10 < F_WMIN) return false;
-    int x = 0;
-    for (int b = 0; b < nb; ++b) {
-        const int w = base + (b < rem ? 1 : 0);
-        if (x0) x0[b] = x;
-        if (wo) wo[b] = w;
-        x += w;
-    }
-    if (n_cblocks) *n_cblocks = nb;
-    return true;
-}
-
-bool rn_stage23_supported(int in_side) { return rn_stage23_plan(in_side, nullptr, nullptr, nullptr); }
-
 int rn_stage23_launch(int dtype, hipStream_t s, const Stage23Args& a, int n) {
     auto launch = [&](auto kern) -> int {
         static std::atomic<unsigned long long> attr_devices{0};     // per device and instantiation, see launch_rw

@@ -45,6 +45,7 @@ namespace {
 // once); the rate does not move (the pass is not bound by HBM; gpurun_out/r4/s17_nt.txt).
 constexpr int RN_NT_OUT = 2, RN_NT_SKIP = 2;
 constexpr int X_NA = 4, X_NB = 4, X_NSK = 3;     // ring depths: A rows, B rows, private skip rows
+constexpr int X_WMIN = 193;
 constexpr int X_WMAX = 215;                      // widest A row (column blocks: 193..215, rn_stage23_plan; the tail DMA piece needs W > 192)
 constexpr int X_ROWA = X_WMAX * 64;              // bytes per A ring row (32 channels x 16 bit per pixel)
 constexpr int X_BDUMMY = X_WMAX - 5;             // B ring column that invalid lanes write to (never read for a valid output)
@@ -881,6 +882,28 @@ __global__ __launch_bounds__(512, 2) void stage23x_kernel(const Stage23Args a) {
 }
 
 }  // namespace
+
+// Column blocks of the output side (= in_side - 10): as few as fit the rings, of equal width +-1.  Every block's input
+// width (its output width + 10) must lie in [X_WMIN, X_WMAX].  224 x 224: one block of 205; 600 x 600: 194 + 194 + 193.
+bool rn_stage23_plan(int in_side, int* n_cblocks, int* x0, int* wo) {
+    const int out = in_side - 10;
+    if (out < X_WMIN - 10) return false;
+    const int nb = (out + (X_WMAX - 10) - 1) / (X_WMAX - 10);
+    if (nb > 4) return false;
+    const int base = out / nb, rem = out % nb;
+    if (base + 10 < X_WMIN) return false;
+    int x = 0;
+    for (int b = 0; b < nb; ++b) {
+        const int w = base + (b < rem ? 1 : 0);
+        if (x0) x0[b] = x;
+        if (wo) wo[b] = w;
+        x += w;
+    }
+    if (n_cblocks) *n_cblocks = nb;
+    return true;
+}
+
+bool rn_stage23_supported(int in_side) { return rn_stage23_plan(in_side, nullptr, nullptr, nullptr); }
 
 // B-operand fragments of the 16x16x32 form: frag[tap][half][lane][j] = W[k = 32 tap + 8 (lane / 16) + j][cout(half, lane % 16)]
 // with cout(h, n) = 8 (n / 4) + 4 h + n % 4 (so that a lane's pooled rows 4 g + i of the two halves are couts 8 g .. 8 g + 7)

@@ -14,9 +14,11 @@ result because the graph has no cross-image coupling (inference-mode BN).
 """
 from __future__ import annotations
 
+import contextlib
 from glob import glob
 import os
 import shutil
+import sys
 
 import numpy as np
 
@@ -66,6 +68,11 @@ def _classify(nn, ims):
     return outs if isinstance(outs, tuple) else (outs, None)
 
 
+class _Closer:
+    def __init__(self, fn):
+        self.close = fn
+
+
 def _usable_cores():
     try:
         return len(os.sched_getaffinity(0))          # the cores THIS process may run on (cgroup / taskset aware)
@@ -77,6 +84,21 @@ def _usable_cores():
 # page faults of its fresh 6-8 MB buffers (tools/bench_images.py --threads and tools/bench_decode.py sweep it: 16 is the optimum for
 # VGA files, 32 is 13 % better for 1080p; DESIGN.md section 5 has the figures of the GPU box's 256-thread host).
 DECODE_THREADS = max(1, min(16, _usable_cores()))
+
+
+def _progress(n):
+    """The reference walks its file list under ``tqdm(range(num_fpaths))`` (infer.py:46, :79): a progress bar on stderr.  Same here
+    when tqdm is importable and stderr is a terminal or ROOMNET_PROGRESS=1 asks for it; returns an ``update(k)`` callable and a
+    ``close()``."""
+    try:
+        from tqdm import tqdm
+    except ImportError:
+        return (lambda k=1: None), (lambda: None)
+    want = os.environ.get('ROOMNET_PROGRESS')
+    if want == '0' or (want is None and not sys.stderr.isatty()):
+        return (lambda k=1: None), (lambda: None)
+    bar = tqdm(total=n, file=sys.stderr)
+    return bar.update, bar.close
 
 
 def _infer_files(nn, fpaths, batch_size, decode_threads=None):
@@ -102,7 +124,8 @@ def _infer_files(nn, fpaths, batch_size, decode_threads=None):
     window = max(2 * batch_size, nthreads)
     todo = iter(enumerate(fpaths))
     inflight = deque()
-    with ThreadPoolExecutor(max_workers=nthreads) as pool:
+    tick, done = _progress(len(fpaths))
+    with contextlib.closing(_Closer(done)), ThreadPoolExecutor(max_workers=nthreads) as pool:
         def top_up():
             while len(inflight) < window:
                 nxt = next(todo, None)
@@ -113,6 +136,7 @@ def _infer_files(nn, fpaths, batch_size, decode_threads=None):
         while inflight:
             i, fpath, fut = inflight.popleft()
             im = fut.result()
+            tick(1)
             top_up()
             if im is None:
                 # the reference crashes here (cv2.imread returns None, infer.py:81-82); report and go on

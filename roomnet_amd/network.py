@@ -62,6 +62,44 @@ def _initializer_values(graph: Graph, seed: int = 0) -> Dict[str, np.ndarray]:
     return out
 
 
+class _Placeholder:
+    """What the reference keeps in ``self.x_tensor`` (``network.py:28``: ``tf.placeholder(tf.float32, [None, S, S, 3],
+    name='input_x_tensor')``): there is no TensorFlow graph here, so it is a description -- ``name``, ``shape``, ``dtype`` -- and
+    the first entry of ``RoomNet.layers``."""
+
+    def __init__(self, im_side):
+        self.name = 'input_x_tensor:0'
+        self.shape = [None, im_side, im_side, 3]
+        self.dtype = np.float32
+
+    def __repr__(self):
+        return "<placeholder %r shape=(?, %d, %d, 3) dtype=float32>" % (self.name, self.shape[1], self.shape[2])
+
+
+def _layer_names(graph: Graph):
+    """``RoomNet.layers`` of the reference (``network.py:30``, ``:207``, ``:222``): the placeholder, then one list per conv_block /
+    dense_block with that block's tensors in creation order.  Here the entries are the NAMES the per-layer read-out answers to
+    (``RoomNet.tap(name)`` -> ``rn_tap``): ``sK.conv`` (conv + ReLU6), ``sK.pool``, ``sK.bn``, ``sK.add``, ``sK.bn2`` for conv stage K,
+    ``dK.mm``, ``dK.relu``, ``dK.bn`` for dense block K.  A conv_block of depth d is d consecutive stages; the block that a stage
+    with a skip connection closes started at its skip stage."""
+    blocks, cur = [], []
+    for s in graph.stages:
+        names = ["s%d.conv" % s.index] + (["s%d.pool" % s.index] if s.pool_k else []) + ["s%d.bn" % s.index]
+        if s.residual:
+            names += ["s%d.add" % s.index, "s%d.bn2" % s.index]
+        cur.append((s, names))
+    # group: a residual stage ends the block its skip stage began; other stages are blocks of their own unless inside such a span
+    i, n = 0, len(cur)
+    ends = {s.skip_stage: s.index for s, _ in cur if s.residual}
+    while i < n:
+        j = ends.get(cur[i][0].index, cur[i][0].index)
+        blocks.append([nm for k in range(i, j + 1) for nm in cur[k][1]])
+        i = j + 1
+    for d in graph.dense:
+        blocks.append(["d%d.mm" % d.index, "d%d.relu" % d.index] + (["d%d.bn" % d.index] if d.bn_name else []))
+    return blocks
+
+
 class RoomNet:
 
     def __init__(self, num_classes, im_side=600, compute_bn_mean_var=True, start_step=0, dropout_enabled=False,
@@ -83,6 +121,9 @@ class RoomNet:
             raise NotImplementedError("compute_bn_mean_var=True (batch-statistics BN) belongs to the training "
                                       "path, which is out of scope; construct with compute_bn_mean_var=False")
         self.graph = build_graph(num_classes=num_classes, im_side=im_side)
+        # network.py:28-30: the input placeholder and the per-block list of layer tensors -- here their descriptions / tap names
+        self.x_tensor = _Placeholder(im_side)
+        self.layers = [self.x_tensor] + _layer_names(self.graph)
         self.device = device
         self.dtype = dtype
         self.max_batch = max_batch
@@ -173,6 +214,12 @@ class RoomNet:
             self.sess.engine = Engine(self.graph, self.sess.variables, device=self.device, dtype=self.dtype,
                                       max_batch=self.max_batch)
         return self.sess.engine
+
+    def tap(self, name, n=1):
+        """The per-layer read-out the reference gets from ``sess.run(self.layers[k][j], ...)``: tensor ``name`` (an entry of
+        ``self.layers``) of the LAST inference call, float32 ``[n, h, w, c]`` (``rn_tap``).  Float32 engines built with taps hold
+        every node; the throughput engines hold the tensors their launches write (RoomNetLibraryError otherwise)."""
+        return self._engine().tap(name, n)
 
     # ----------------------------------------------------------------- inference
     def infer(self, im_in):

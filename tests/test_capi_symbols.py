@@ -47,3 +47,16 @@ def test_no_product_module_imports_the_oracle():
                 text = open(os.path.join(dirpath, f), errors="replace").read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M), f
                 assert "tf_ops" not in text, f
+
+
+def test_ab_library_exports_the_same_symbols_and_only_it_takes_the_round2_flag(weights):
+    """Round 6: the round-2 comparison kernels (RN_FLAG_PAIR_32X32, rn_stage23.hip) live in libroomnet_hip_ab.so -- the product
+    library's objects plus that one -- and the product library answers the flag with RN_E_INVALID before it touches a device."""
+    assert os.path.isfile(_capi.AB_LIB_PATH), "csrc/build.sh builds both libraries"
+    ab = ctypes.CDLL(_capi.AB_LIB_PATH)
+    for name in _declared_symbols():
+        assert hasattr(ab, name), name
+    assert os.path.getsize(_capi.LIB_PATH) < os.path.getsize(_capi.AB_LIB_PATH)
+    from roomnet_amd.graph import build_graph
+    with pytest.raises(ValueError, match="libroomnet_hip_ab.so"):
+        _capi.Engine(build_graph(6, 224), weights, device=0, dtype="bf16", max_batch=1, pair32=True, lib_path=_capi.LIB_PATH)

@@ -814,38 +814,131 @@ def test_two_slot_pipeline_out_of_pinned_host_buffers(engine, parity_images):
         _capi.PinnedArray((1 << 46,), np.uint8)                   # 64 TiB: the error convention, not an abort
 
 
+def _to16_rne(x, dtype):
+    """float32 -> the handle's 16-bit storage and back (round to nearest even), as the kernels' v_cvt_pk_* do."""
+    x = np.ascontiguousarray(x, np.float32)
+    if dtype == "f16":
+        return x.astype(np.float16).astype(np.float32)
+    u = x.view(np.uint32).astype(np.uint64)
+    r = ((u + 0x7FFF + ((u >> 16) & 1)) & 0xFFFF0000).astype(np.uint32)
+    return r.view(np.float32)
+
+
+def _bn_tables(weights, bn_index, pool_area):
+    """(scale, shift) of a pooled stage's folded BatchNorm as rn_fused_prepare builds them in float32: the kernels form
+    fma(H, scale, shift) with H = the pooled SUM of ReLU6 / 6 values (network.py:189-193; weights / 6, scale x 6)."""
+    n = "batch_normalization" if bn_index == 0 else "batch_normalization_%d" % bn_index
+    g, b, m, v = (np.asarray(weights[n + "/" + k], np.float32) for k in ("gamma", "beta", "moving_mean", "moving_variance"))
+    inv = (np.float32(1.0) / np.sqrt(v + np.float32(1e-3))) * g
+    sc = (inv / np.float32(pool_area)) * np.float32(6.0)
+    sh = b - m * inv
+    return sc.astype(np.float32), sh.astype(np.float32)
+
+
+def _per_channel_arms(a, b, dtype, exact_channels, what, frac=1e-3, n_ulp=2):
+    """Folded against computed, channel by channel: the channels in `exact_channels` bit for bit; the others differ only where
+    a one-ulp difference upstream (another fp32 summation order) tips a 16-bit rounding: at most `frac` of the elements, each
+    by at most `n_ulp` 16-bit ulps of the element (1 % of the abs-max as the floor)."""
+    for c in exact_channels:
+        np.testing.assert_array_equal(a[..., c], b[..., c], err_msg="%s channel %d" % (what, c))
+    ulp = 2.0 ** (-8 if dtype == "bf16" else -11)
+    d = np.abs(a.astype(np.float64) - b.astype(np.float64))
+    lim = n_ulp * ulp * np.maximum(np.abs(b.astype(np.float64)), 0.01 * float(np.abs(b).max()))
+    assert int((a != b).sum()) <= max(2, frac * a.size) and float((d / lim).max()) <= 1.0, (what, dtype, int((a != b).sum()), a.size, float((d / lim).max()))
+
+
 @pytest.mark.parametrize("dtype", ["bf16", "f16"])
 def test_frozen_channels_fold_against_computing_them(weights, parity_images, dtype, record):
-    """Round 5: 16 of the 32 channels of the fused pair's on-chip tensor (stage 2's output) are FROZEN on the shipped checkpoint
-    -- the reference's L2 regulariser drove their BN gammas to ~1e-20, their stored 16-bit value is one number for every image,
-    which rn_create proves per channel -- so the default handle does not convolve them (RN_FLAG_COMPUTE_FROZEN: the arm that
-    does).  Both arms against each other at batch 1 / 8 / 160 (band decompositions, the one-launch back end) and against the
-    oracle through the shared parity tests; the probabilities agree far inside the parity tolerance."""
+    """Rounds 5 / 6: channels the shipped checkpoint's BatchNorm freezes are not convolved (rn_create proves them constant;
+    RN_FLAG_COMPUTE_FROZEN is the arm that computes them).  Both arms against each other at batch 1 / 8 / 160 (band
+    decompositions, the one-launch back end), CHANNEL BY CHANNEL: the constant channels of s4.bn (round 6: the 16-bit store of
+    fma(H, sc, sh) is one number for every H in [0, 16]) hold that number at every pixel in BOTH arms, and so do the channels of
+    s5.bn2 behind them; every other channel differs in <= 1e-3 of its elements by <= 2 ulps (measured: 3e-5 of the elements, one
+    ulp).  Both arms are held to the oracle by the shared parity tests."""
     g = build_graph(6, 224)
+    sc4, sh4 = _bn_tables(weights, 5, 16)
+    const4 = [c for c in range(64) if _to16_rne(np.float32(0.0) * sc4[c] + sh4[c], dtype) == _to16_rne(np.float32(np.float32(16.0) * sc4[c] + sh4[c]), dtype)]
     for nb in (1, 8, 160):
         pick = (np.arange(nb) * 5) % len(parity_images)
         ims = parity_images[pick]
         fold = _capi.Engine(g, weights, device=0, dtype=dtype, max_batch=nb)
         full = _capi.Engine(g, weights, device=0, dtype=dtype, max_batch=nb, compute_frozen=True)
         try:
+            ci = fold.const_info()
+            assert ci["stage"] == 4 and ci["channels_not_convolved"] == 16 and ci["next_stage_input_channels"] == 48, ci
+            assert ci["channels_proven_constant"] == len(const4) == (26 if dtype == "bf16" else 23), (ci, len(const4))
+            assert full.const_info()["stage"] == -1
             ids_a, probs_a = fold.forward_u8(ims)
             ids_b, probs_b = full.forward_u8(ims)
-            a, b = fold.tap("s3.bn2", nb), full.tap("s3.bn2", nb)
-            _same_up_to_sum_order(a, b, dtype, ("s3.bn2 folded vs computed", nb))
             np.testing.assert_array_equal(fold.tap("s1.bn", nb), full.tap("s1.bn", nb))      # (in front of the pair: the same kernel)
-            # stage 5's frozen quarters: its 44 frozen first-BN channels are not convolved and the channels of s4.bn / s5.bn2 are
-            # stored relabelled -- rn_tap hands them out in the reference's order (a wrong relabelling would be off by O(1))
-            _same_up_to_sum_order(fold.tap("s4.bn", nb), full.tap("s4.bn", nb), dtype, ("s4.bn folded vs computed", nb), frac=1e-2, n_ulp=8)
-            _same_up_to_sum_order(fold.tap("s5.bn2", nb), full.tap("s5.bn2", nb), dtype, ("s5.bn2 folded vs computed", nb), frac=3e-2, n_ulp=16)
+            a, b = fold.tap("s3.bn2", nb), full.tap("s3.bn2", nb)
+            _per_channel_arms(a, b, dtype, [], ("s3.bn2", nb))
+            a4, b4 = fold.tap("s4.bn", nb), full.tap("s4.bn", nb)
+            for arm in (a4, b4):          # the constant channels ARE their table value, in both arms, at every pixel
+                for c in const4:
+                    assert (arm[..., c] == _to16_rne(sh4[c], dtype)).all(), (dtype, nb, c)
+            _per_channel_arms(a4, b4, dtype, const4, ("s4.bn", nb))
+            a5, b5 = fold.tap("s5.bn2", nb), full.tap("s5.bn2", nb)
+            const5 = [c for c in range(64) if np.unique(b5[..., c]).size == 1]         # (frozen first BN + constant skip channel)
+            assert len(const5) >= 16 and set(const5) <= set(const4), (const5, const4)
+            _per_channel_arms(a5, b5, dtype, const5, ("s5.bn2", nb))
             np.testing.assert_allclose(probs_a, probs_b, rtol=0, atol=2e-3)
             np.testing.assert_array_equal(ids_a, ids_b)
             if nb == 160:
                 record("frozen_channel_fold", dtype, {"elements_differing_in_s3_bn2": int((a != b).sum()), "elements": int(a.size),
                                                        "max_abs_diff_s3_bn2": float(np.abs(a - b).max()),
+                                                       "elements_differing_in_s5_bn2": int((a5 != b5).sum()), "elements_s5_bn2": int(a5.size),
+                                                       "constant_channels_s4_bn": len(const4), "constant_channels_s5_bn2": len(const5),
                                                        "max_abs_dprob": float(np.abs(probs_a - probs_b).max())})
         finally:
             fold.close()
             full.close()
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+def test_frozen_channels_are_their_table_value_at_every_pixel(weights, parity_images, dtype):
+    """The fold's premise, on the tensors themselves (one launch per stage, so that s2.bn exists in HBM): every channel of s2.bn
+    whose fma returns its addend in float32 (|sc| 16 < 2^-25 |sh|) equals to16(sh) at every pixel of every image -- computed
+    (RN_FLAG_COMPUTE_FROZEN) and default handle alike; the live channels are not constants."""
+    g = build_graph(6, 224)
+    sc2, sh2 = _bn_tables(weights, 2, 16)
+    frozen = [c for c in range(32) if abs(float(sc2[c])) * 16.0 * (1.0 + 1e-6) < abs(float(sh2[c])) * 2.0 ** -25]
+    assert len(frozen) == 18
+    ims = parity_images[[1, 14, 30, 41, 52, 56, 60, 63]]
+    for cf in (False, True):
+        e = _capi.Engine(g, weights, device=0, dtype=dtype, max_batch=8, stage_launches=True, compute_frozen=cf)
+        try:
+            e.forward_u8(ims)
+            t = e.tap("s2.bn", 8)
+            for c in range(32):
+                if c in frozen:
+                    assert (t[..., c] == _to16_rne(sh2[c], dtype)).all(), (dtype, cf, c)
+            assert sum(np.unique(t[..., c]).size > 1 for c in range(32) if c not in frozen) >= 6
+        finally:
+            e.close()
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+def test_results_are_reproducible_at_batch_160_in_both_arms(weights, parity_images, dtype):
+    """Twelve passes over the same 160 images on one handle give the same bits every time -- stage tensors, probabilities, ids --
+    on the default handle and on the computing arm (a counted wait one short, a ring slot reused too early would show here as a
+    rare differing tile)."""
+    g = build_graph(6, 224)
+    ims = parity_images[(np.arange(160) * 7) % len(parity_images)]
+    for cf in (False, True):
+        e = _capi.Engine(g, weights, device=0, dtype=dtype, max_batch=160, compute_frozen=cf)
+        try:
+            ids0, probs0 = e.forward_u8(ims)
+            t0 = {n: e.tap(n, 160) for n in ("s3.bn2", "s4.bn", "s5.bn2")}
+            for rep in range(12):
+                ids, probs = e.forward_u8(ims)
+                np.testing.assert_array_equal(probs, probs0)
+                np.testing.assert_array_equal(ids, ids0)
+                if rep % 4 == 3:
+                    for n, t in t0.items():
+                        np.testing.assert_array_equal(e.tap(n, 160), t, err_msg="%s rep %d cf %s" % (n, rep, cf))
+        finally:
+            e.close()
 
 
 @pytest.mark.parametrize("case", ["none", "stage2_only_15_and_17", "both_other_sets", "everything_of_stage2"])
@@ -871,6 +964,23 @@ def test_frozen_channel_fold_on_other_checkpoints(weights, parity_images, case):
             info = e.frozen_info()
             for k, v in want.items():
                 assert info[k] == v, (case, dtype, info)
+            # round 6: the constant channels of s4.bn fold only behind a folded stage 5, and only with 16 channels that are both
+            # constants of stage 4's 16-bit store and frozen channels of stage 5 (restated here in NumPy float32)
+            sc4, sh4 = _bn_tables(w, 5, 16)
+            c4 = {c for c in range(64) if _to16_rne(sh4[c], dtype) == _to16_rne(np.float32(np.float32(16.0) * sc4[c] + sh4[c]), dtype)}
+            f32 = np.float32
+            g6, b6, m6, v6 = (np.asarray(w["batch_normalization_6/" + k], f32) for k in ("gamma", "beta", "moving_mean", "moving_variance"))
+            g7, b7, m7, v7 = (np.asarray(w["batch_normalization_7/" + k], f32) for k in ("gamma", "beta", "moving_mean", "moving_variance"))
+            inv6 = (f32(1.0) / np.sqrt(v6 + f32(1e-3))) * g6
+            inv7 = (f32(1.0) / np.sqrt(v7 + f32(1e-3))) * g7
+            t1 = (b6 - m6 * inv6) * inv7 + (b7 - m7 * inv7)
+            t0 = ((inv6 / f32(16.0)) * inv7) * f32(6.0)
+            fz5 = {c for c in range(64) if abs(float(t0[c])) * 16.0 * (1.0 + 1e-6) < abs(float(t1[c])) * 2.0 ** -25}
+            ci = e.const_info()
+            expect_fold = info["residual_stage_folded"] == 5 and len(c4 & fz5) >= 16
+            assert ci["stage"] == (4 if expect_fold else -1), (case, dtype, ci, len(c4), len(fz5), len(c4 & fz5))
+            if info["residual_stage_folded"] == 5:
+                assert ci["channels_proven_constant"] == len(c4), (case, dtype, ci, len(c4))
             ids, probs = e.forward_u8(ims)
             for name in ("s1.bn", "s3.bn2", "s4.bn", "s5.bn2", "s8.bn"):
                 got, ref_t = e.tap(name, 4), np.asarray(ref["taps"][name])

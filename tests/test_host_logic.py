@@ -416,3 +416,50 @@ def test_classify_im_dir_writes_overlays_on_the_writer_pool(tmp_path, capsys):
     cells = read_xls(xl)["classification_results"]
     assert [cells[(r + 1, 0)] for r in range(len(listed))] == [os.path.basename(p) for p in listed]
     assert all(cells[(r + 1, 1)] in CLASS_LABELS for r in range(len(listed))) and (len(listed) + 1, 0) not in cells
+
+
+def test_directory_drivers_show_the_reference_progress_bar_on_stderr(tmp_path, capsys, monkeypatch):
+    """infer.py:46 / :79 walk the file list under tqdm: a progress bar on stderr, nothing on stdout.  Here: the same bar when tqdm
+    is importable and stderr is a terminal, or ROOMNET_PROGRESS=1 asks for it (0 = never); it counts every file of the list."""
+    pytest.importorskip("tqdm")
+    from roomnet_amd import infer as I
+    from roomnet_amd.imageio import imwrite
+    rng = np.random.default_rng(2)
+    paths = []
+    for k in range(5):
+        p = str(tmp_path / ("im%02d.png" % k))
+        imwrite(p, rng.integers(0, 256, (30, 40, 3), dtype=np.uint8))
+        paths.append(p)
+
+    class Stub:
+        im_side = 16
+
+        def center_crop(self, x):
+            h, w, _ = x.shape
+            o = abs((w - h) // 2)
+            return x[:, o:o + h, :] if h < w else (x[o:o + w, :, :] if w < h else x.copy())
+
+        def infer(self, batch):
+            return np.zeros(len(batch), np.int64), np.tile(np.float32([1, 0, 0, 0, 0, 0]), (len(batch), 1))
+
+    monkeypatch.setenv("ROOMNET_PROGRESS", "1")
+    assert len(list(I._infer_files(Stub(), paths, batch_size=2, decode_threads=2))) == 5
+    cap = capsys.readouterr()
+    assert "5/5" in cap.err and "5/5" not in cap.out
+    monkeypatch.setenv("ROOMNET_PROGRESS", "0")
+    assert len(list(I._infer_files(Stub(), paths, batch_size=2, decode_threads=2))) == 5
+    assert "5/5" not in capsys.readouterr().err
+
+
+def test_roomnet_keeps_the_reference_x_tensor_and_layers_attributes():
+    """network.py:28-30, :207, :222: ``x_tensor`` (the input placeholder) and ``layers`` = [placeholder, one list per conv_block /
+    dense_block].  Here they describe the same structure: 1 + 5 + 4 entries, the blocks' tensors by their tap names."""
+    from roomnet_amd.network import RoomNet
+    nn = RoomNet(num_classes=6, im_side=224, compute_bn_mean_var=False, optimized_inference=True)
+    assert nn.x_tensor.shape == [None, 224, 224, 3] and nn.x_tensor.name == "input_x_tensor:0" and nn.x_tensor.dtype == np.float32
+    assert nn.layers[0] is nn.x_tensor and len(nn.layers) == 10
+    assert nn.layers[1] == ["s0.conv", "s0.pool", "s0.bn"]                       # network.py:226
+    assert nn.layers[2][0] == "s1.conv" and nn.layers[2][-2:] == ["s3.add", "s3.bn2"] and len(nn.layers[2]) == 11   # :227, depth 3
+    assert nn.layers[3][-1] == "s5.bn2" and nn.layers[4] == ["s6.conv", "s6.bn"] and nn.layers[5][-1] == "s9.bn2"   # :228-230
+    assert nn.layers[6] == ["d0.mm", "d0.relu", "d0.bn"] and nn.layers[9] == ["d3.mm", "d3.relu"]                   # :234-237
+    assert RoomNet(6, im_side=600, compute_bn_mean_var=False, optimized_inference=True).x_tensor.shape[1] == 600
