@@ -213,6 +213,11 @@ RN_API int rn_forward_f32_device(rn_handle* h, const float* d_rgb_nhwc, int n, f
  * buffer [max_batch, im_side, im_side, 3] that rn_forward_u8_device then takes.  Integer-exact restatement of
  * OpenCV's fixed-point algorithm (bit-identical to roomnet_amd/imageops.py).  Asynchronous on the handle's stream. */
 RN_API int rn_crop_resize_u8_device(rn_handle* h, const uint8_t* d_src, int src_h, int src_w, uint8_t* d_dst_batch, int index);
+/* The same for a BATCH of device-resident images in ONE launch: image i (d_srcs[i], heights[i] x widths[i] BGR uint8, HWC, any
+ * sizes) is centre-cropped and resized into slot i of d_dst_batch ([n, S, S, 3]).  Asynchronous on the handle's stream;
+ * n <= max_batch.  network.py:149-152 for a whole directory's worth of decoded images at once. */
+RN_API int rn_crop_resize_batch_u8_device(rn_handle* h, const uint8_t* const* d_srcs, const int* heights, const int* widths, int n,
+                                          uint8_t* d_dst_batch);
 /* infer.py:79-82 for a whole batch: n host images of individual sizes heights[i] x widths[i] (BGR uint8 HWC) are
  * uploaded, centre-cropped, resized and classified; probs [n, num_classes], ids [n] on the host.  Synchronous. */
 RN_API int rn_classify_images_u8(rn_handle* h, const uint8_t* const* images, const int* heights, const int* widths, int n,

@@ -38,7 +38,7 @@ EXPORTED_SYMBOLS = (
     "rn_forward_u8", "rn_submit_u8", "rn_collect", "rn_forward_f32", "rn_forward_u8_device", "rn_forward_f32_device", "rn_sync",
     "rn_set_stream", "rn_set_stream_null", "rn_node_count", "rn_node_info_get", "rn_tap", "rn_set_profiling", "rn_timing",
     "rn_dominant_stage", "rn_stage_launch", "rn_device_malloc", "rn_device_free", "rn_memcpy_h2d", "rn_memcpy_d2h",
-    "rn_crop_resize_u8_device", "rn_classify_images_u8", "rn_host_alloc", "rn_host_free", "rn_frozen_info", "rn_const_info",
+    "rn_crop_resize_u8_device", "rn_crop_resize_batch_u8_device", "rn_classify_images_u8", "rn_host_alloc", "rn_host_free", "rn_frozen_info", "rn_const_info",
     "rn_group_create", "rn_group_destroy", "rn_group_size", "rn_group_handle", "rn_group_forward_u8",
     "rn_group_forward_u8_device", "rn_group_result_buffer", "rn_group_sync", "rn_group_plan",
 )
@@ -155,6 +155,9 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.rn_memcpy_d2h.restype = i32
     lib.rn_crop_resize_u8_device.argtypes = [vp, vp, i32, i32, vp, i32]
     lib.rn_crop_resize_u8_device.restype = i32
+    if hasattr(lib, "rn_crop_resize_batch_u8_device"):
+        lib.rn_crop_resize_batch_u8_device.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_int), C.POINTER(C.c_int), i32, vp]
+        lib.rn_crop_resize_batch_u8_device.restype = i32
     lib.rn_classify_images_u8.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_int), C.POINTER(C.c_int), i32, vp, vp]
     lib.rn_classify_images_u8.restype = i32
     lib.rn_group_create.argtypes = [C.POINTER(rn_weights), i32, C.POINTER(C.c_int), i32, i32, C.c_uint, C.POINTER(vp)]
@@ -342,6 +345,32 @@ class Engine:
             return out
         finally:
             self.device_free(d_src)
+            self.device_free(d_dst)
+
+    def crop_resize_batch(self, ims, repeat: int = 1) -> np.ndarray:
+        """A list of images (any sizes, <= max_batch of them) through the BATCHED device crop + resize -- one launch for all of them
+        (``rn_crop_resize_batch_u8_device``); returns the ``[n, S, S, 3]`` uint8 results.  ``repeat`` > 1 launches it that often
+        (profiling / timing of the one kernel)."""
+        ims = [np.ascontiguousarray(im, dtype=np.uint8) for im in ims]
+        n, s = len(ims), self.graph.im_side
+        d_srcs = [self.device_malloc(im.nbytes) for im in ims]
+        d_dst = self.device_malloc(self.max_batch * s * s * 3)
+        try:
+            for d, im in zip(d_srcs, ims):
+                self.h2d(d, im)
+            ptrs = (C.c_void_p * n)(*d_srcs)
+            hs = (C.c_int * n)(*[im.shape[0] for im in ims])
+            ws = (C.c_int * n)(*[im.shape[1] for im in ims])
+            for _ in range(max(1, repeat)):
+                _check(self.lib, self.lib.rn_crop_resize_batch_u8_device(self.handle, ptrs, hs, ws, n, C.c_void_p(d_dst)),
+                       "rn_crop_resize_batch_u8_device")
+            self.sync()
+            out = np.empty((n, s, s, 3), np.uint8)
+            self.d2h(out, d_dst)
+            return out
+        finally:
+            for d in d_srcs:
+                self.device_free(d)
             self.device_free(d_dst)
 
     def forward_f32(self, x_rgb: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:

@@ -676,6 +676,7 @@ extern "C" void rn_destroy(rn_handle* h) {
         if (e) (void)hipEventDestroy(e);
     for (void* p : h->allocs) (void)hipFree(p);
     if (h->d_raw) (void)hipFree(h->d_raw);
+    if (h->d_items) (void)hipFree(h->d_items);
     for (auto& sl : h->slots) {
         if (sl.d_in) (void)hipFree(sl.d_in);
         if (sl.d_probs) (void)hipFree(sl.d_probs);
@@ -878,6 +879,45 @@ extern "C" int rn_crop_resize_u8_device(rn_handle* h, const uint8_t* d_src, int 
                                static_cast<int64_t>(src_w) * 3, d_dst_batch + static_cast<int64_t>(index) * S * S * 3, S, S);
 }
 
+// the device table of a batched resize (max_batch entries), allocated at the first use
+static int ensure_items(rn_handle* h) {
+    if (h->d_items) return RN_OK;
+    void* p = nullptr;
+    hipError_t e = hipMalloc(&p, static_cast<size_t>(h->max_batch) * sizeof(rn_resize_item));
+    if (e != hipSuccess) {
+        rn_set_error("hipMalloc(resize table) failed: %s", hipGetErrorString(e));
+        return RN_E_NOMEM;
+    }
+    h->d_items = static_cast<rn_resize_item*>(p);
+    h->items_host.resize(static_cast<size_t>(h->max_batch));
+    return RN_OK;
+}
+
+extern "C" int rn_crop_resize_batch_u8_device(rn_handle* h, const uint8_t* const* d_srcs, const int* heights, const int* widths, int n,
+                                              uint8_t* d_dst_batch) {
+    if (!h || !d_srcs || !heights || !widths || !d_dst_batch || n < 1 || n > h->max_batch) {
+        rn_set_error("rn_crop_resize_batch_u8_device: bad argument (%d images, max_batch %d)", n, h ? h->max_batch : 0);
+        return RN_E_INVALID;
+    }
+    DeviceGuard guard(h->device);
+    int rc = ensure_items(h);
+    if (rc != RN_OK) return rc;
+    // (the previous call's table may still be on its way up: the host copy is rewritten only behind the stream)
+    RN_HIP(hipStreamSynchronize(h->stream));
+    for (int i = 0; i < n; ++i) {
+        if (!d_srcs[i] || heights[i] < 1 || widths[i] < 1) {
+            rn_set_error("rn_crop_resize_batch_u8_device: image %d is empty", i);
+            return RN_E_INVALID;
+        }
+        int x0, y0, side;
+        center_crop_window(heights[i], widths[i], &x0, &y0, &side);
+        rn_resize_item_fill(&h->items_host[i], d_srcs[i] + (static_cast<int64_t>(y0) * widths[i] + x0) * 3, side, side,
+                            static_cast<int64_t>(widths[i]) * 3, h->im_side);
+    }
+    RN_HIP(hipMemcpyAsync(h->d_items, h->items_host.data(), static_cast<size_t>(n) * sizeof(rn_resize_item), hipMemcpyHostToDevice, h->stream));
+    return rn_launch_resize_batch_u8(h->stream, h->d_items, n, d_dst_batch, h->im_side);
+}
+
 extern "C" int rn_classify_images_u8(rn_handle* h, const uint8_t* const* images, const int* heights, const int* widths, int n,
                                      float* probs, int64_t* ids) {
     int rc = check_call(h, n, images, probs, ids);
@@ -915,6 +955,7 @@ extern "C" int rn_classify_images_u8(rn_handle* h, const uint8_t* const* images,
     }
     size_t off = 0;
     const int S = h->im_side;
+    if ((rc = ensure_items(h)) != RN_OK) return rc;
     for (int i = 0; i < n; ++i) {
         int x0, y0, side;
         center_crop_window(heights[i], widths[i], &x0, &y0, &side);
@@ -925,11 +966,12 @@ extern "C" int rn_classify_images_u8(rn_handle* h, const uint8_t* const* images,
         else
             RN_HIP(hipMemcpy2DAsync(h->d_raw + off, row, win, static_cast<size_t>(widths[i]) * 3, row, side,
                                     hipMemcpyHostToDevice, h->stream));
-        if ((rc = rn_launch_resize_u8(h->stream, h->d_raw + off, side, side, static_cast<int64_t>(row),
-                                      h->d_in_u8 + static_cast<int64_t>(i) * S * S * 3, S, S)) != RN_OK)
-            return rc;
+        rn_resize_item_fill(&h->items_host[i], h->d_raw + off, side, side, static_cast<int64_t>(row), S);
         off += bytes;
     }
+    // ONE resize launch for the batch (the crop windows' table goes up behind the images)
+    RN_HIP(hipMemcpyAsync(h->d_items, h->items_host.data(), static_cast<size_t>(n) * sizeof(rn_resize_item), hipMemcpyHostToDevice, h->stream));
+    if ((rc = rn_launch_resize_batch_u8(h->stream, h->d_items, n, h->d_in_u8, S)) != RN_OK) return rc;
     if ((rc = rn_forward_u8_device(h, h->d_in_u8, n, h->d_probs, h->d_ids)) != RN_OK) return rc;
     RN_HIP(hipMemcpyAsync(probs, h->d_probs, static_cast<size_t>(n) * h->num_classes * 4, hipMemcpyDeviceToHost,
                           h->stream));

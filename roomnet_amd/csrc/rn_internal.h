@@ -78,6 +78,15 @@ struct NodeBuf {
     int dtype = RN_DTYPE_F32;    // storage type of ptr
 };
 
+// one image of a batched crop + resize (rn_imageops.hip): crop window at `src`, scales and mode as cv::resize computes them
+struct rn_resize_item {
+    const uint8_t* src;
+    int src_h, src_w;
+    int64_t src_row_bytes;
+    double scale_x, scale_y;
+    int mode;
+};
+
 struct rn_handle {
     int device = 0;
     int dtype = RN_DTYPE_F32;
@@ -96,6 +105,8 @@ struct rn_handle {
     // staging for host-buffer calls
     uint8_t* d_in_u8 = nullptr;
     uint8_t* d_raw = nullptr;      // staging for raw (un-resized) images, rn_classify_images_u8
+    rn_resize_item* d_items = nullptr;           // [max_batch] crop windows of a batched resize (device) ...
+    std::vector<rn_resize_item> items_host;      // ... and their host copy (kept until the next call: the upload is asynchronous)
     size_t raw_cap = 0;
     float* d_probs = nullptr;
     int64_t* d_ids = nullptr;
@@ -154,6 +165,8 @@ struct HeadArgs {
     float* tap_relu[RN_MAX_DENSE];
     float* tap_bn[RN_MAX_DENSE];
 };
+void rn_resize_item_fill(rn_resize_item* it, const uint8_t* d_src, int src_h, int src_w, int64_t src_row_bytes, int S);
+int rn_launch_resize_batch_u8(hipStream_t s, const rn_resize_item* d_items, int n, uint8_t* d_dst_base, int S);
 int rn_launch_resize_u8(hipStream_t s, const uint8_t* d_src, int src_h, int src_w, int64_t src_row_bytes, uint8_t* d_dst,
                         int dst_h, int dst_w);
 int rn_launch_head(hipStream_t s, const void* flat, int flat_dtype, int n, const HeadArgs& a, float* probs,

@@ -70,33 +70,8 @@ __global__ __launch_bounds__(NQ == 4 ? 512 : 768, NQ == 4 ? 2 : 3) void stage4x_
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // cout quarter / pixel run.  NQ = 4: waves w and w + 4 share a SIMD (7 + 6 tiles).  NQ = 3: waves w, w + 4, w + 8 share a
     // SIMD and take the runs w, w + 1, w + 2 (mod 4) of the quarters 0, 1, 2
-    int cq = NQ == 4 ? (wave & 3) : (wave >> 2);
-    int run = NQ == 4 ? (wave >> 2) : (((wave & 3) + (wave >> 2)) & 3);
-#ifdef RN_HWID_ROLES
-    if constexpr (NQ == 3) {
-        // Roles by the SIMD a wave actually runs on (HW_ID bits 5:4) instead of by its index: the k-th wave to arrive on SIMD s
-        // takes quarter k and run (s + k) mod 4 -- 10 / 9 / 10 / 10 tile rows per SIMD whatever order the dispatcher placed the
-        // twelve waves in (166 registers: three waves per SIMD at most).  Counters in the first bytes of the unused table area.
-        int* const cnt = reinterpret_cast<int*>(smem);
-        if (tid < 4) cnt[tid] = 0;
-        __syncthreads();
-        unsigned hwid;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
-        const int simd = static_cast<int>((hwid >> 4) & 3);
-        int rank = 0;
-        if (lane == 0) rank = atomicAdd(&cnt[simd], 1);
-        rank = __builtin_amdgcn_readfirstlane(rank);
-        if (rank < 3) {
-            cq = rank;
-            run = (simd + rank) & 3;
-        } else {
-            // (cannot happen with three waves per SIMD; keep every role filled exactly once anyway)
-            cq = wave >> 2;
-            run = ((wave & 3) + (wave >> 2)) & 3;
-        }
-        __syncthreads();
-    }
-#endif
+    const int cq = NQ == 4 ? (wave & 3) : (wave >> 2);
+    const int run = NQ == 4 ? (wave >> 2) : (((wave & 3) + (wave >> 2)) & 3);
     const int px16 = lane & 15, g = lane >> 4;
     const int cb = blockIdx.x % a.n_cb, band = blockIdx.x / a.n_cb, n = blockIdx.y;
     const int Win = a.W, Wo_full = a.Wo, Ho = a.Ho;

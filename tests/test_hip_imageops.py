@@ -88,3 +88,19 @@ def test_bad_images_are_rejected(engine):
         assert rc < 0 and b"rn_crop_resize_u8_device" in engine.lib.rn_last_error()
     finally:
         engine.device_free(d)
+
+
+def test_batched_crop_resize_is_one_launch_and_byte_identical(engine):
+    """rn_crop_resize_batch_u8_device: eight images of eight different shapes (copy, exact 2x box, up- and down-scales, 1 x 1) in ONE
+    launch, every slot byte for byte the host restatement -- and twice in a row on the same handle (the table is re-uploaded)."""
+    shapes = [(224, 224), (448, 448), (480, 640), (1080, 1920), (97, 131), (1, 1), (3000, 17), (601, 448)]
+    rng = np.random.default_rng(77)
+    ims = [rng.integers(0, 256, (h, w, 3), dtype=np.uint8) for h, w in shapes]
+    for order in (range(8), reversed(range(8))):
+        batch = [ims[k] for k in order]
+        got = engine.crop_resize_batch(batch)
+        assert got.shape == (8, 224, 224, 3)
+        for k, im in enumerate(batch):
+            np.testing.assert_array_equal(got[k], _host(im), err_msg=str(im.shape))
+    with pytest.raises((ValueError, _capi.RoomNetLibraryError)):
+        engine.crop_resize_batch([ims[0]] * 9)           # more than max_batch
