@@ -375,6 +375,8 @@ def main():
     ap.add_argument("--compute-frozen", action="store_true",
                     help="RN_FLAG_COMPUTE_FROZEN: convolve the channels rn_create proves constant too (the comparison arm: same bits)")
     ap.add_argument("--no-unfolded-arm", action="store_true", help="skip the RN_FLAG_COMPUTE_FROZEN comparison pass")
+    ap.add_argument("--no-dither", action="store_true",
+                    help="RN_FLAG_NO_DITHER: plain rounding of weights and stores (rounds 1-5; the comparison arm of the refined rounding)")
     ap.add_argument("--no-other-configs", action="store_true",
                     help="skip `other_configs` (64 x 600 x 600 fp16, 256 x 224 x 224 float32, batch-1 latency) of the default run")
     ap.add_argument("--stub-engine", action="store_true", help=argparse.SUPPRESS)    # CPU tensors + gloo (tests)
@@ -429,11 +431,11 @@ def main():
             weights["dense/kernel"] = np.random.default_rng(600).uniform(
                 -0.04, 0.04, (graph.flat_len, 32)).astype(np.float32)
         eng = _capi.Engine(graph, weights, device=local_rank, dtype=args.dtype, max_batch=B,
-                           stage_launches=args.stage_launches, pair32=args.pair32, compute_frozen=args.compute_frozen)
+                           stage_launches=args.stage_launches, pair32=args.pair32, compute_frozen=args.compute_frozen, no_dither=args.no_dither)
     engs = [eng]
     if not stub and args.handles == 2:
         engs.append(_capi.Engine(graph, weights, device=local_rank, dtype=args.dtype, max_batch=B,
-                                 stage_launches=args.stage_launches, pair32=args.pair32, compute_frozen=args.compute_frozen))
+                                 stage_launches=args.stage_launches, pair32=args.pair32, compute_frozen=args.compute_frozen, no_dither=args.no_dither))
 
     ims = torch.from_numpy(perf_batch(B, args.side, seed=rank)).to(dev)
     # probs [B,6] fp32 and ids [B] int64 live in ONE byte buffer per rank, so the result exchange is a single
@@ -589,7 +591,7 @@ def main():
         folded = fold_info["pair_channels_not_convolved"] > 0 or fold_info["residual_stage_folded"] >= 0
         if folded and not args.no_unfolded_arm and rank == 0:
             e2 = _capi.Engine(graph, weights, device=local_rank, dtype=args.dtype, max_batch=B,
-                              stage_launches=args.stage_launches, pair32=args.pair32, compute_frozen=True)
+                              stage_launches=args.stage_launches, pair32=args.pair32, compute_frozen=True, no_dither=args.no_dither)
             e2.set_stream(stream.cuda_stream)
             # the conditions of `value`: the same untimed steps in front of the timed ones (the chip idled while the handle was built)
             unfolded_untimed = (args.warmup + args.steps if cold_elapsed is not None else 0) + spinup_steps + args.warmup
@@ -836,7 +838,7 @@ def main():
                 out["path"]["pcie_pipelined_images_per_sec"] = pcie_pipe_rate
                 out["path"]["pcie_pipelined_pinned_images_per_sec"] = pcie_pinned_rate
             headline = world == 1 and not multi and args.side == 224 and B == 256 and args.dtype == "bf16" and not (
-                args.stage_launches or args.pair32 or args.compute_frozen)
+                args.stage_launches or args.pair32 or args.compute_frozen or args.no_dither)
             if headline and not args.no_other_configs:
                 # BASELINE's other single-GPU shards, same process, parity-gated (profiles/r6_*: the same numbers from own runs)
                 others = [measure_latency(torch, eng, graph, dev, stream, args.side)]

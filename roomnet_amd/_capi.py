@@ -19,7 +19,8 @@ RN_FLAG_TAPS = 1
 RN_FLAG_STAGE_LAUNCHES = 2      # 16-bit handles: one launch per conv stage (no cross-stage fusion)
 RN_FLAG_GENERIC_KERNELS = 4     # 16-bit handles: generic stage kernel everywhere (diagnostic cross-check)
 RN_FLAG_PAIR_32X32 = 8          # 16-bit handles: the fused stage pair on the round-2 32x32x16 kernel (comparison arm)
-RN_FLAG_COMPUTE_FROZEN = 16     # convolve the provably constant channels too (comparison arm of the frozen-channel folding)
+RN_FLAG_COMPUTE_FROZEN = 16
+RN_FLAG_NO_DITHER = 32     # convolve the provably constant channels too (comparison arm of the frozen-channel folding)
 RN_MAX_STAGES = 16
 RN_MAX_DENSE = 8
 RN_NAME_LEN = 32
@@ -255,7 +256,7 @@ class Engine:
     def __init__(self, graph: Graph, weights: Dict[str, np.ndarray], device: int = 0, dtype="f32",
                  max_batch: int = 64, taps: bool = False, lib_path: Optional[str] = None,
                  stage_launches: bool = False, generic_kernels: bool = False, pair32: bool = False,
-                 compute_frozen: bool = False):
+                 compute_frozen: bool = False, no_dither: bool = False):
         if pair32 and lib_path is None and "ROOMNET_HIP_LIB" not in os.environ:
             lib_path = AB_LIB_PATH           # (the round-2 comparison kernels are not in the product library)
         self.lib = load_library(lib_path)
@@ -269,7 +270,8 @@ class Engine:
                                 (RN_FLAG_TAPS if taps else 0) | (RN_FLAG_STAGE_LAUNCHES if stage_launches else 0)
                                 | (RN_FLAG_GENERIC_KERNELS if generic_kernels else 0)
                                 | (RN_FLAG_PAIR_32X32 if pair32 else 0)
-                                | (RN_FLAG_COMPUTE_FROZEN if compute_frozen else 0), C.byref(h))
+                                | (RN_FLAG_COMPUTE_FROZEN if compute_frozen else 0)
+                                | (RN_FLAG_NO_DITHER if no_dither else 0), C.byref(h))
         _check(self.lib, rc, "rn_create")
         self._h = h
         self._nodes: Optional[Dict[str, Tuple[int, Tuple[int, int, int]]]] = None

@@ -129,7 +129,7 @@ int validate(const rn_weights* w, int dtype, int max_batch, unsigned flags) {
         rn_set_error("rn_create: unknown dtype %d", dtype);
         return RN_E_INVALID;
     }
-    if (flags & ~(RN_FLAG_TAPS | RN_FLAG_STAGE_LAUNCHES | RN_FLAG_GENERIC_KERNELS | RN_FLAG_PAIR_32X32 | RN_FLAG_COMPUTE_FROZEN)) {
+    if (flags & ~(RN_FLAG_TAPS | RN_FLAG_STAGE_LAUNCHES | RN_FLAG_GENERIC_KERNELS | RN_FLAG_PAIR_32X32 | RN_FLAG_COMPUTE_FROZEN | RN_FLAG_NO_DITHER)) {
         rn_set_error("rn_create: unknown flag bits 0x%x", flags);
         return RN_E_INVALID;
     }

@@ -640,6 +640,15 @@ struct FusedState {
     // stage too, so the same positions of the residual stage's output are constants as well.  Neither kernel computes them: both
     // tensors are filled once (rn_fused_post_alloc), the residual stage contracts 48 input channels and starts its accumulators
     // from the constants' contribution.
+    // round 6: refined rounding of the 16-bit handles (default; off under RN_FLAG_NO_DITHER and on the legacy comparison arms):
+    // `refine` = conv weights rounded with the residual carried from tap to tap (diffuse_taps), `dither` (bf16 only) = the stores of
+    // the large stage outputs go through v_cvt_sr_bf16_f32 with a seed that depends on the output row (rn_stage.h)
+    bool refine = false;
+    bool dither = false;
+    std::vector<char> dither_out;    // per conv stage: its output rows are dithered
+    int relabel_stage = -1;          // the residual stage whose channels (and its neighbours') are stored relabelled -- also on the
+                                     // arm that computes every channel (same channel order in both arms: same MFMA summation order)
+    bool const_layout = false;       // positions 48..63 of the two relabelled tensors hold the constant channels (both arms)
     int const4_proven = 0;           // channels of that stage with a constant 16-bit store on this handle
     bool const4 = false;             // 16 of them sit in positions 48..63 and are not computed
     unsigned short const4_val[16] = {};   // their stored values (s4.bn positions 48..63)
@@ -663,12 +672,53 @@ void rn_fused_release(rn_handle* h) {
     h->fused = nullptr;
 }
 
+// Conv weights [tap][cin][cout] -> the handle's 16-bit values with the rounding residual CARRIED from tap to tap (centre first): the
+// nine taps of a (cin, cout) pair then sum to the exact sum within half an ulp of ONE weight instead of the sum of nine independent
+// roundings -- smooth image content sees the tap sum (on the parity set the weight share of the bf16 logit error goes from 0.061 to
+// 0.007, tools/sim16.py).  The array is rewritten with exactly representable values: every later conversion is exact, every kernel
+// family packs the same numbers.
+static void diffuse_taps(float* w, int cin, int cout, int dtype) {
+    static const int order[9] = {4, 0, 8, 2, 6, 1, 7, 3, 5};
+    for (int ci = 0; ci < cin; ++ci)
+        for (int co = 0; co < cout; ++co) {
+            float carry = 0.f;
+            for (int t : order) {
+                float& x = w[(static_cast<size_t>(t) * cin + ci) * cout + co];
+                const float v = x + carry;
+                const float q = dtype == RN_DTYPE_BF16 ? bf16_bits_to_f32(f32_to_bf16(v)) : f16_to_f32(f32_to_f16(v));
+                carry = std::isfinite(q) ? v - q : 0.f;
+                x = q;
+            }
+        }
+}
+
 int rn_fused_prepare(rn_handle* h, const rn_weights* w_in) {
     const int dti = h->dtype == RN_DTYPE_BF16 ? 0 : 1;
     (void)dti;
     auto* fs = new FusedState();
     fs->st.resize(h->stages.size());
     h->fused = fs;
+    fs->refine = !(h->flags & (RN_FLAG_GENERIC_KERNELS | RN_FLAG_PAIR_32X32 | RN_FLAG_NO_DITHER));
+    fs->dither = fs->refine && h->dtype == RN_DTYPE_BF16;
+    fs->dither_out.assign(h->stages.size(), 0);
+    {
+        // dithered outputs: the large stage tensors in front of the back end (the last four stages run in one launch per image and
+        // keep their tensors in LDS), except stage 0 (it lives in LDS rings inside stage 1's kernel) and the first stage of a
+        // fusable 32 -> 32 pair (its output is the pair's on-chip tensor; the frozen-channel fold relies on its plain rounding)
+        const int ns = static_cast<int>(h->stages.size());
+        for (int i = 1; i + 4 < ns && fs->dither; ++i) {
+            const StagePlan& s = h->stages[i];
+            const bool pair_first = i + 1 < ns && s.cin == 32 && s.cout == 32 && s.pool_k == 4 && s.pool_s == 1 && s.skip_stage < 0 &&
+                                    h->stages[i + 1].cin == 32 && h->stages[i + 1].cout == 32 && h->stages[i + 1].skip_stage == i - 1;
+            fs->dither_out[i] = pair_first ? 0 : 1;
+        }
+    }
+    // the handle's 16-bit store of a value whose rounding is not dithered (constant channels, tables)
+    const auto cv_store = [&](float v) -> unsigned short {
+        // (bf16: the row-blocked stage kernels store through v_cvt_sr_bf16_f32 whether the handle dithers or not)
+        if (h->dtype == RN_DTYPE_BF16) return rn_sr_bf16_host(v, RN_SEED_PLAIN);
+        return h->dtype == RN_DTYPE_BF16 ? f32_to_bf16(v) : f32_to_f16(v);
+    };
     // ---- frozen first-BN channels of a 64 -> 64 residual stage (stage 5 of the network; rn_stage5x.hip).  Its epilogue forms
     // y1 = fma(H, sc1', sh1') with H = a pooled sum of ReLU6 / 6 values in [0, 16]: where |sc1'| * 16 < 2^-25 |sh1'| the fma
     // returns sh1' EXACTLY in float32 for every input -- the channel's convolution cannot change a bit of the output (the
@@ -683,7 +733,8 @@ int rn_fused_prepare(rn_handle* h, const rn_weights* w_in) {
     rn_weights wp = *w_in;
     wp.stages = stg.data();
     const rn_weights* const w = &wp;
-    if (!(h->flags & (RN_FLAG_COMPUTE_FROZEN | RN_FLAG_GENERIC_KERNELS | RN_FLAG_PAIR_32X32))) {
+    const bool fold_ok = !(h->flags & RN_FLAG_COMPUTE_FROZEN);      // (the computing arm keeps the relabelling and folds nothing)
+    if (!(h->flags & (RN_FLAG_GENERIC_KERNELS | RN_FLAG_PAIR_32X32))) {
         for (int r = 2; r + 1 < w_in->n_stages; ++r) {
             const rn_conv_stage& s5 = w_in->stages[r];
             const rn_conv_stage& s4 = w_in->stages[r - 1];
@@ -724,8 +775,7 @@ int rn_fused_prepare(rn_handle* h, const rn_weights* w_in) {
                 float sc = inv / 16.0f;
                 const float sh = s4.beta[c] - s4.mean[c] * inv;
                 sc *= 6.0f;
-                const auto cv = [&](float v) { return h->dtype == RN_DTYPE_BF16 ? f32_to_bf16(v) : f32_to_f16(v); };
-                const unsigned short v0 = cv(std::fmaf(0.0f, sc, sh)), v16 = cv(std::fmaf(16.0f, sc, sh));
+                const unsigned short v0 = cv_store(std::fmaf(0.0f, sc, sh)), v16 = cv_store(std::fmaf(16.0f, sc, sh));
                 cst_val[c] = v0;
                 if (v0 == v16 && std::isfinite(sh)) cst.push_back(c);
             }
@@ -734,7 +784,8 @@ int rn_fused_prepare(rn_handle* h, const rn_weights* w_in) {
                 // frozen channels that are constants of the stage in front go LAST (positions 48..63 when there are 16 of them)
                 std::vector<int> both, only;
                 for (int c : frozen) (std::find(cst.begin(), cst.end(), c) != cst.end() ? both : only).push_back(c);
-                fs->const4 = both.size() >= 16;
+                fs->const_layout = both.size() >= 16;
+                fs->const4 = fs->const_layout && fold_ok;
                 frozen = only;
                 frozen.insert(frozen.end(), both.begin(), both.end());
             }
@@ -746,7 +797,7 @@ int rn_fused_prepare(rn_handle* h, const rn_weights* w_in) {
             std::sort(live.begin(), live.end());
             for (int p = 0; p < 32; ++p) pi[p] = live[p];
             for (int p = 0; p < 32; ++p) pi[32 + p] = frozen[p];
-            if (fs->const4)
+            if (fs->const_layout)
                 for (int p = 0; p < 16; ++p) fs->const4_val[p] = cst_val[pi[48 + p]];
             auto perm_vec = [&](const float* src) -> const float* {
                 if (!src) return nullptr;
@@ -778,8 +829,11 @@ int rn_fused_prepare(rn_handle* h, const rn_weights* w_in) {
             stg[r].mean2 = perm_vec(s5.mean2);
             stg[r].variance2 = perm_vec(s5.variance2);
             stg[r + 1].kernel = perm_kernel(s6.kernel, 64, s6.cout, true, false);
-            fs->fold5_stage = r;
-            fs->fold5_live_q = 2;
+            fs->relabel_stage = r;
+            if (fold_ok) {
+                fs->fold5_stage = r;
+                fs->fold5_live_q = 2;
+            }
             fs->node_perm[h->stages[r - 1].node_bn] = pi;
             fs->node_perm[h->stages[r].node_bn2] = pi;
             break;
@@ -908,10 +962,9 @@ int rn_fused_prepare(rn_handle* h, const rn_weights* w_in) {
                 // the residual stage's output at the positions of the constant channels: y1 = fma(0, sc1', sh1') = sh1' (frozen first
                 // BN), the bilinear resize of a constant channel is the constant (its two weights are exact 16-bit numbers that
                 // sum to 1, the products are exact in float32), y = fma(v, sc2, y1) -- what rn_stage5x.hip computes for them
-                const auto cv = [&](float v) { return h->dtype == RN_DTYPE_BF16 ? f32_to_bf16(v) : f32_to_f16(v); };
                 for (int p = 0; p < 16; ++p) {
                     const float v = h->dtype == RN_DTYPE_BF16 ? bf16_bits_to_f32(fs->const4_val[p]) : f16_to_f32(fs->const4_val[p]);
-                    fs->const5_val[p] = cv(std::fmaf(v, tab[2 * 64 + 48 + p], tab[64 + 48 + p]));
+                    fs->const5_val[p] = cv_store(std::fmaf(v, tab[2 * 64 + 48 + p], tab[64 + 48 + p]));
                 }
             }
         }
@@ -939,9 +992,14 @@ int rn_fused_prepare(rn_handle* h, const rn_weights* w_in) {
         const float* wsrc = w->stages[i].kernel;   // HWIO == [k = tap*cin + c][cout]
         const int K = 9 * s.cin;
         std::vector<float> wsixth;
-        if (f.sixth) {
+        if (f.sixth || fs->refine) {
             wsixth.assign(wsrc, wsrc + static_cast<size_t>(K) * s.cout);
-            for (float& v : wsixth) v /= 6.0f;
+            if (f.sixth)
+                for (float& v : wsixth) v /= 6.0f;
+#ifndef RN_REFINE_UPTO
+#define RN_REFINE_UPTO 99        // (diagnostic builds: the last conv stage whose weights get the carried rounding)
+#endif
+            if (fs->refine && static_cast<int>(i) <= RN_REFINE_UPTO) diffuse_taps(wsixth.data(), s.cin, s.cout, h->dtype);      // (every pack below converts exactly)
             wsrc = wsixth.data();
         }
         for (int c = 0; c < kc; ++c)
@@ -1119,6 +1177,15 @@ int rn_fused_prepare(rn_handle* h, const rn_weights* w_in) {
                 // of 32 (its L2 regulariser drove their BN gamma to ~1e-20): with >= 16 of them the first conv computes half of
                 // its couts.  perm[p] = the channel at B-ring position p; the positions (p & 7) >= 4 -- the second half of every
                 // 8-cout group -- take frozen channels.
+                // both convs' weights / 6 (pool 4/1 stages), with the handle's refined rounding when it is on: every use below -- the
+                // two fragment packs and the frozen channels' constant -- reads THESE arrays
+                std::vector<float> wq[2];
+                for (int which = 0; which < 2; ++which) {
+                    const float* raw = w->stages[i + which].kernel;       // [tap][cin][cout]
+                    wq[which].assign(raw, raw + static_cast<size_t>(9) * 32 * 32);
+                    for (float& v : wq[which]) v /= 6.0f;
+                    if (fs->refine) diffuse_taps(wq[which].data(), 32, 32, h->dtype);
+                }
                 int perm[32];
                 {
                     std::vector<int> frozen, live;
@@ -1158,14 +1225,14 @@ int rn_fused_prepare(rn_handle* h, const rn_weights* w_in) {
                             std::memcpy(&f, &bits, 4);
                             return f;
                         };
-                        const float* w3src = w->stages[i + 1].kernel;       // [tap][cin][cout]
+                        const float* w3src = wq[1].data();                  // [tap][cin][cout], already / 6
                         for (int co = 0; co < 32; ++co) {
                             double sum = 0.0;
                             for (int p = 0; p < 32; ++p) {
                                 if ((p & 7) < 4) continue;
-                                const double val = bk(cv(t1[32 + perm[p]]));
+                                const double val = bk(cv_store(t1[32 + perm[p]]));      // (the channel's stored value: the kernels' own store)
                                 for (int tap = 0; tap < 9; ++tap)
-                                    sum += static_cast<double>(bk(cv(w3src[(static_cast<size_t>(tap) * 32 + perm[p]) * 32 + co] / 6.0f))) * val;
+                                    sum += static_cast<double>(bk(cv(w3src[(static_cast<size_t>(tap) * 32 + perm[p]) * 32 + co]))) * val;
                             }
                             tabx[160 + co] = static_cast<float>(sum);
                         }
@@ -1183,19 +1250,17 @@ int rn_fused_prepare(rn_handle* h, const rn_weights* w_in) {
                     std::vector<unsigned short> f16;
                     // (both stages are pool 4/1 register-weights stages: `sixth` weights, like their fragments above)
                     std::vector<float> w6(static_cast<size_t>(9) * 32 * 32);
-                    const float* wsrc6 = w->stages[i + which].kernel;       // [tap][cin][cout]
+                    const float* wsrc6 = wq[which].data();                  // [tap][cin][cout], already / 6
                     for (int tap = 0; tap < 9; ++tap)
                         for (int ci = 0; ci < 32; ++ci)
                             for (int co = 0; co < 32; ++co)
                                 w6[(static_cast<size_t>(tap) * 32 + ci) * 32 + co] =
-                                    (which == 0 ? wsrc6[(static_cast<size_t>(tap) * 32 + ci) * 32 + perm[co]]        // B's channels = the first conv's couts
-                                                : wsrc6[(static_cast<size_t>(tap) * 32 + perm[ci]) * 32 + co]) / 6.0f; // ... and the second conv's cins
+                                    which == 0 ? wsrc6[(static_cast<size_t>(tap) * 32 + ci) * 32 + perm[co]]        // B's channels = the first conv's couts
+                                               : wsrc6[(static_cast<size_t>(tap) * 32 + perm[ci]) * 32 + co];       // ... and the second conv's cins
                     if (which == 1 && fs->pair_producer_halves == 1) {
                         int ring_cin[16];
                         for (int r = 0; r < 16; ++r) ring_cin[r] = perm[8 * (r >> 2) + (r & 3)];
-                        std::vector<float> w3s(static_cast<size_t>(9) * 32 * 32);
-                        for (size_t q = 0; q < w3s.size(); ++q) w3s[q] = wsrc6[q] / 6.0f;
-                        rn_stage23x_pack_narrow(w3s.data(), ring_cin, h->dtype, f32_to_bf16, f32_to_f16, &f16);
+                        rn_stage23x_pack_narrow(wq[1].data(), ring_cin, h->dtype, f32_to_bf16, f32_to_f16, &f16);
                     } else
                         rn_stage23x_pack(w6.data(), h->dtype, f32_to_bf16, f32_to_f16, &f16);
                     void* d16 = nullptr;
@@ -1414,6 +1479,7 @@ int rn_fused_forward(rn_handle* h, const uint8_t* d_bgr, const float* d_rgb, int
             fa.wfrag3 = fs->pair_x16 ? fs->pair_wfrag_b : fs->st[i + 1].wfrag;
             fa.ptab = fs->pair_x16 ? fs->pair_ptab_x : fs->pair_ptab;
             fa.producer_halves = fs->pair_x16 ? fs->pair_producer_halves : 2;
+            fa.dither = fs->dither_out[i + 1];
             fa.narrow_b = fa.producer_halves == 1 ? 1 : 0;
             fa.rlo = s2.rt.lo;
             fa.rhi = s2.rt.hi;
@@ -1522,6 +1588,10 @@ int rn_fused_forward(rn_handle* h, const uint8_t* d_bgr, const float* d_rgb, int
         }
         a.H = a.W = s.in_side;
         a.Ho = a.Wo = s.out_side;
+        a.dither = fs->dither_out[i];
+        a.plain_q = -1;
+        // (both arms: the constant channels sit in the last quarter of the two relabelled tensors and keep the plain rounding)
+        if (fs->const_layout && (static_cast<int>(i) == fs->relabel_stage || static_cast<int>(i) + 1 == fs->relabel_stage)) a.plain_q = 3;
         if (f.use_c16) {
             Conv16Args ca{};
             ca.in = a.in;

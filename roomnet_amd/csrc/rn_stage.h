@@ -61,6 +61,37 @@ __device__ __forceinline__ unsigned pack2(float a, float b) {
     }
 }
 
+// ---- dithered 16-bit stores (bf16 handles, round 6).  A bf16 store keeps 8 significand bits: on smooth image
+// content every pixel of a region rounds the same way and the errors ADD through the 3 x 3 windows of the next convolution
+// (the worst logit errors of the parity set were solid-colour and gradient images).  v_cvt_sr_bf16_f32 computes
+// (bits + (seed >> 16)) >> 16 (tools/ubench/cvt_sr.hip: no mismatch in 2 M conversions); with a seed that depends on the
+// OUTPUT ROW only -- 1/6, 3/6, 5/6 of an ulp for rows 0, 1, 2 mod 3 -- the three rows of every window carry three different
+// rounding offsets and their errors cancel to a third of an ulp of the window's mean: deterministic, position-dependent
+// rounding, each stored value within one ulp of the exact one (instead of half).  One instruction per value (RNE: one per pair).
+constexpr unsigned RN_SEED_PLAIN = 0x80000000u;      // the un-dithered form of the same instruction: round half up
+__host__ __device__ __forceinline__ unsigned rn_dither_seed(int row) {
+    const int p = row % 3;
+    return p == 0 ? 0x2AAA0000u : (p == 1 ? 0x80000000u : 0xD5550000u);
+}
+// two floats -> one dword of two bf16 values through v_cvt_sr_bf16_f32 with a wave-uniform seed.  (Inline asm: the builtin wants
+// the old destination as an operand and the compiler zeroes it first; the inputs are VALU results -- the BN fma -- never raw MFMA
+// results, so no hazard needs padding inside the string.)
+__device__ __forceinline__ unsigned pack2_sr_bf16(float a, float b, unsigned seed) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    unsigned r;
+    asm("v_cvt_sr_bf16_f32 %0, %1, %3\n\tv_cvt_sr_bf16_f32 %0, %2, %3 op_sel:[0,0,1]" : "=&v"(r) : "v"(a), "v"(b), "s"(seed));
+    return r;
+#else
+    return 0;
+#endif
+}
+// the same conversion on the host (rn_create's proofs of constant channels, the tests)
+inline unsigned short rn_sr_bf16_host(float v, unsigned seed) {
+    unsigned u;
+    __builtin_memcpy(&u, &v, 4);
+    return static_cast<unsigned short>((u + (seed >> 16)) >> 16);
+}
+
 // ReLU6 of two accumulators of a stage whose conv weights are stored DIVIDED BY 6 (rn_fused_prepare: `sixth`), as one
 // instruction: relu6(6 x) / 6 = clamp(x, 0, 1), and the [0, 1] clamp is the free output modifier of the fp16 conversion
 // (LLVM folds the packed min / max into `v_cvt_pk_f16_f32 ... clamp`).  The pooled sums stay scaled by 1/6; the folded BN
@@ -278,6 +309,10 @@ struct StageArgs {
     // kernels write them next to the computed channels so that every 128-byte pixel of the output leaves as a FULL line (lines
     // with a quarter missing are read-modify-write cycles of the ECC memory: measured 10-20 % on both launches, box by box)
     const unsigned short* cvals;
+    // dithered stores (bf16 handles, pack2_sr_bf16): 1 = the stage's output rows are stored with rn_dither_seed(row); plain_q = the
+    // cout quarter (rn_stage4x / 5x) whose channels are constants of the handle and are stored with RN_SEED_PLAIN, or -1
+    int dither;
+    int plain_q;
 };
 
 // Column-block plan of a row-blocked kernel: the fewest blocks (<= 4) of equal width +-1 whose widths lie in [wo_min, wo_max].
@@ -322,6 +357,7 @@ struct Stage23Args {
     int producer_halves;
     int narrow_b;                 // (with producer_halves == 1) the B ring holds the 16 computed channels only; wfrag3 = rn_stage23x_pack_narrow's
                                   // 12 fragments, ptab row 5 = the second conv's constant of the frozen channels
+    int dither;                   // bf16: the pair's OUTPUT rows are stored with rn_dither_seed(row) (its on-chip tensor never is)
 };
 
 // 64 -> 128 stage without pooling on 16x16x32 matrix tiles (rn_conv16.hip)

@@ -39,6 +39,16 @@ using namespace rnk;
 
 namespace {
 
+// the on-chip tensor's 16-bit store (never dithered): bf16 goes through the same instruction as every other bf16 store of the
+// row-blocked kernels, with the plain seed -- round half up -- so that the stage-launch arm (rn_stage_rw.hip) stores the same bits
+template <int DT>
+__device__ __forceinline__ unsigned pack2p(float a, float b) {
+    if constexpr (DT == RN_DTYPE_BF16)
+        return pack2_sr_bf16(a, b, RN_SEED_PLAIN);
+    else
+        return pack2<DT>(a, b);
+}
+
 // Cache policy (aux operand of the buffer store / LDS-DMA; 2 = nt): the output rows and the residual's second read of an A row are
 // streamed -- neither is read again by this launch -- so that the L2 keeps the A rows between their first read (the conv operand)
 // and their second (the skip row, 0-10 row steps later).  FETCH_SIZE of the launch 1 315 -> 928 MB per 256 images (757 = every A row
@@ -349,7 +359,7 @@ __global__ __launch_bounds__(512, 2) void stage23x_kernel(const Stage23Args a) {
             if (PH == 2 || !(f & 1)) asm volatile("" : "+v"(w2[f]));
         lds_barrier();
         // PH == 1: the frozen channels of the lane's group (positions 8 g + 4 .. 8 g + 7) as the two dwords every store carries
-        [[maybe_unused]] const int cdead0 = static_cast<int>(pack2<DT>(shv[1][0], shv[1][1])), cdead1 = static_cast<int>(pack2<DT>(shv[1][2], shv[1][3]));
+        [[maybe_unused]] const int cdead0 = static_cast<int>(pack2p<DT>(shv[1][0], shv[1][1])), cdead1 = static_cast<int>(pack2p<DT>(shv[1][2], shv[1][3]));
 
         // ---- PH == 1: two adjacent tiles share a chain (one accumulator each: two independent MFMA chains, as the two halves of a
         // tile are in the full form); a tap costs two operand reads and two MFMAs
@@ -428,10 +438,10 @@ __global__ __launch_bounds__(512, 2) void stage23x_kernel(const Stage23Args a) {
             for (int i = 0; i < 4; ++i) y[i] = __builtin_fmaf(H[i], scv[0][i], shv[0][i]);
             auto& wb = wbB;
             if constexpr (NB) {
-                const i32x2 d = {static_cast<int>(pack2<DT>(y[0], y[1])), static_cast<int>(pack2<DT>(y[2], y[3]))};
+                const i32x2 d = {static_cast<int>(pack2p<DT>(y[0], y[1])), static_cast<int>(pack2p<DT>(y[2], y[3]))};
                 asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(wb[k]), "v"(d), "n"(off) : "memory");
             } else {
-                const i32x4 d = {static_cast<int>(pack2<DT>(y[0], y[1])), static_cast<int>(pack2<DT>(y[2], y[3])), cdead0, cdead1};
+                const i32x4 d = {static_cast<int>(pack2p<DT>(y[0], y[1])), static_cast<int>(pack2p<DT>(y[2], y[3])), cdead0, cdead1};
                 asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(wb[k]), "v"(d), "n"(off) : "memory");
             }
         };
@@ -451,8 +461,8 @@ __global__ __launch_bounds__(512, 2) void stage23x_kernel(const Stage23Args a) {
             for (int h = 0; h < 2; ++h)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) y[4 * h + i] = __builtin_fmaf(H[h][i], scv[h][i], shv[h][i]);
-            const i32x4 d = {static_cast<int>(pack2<DT>(y[0], y[1])), static_cast<int>(pack2<DT>(y[2], y[3])),
-                             static_cast<int>(pack2<DT>(y[4], y[5])), static_cast<int>(pack2<DT>(y[6], y[7]))};
+            const i32x4 d = {static_cast<int>(pack2p<DT>(y[0], y[1])), static_cast<int>(pack2p<DT>(y[2], y[3])),
+                             static_cast<int>(pack2p<DT>(y[4], y[5])), static_cast<int>(pack2p<DT>(y[6], y[7]))};
             auto& wb = wbB;
             asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(wb[k]), "v"(d), "n"(off) : "memory");
         };
@@ -669,6 +679,7 @@ __global__ __launch_bounds__(512, 2) void stage23x_kernel(const Stage23Args a) {
         unsigned sk_lo, sk_hi;
         const char* row;          // (the buffer resource is built at the store: four more scalars held across the step spilled)
         int emit_mask;
+        unsigned seed;            // dither seed of the output row (bf16 handles)
     };
     VLerp vl_cur = vlerp_of(yo0);
     VLerp vl_pre = vl_cur;                                // interpolation of the NEXT step's output row, one step ahead
@@ -785,8 +796,13 @@ __global__ __launch_bounds__(512, 2) void stage23x_kernel(const Stage23Args a) {
                 y[4 * h + i] = __builtin_fmaf(rs, tsc2[h][i], y1);
             }
         }
-        const i32x4 d = {static_cast<int>(pack2<DT>(y[0], y[1])), static_cast<int>(pack2<DT>(y[2], y[3])),
-                         static_cast<int>(pack2<DT>(y[4], y[5])), static_cast<int>(pack2<DT>(y[6], y[7]))};
+        i32x4 d;
+        if constexpr (DT == RN_DTYPE_BF16)          // (bf16: v_cvt_sr_bf16_f32 with the output row's dither seed or the plain one, rn_stage.h)
+            d = i32x4{static_cast<int>(pack2_sr_bf16(y[0], y[1], cx.seed)), static_cast<int>(pack2_sr_bf16(y[2], y[3], cx.seed)),
+                      static_cast<int>(pack2_sr_bf16(y[4], y[5], cx.seed)), static_cast<int>(pack2_sr_bf16(y[6], y[7], cx.seed))};
+        else
+            d = i32x4{static_cast<int>(pack2<DT>(y[0], y[1])), static_cast<int>(pack2<DT>(y[2], y[3])),
+                      static_cast<int>(pack2<DT>(y[4], y[5])), static_cast<int>(pack2<DT>(y[6], y[7]))};
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(cx.row), 0, out_row_bytes, 0x00020000);
         const int vo = (px16 < lim(k) ? voff0 + 1024 * k : OOB) | cx.emit_mask;
         __builtin_amdgcn_raw_buffer_store_b128(d, rs, vo, 0, RN_NT_OUT);
@@ -800,6 +816,7 @@ __global__ __launch_bounds__(512, 2) void stage23x_kernel(const Stage23Args a) {
         cx.sk_hi = static_cast<unsigned>((vl_cur.ylo + 1 > Win - 1 ? slot_cur : (slot_cur == X_NSK - 1 ? 0 : slot_cur + 1)) * X_SKROW);
         cx.row = out_row;
         cx.emit_mask = jo >= 0 ? 0 : OOB;
+        cx.seed = a.dither ? rn_dither_seed(yo0 + max(jo, 0)) : RN_SEED_PLAIN;
         if (jo >= 0 && jo < nrows - 1) out_row += out_row_bytes;
         const VLerp vl_next = vl_pre;                  // (computed behind the previous step's third chain)
         {

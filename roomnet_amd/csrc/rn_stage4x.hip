@@ -286,6 +286,8 @@ __global__ __launch_bounds__(NQ == 4 ? 512 : 768, NQ == 4 ? 2 : 3) void stage4x_
             const char* orow = out_img + static_cast<int64_t>(yo0 + rr) * out_row_bytes;
             const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(orow), 0, out_row_bytes, 0x00020000);
             const int emask = emit ? 0 : OOB;
+            // bf16 handles: the row's stores are dithered by the output row (rn_stage.h); a constant quarter keeps the plain seed
+            [[maybe_unused]] const unsigned seed = (!a.dither || cq == a.plain_q) ? RN_SEED_PLAIN : rn_dither_seed(yo0 + rr);
             auto out = [&](auto UC) __attribute__((always_inline)) {
                 constexpr int u = decltype(UC)::value;
                 f32x4 H = mfma16<RN_DTYPE_F16>(op[2 * u], pmA, zero4);
@@ -294,7 +296,11 @@ __global__ __launch_bounds__(NQ == 4 ? 512 : 768, NQ == 4 ? 2 : 3) void stage4x_
                 float y[4];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) y[i] = __builtin_fmaf(H[i], sc[i], sh[i]);
-                const i32x2 d = {static_cast<int>(pack2<DT>(y[0], y[1])), static_cast<int>(pack2<DT>(y[2], y[3]))};
+                i32x2 d;
+                if constexpr (DT == RN_DTYPE_BF16)
+                    d = i32x2{static_cast<int>(pack2_sr_bf16(y[0], y[1], seed)), static_cast<int>(pack2_sr_bf16(y[2], y[3], seed))};
+                else
+                    d = i32x2{static_cast<int>(pack2<DT>(y[0], y[1])), static_cast<int>(pack2<DT>(y[2], y[3]))};
                 __builtin_amdgcn_raw_buffer_store_b64(d, rs, voff[u] | emask, 0, 0);
                 if constexpr (NQ == 3)
                     if (cq == 2) __builtin_amdgcn_raw_buffer_store_b64(cq3v, rs, (voff[u] + 32) | emask, 0, 0);      // (wave-uniform; OOB stays OOB)

@@ -414,6 +414,7 @@ __global__ __launch_bounds__(512, 2) void stage5x_kernel(const StageArgs a) {
             const char* orow = out_img + static_cast<int64_t>(yo0 + rr) * out_row_bytes;
             const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(orow), 0, out_row_bytes, 0x00020000);
             const int emask = emit ? 0 : OOB;
+            [[maybe_unused]] const unsigned seed = (!a.dither || cq == a.plain_q) ? RN_SEED_PLAIN : rn_dither_seed(yo0 + rr);      // (bf16 handles: rn_stage.h)
             if (!epi_live) {
                 // (K48, last quarter: nothing to compute -- its waves store the constants, so that the pixels leave as full lines and
                 //  VM_CNT counts two stores per odd step in every wave: the counted wait at the top of a step is one immediate)
@@ -457,7 +458,11 @@ __global__ __launch_bounds__(512, 2) void stage5x_kernel(const StageArgs a) {
                     const float rsv = __builtin_fmaf(r_hi[i] - lo, yl, lo);
                     y[i] = __builtin_fmaf(rsv, sc2[i], y1);
                 }
-                const i32x2 d = {static_cast<int>(pack2<DT>(y[0], y[1])), static_cast<int>(pack2<DT>(y[2], y[3]))};
+                i32x2 d;
+                if constexpr (DT == RN_DTYPE_BF16)
+                    d = i32x2{static_cast<int>(pack2_sr_bf16(y[0], y[1], seed)), static_cast<int>(pack2_sr_bf16(y[2], y[3], seed))};
+                else
+                    d = i32x2{static_cast<int>(pack2<DT>(y[0], y[1])), static_cast<int>(pack2<DT>(y[2], y[3]))};
                 __builtin_amdgcn_raw_buffer_store_b64(d, rs, voff[u] | emask, 0, 0);
             }
         }
