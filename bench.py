@@ -769,6 +769,8 @@ def main():
                     # 16 constant couts not convolved; the stage behind contracts five K = 32 fragments per kernel row instead of six
                     share[cc["stage"]] = 1.0 - cc["channels_not_convolved"] / float(graph.stages[cc["stage"]].cout)
                     share[cc["stage"] + 1] *= 5.0 / 6.0
+                    if cc["stage"] + 2 < n_st and graph.stages[cc["stage"] + 2].cin == 64:      # (its output's last 16 channels are constants too)
+                        share[cc["stage"] + 2] *= 5.0 / 6.0
             launches = []
             for j, g in enumerate(groups):
                 sec = max(group_ms[j], 1e-9) * 1e-3

@@ -55,6 +55,7 @@ struct BackendArgs {
     const unsigned short* in;     // [N, W, W, 64]
     const i32x4* wfrag6;          // rn_stage6x_pack
     const float* ptab6;           // folded BN: scale[128], shift[128]
+    const float* cstart6;         // K48 (null otherwise): wfrag6 = rn_stage6x_pack48's fragments, cstart6[cout] = the constant input channels' sum
     int W, Wo;                    // stage-6 input / output side
     // stage 7
     const i32x4* wfrag7;          // rn_conv16p_pack: [36][64 lanes]
@@ -79,8 +80,9 @@ __device__ __forceinline__ f32x4 mfma16(i32x4 a, i32x4 b, f32x4 c) {
         return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
 }
 
-template <int DT>
+template <int DT, bool K48>
 __global__ __launch_bounds__(704) void backend_kernel(const BackendArgs a) {
+    constexpr int NF = K48 ? 5 : 6;                 // stage-6 operand fragments per tile and row step (rn_stage6x.hip: K48)
     extern __shared__ __attribute__((aligned(64))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -108,9 +110,9 @@ __global__ __launch_bounds__(704) void backend_kernel(const BackendArgs a) {
     if (wave < 8) {
         // =============================================================== stage 6 (rn_stage6x.hip), output into the mid ring
         const unsigned ring_lds = lds_addr(ring6);
-        i32x4 wf[18];
+        i32x4 wf[3 * NF];
 #pragma unroll
-        for (int f = 0; f < 18; ++f) {
+        for (int f = 0; f < 3 * NF; ++f) {
             const i32x4* src = a.wfrag6 + (f * 8 + wave) * 64 + lane;
             asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(wf[f]) : "v"(src) : "memory");
         }
@@ -137,6 +139,15 @@ __global__ __launch_bounds__(704) void backend_kernel(const BackendArgs a) {
                 const int p = px16 + kx;
                 base[kx][ch] = ring_lds + static_cast<unsigned>(p * 128 + (((4 * ch + g) ^ swz8(p)) << 4));
             }
+        f32x4 cst4 = zero4;
+        if constexpr (K48) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int p = px16 + (j == 0 ? (g >> 1) : 2);
+                base[j][1] = ring_lds + static_cast<unsigned>(p * 128 + (((4 + (g & 1)) ^ swz8(p)) << 4));
+            }
+            cst4 = *reinterpret_cast<const f32x4*>(a.cstart6 + 16 * wave + 4 * g);
+        }
         // a lane holds couts 16 wave + 4 g .. + 3 of pixel 16 k + px16: 8 bytes = half (g & 1) of chunk 2 wave + g / 2 of the pixel
         unsigned moff[3];
 #pragma unroll
@@ -155,7 +166,7 @@ __global__ __launch_bounds__(704) void backend_kernel(const BackendArgs a) {
         for (int j = 0; j < B_AHEAD; ++j) issue_row(j, j);
         wait_vmcnt<0>();
 #pragma unroll
-        for (int f = 0; f < 18; ++f) asm volatile("" : "+v"(wf[f]));
+        for (int f = 0; f < 3 * NF; ++f) asm volatile("" : "+v"(wf[f]));
         lds_barrier();
 
         int slot_cur = 0;
@@ -213,17 +224,50 @@ __global__ __launch_bounds__(704) void backend_kernel(const BackendArgs a) {
                 const unsigned ma = moff[k] + mslot;
                 asm volatile("ds_write_b64 %0, %1" ::"v"(ma), "v"(d) : "memory");
             };
+            [[maybe_unused]] i32x4 fq5[2][K48 ? 5 : 1];
+            auto reads5 = [&](auto KC) __attribute__((always_inline)) {
+                constexpr int k = decltype(KC)::value;
+                auto& dst = fq5[k & 1];
+                auto& bcr = bc;
+#pragma unroll
+                for (int f = 0; f < 5; ++f) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst[f]) : "v"(f < 3 ? bcr[f][0] : bcr[f - 3][1]), "n"(k * 2048));
+            };
+            auto tile5 = [&](auto KC, auto NEXTC) __attribute__((always_inline)) {
+                constexpr int k = decltype(KC)::value;
+                constexpr bool NEXT = decltype(NEXTC)::value != 0;
+                if constexpr (NEXT) reads5(IC<k + 1>{});
+                auto& cur = fq5[k & 1];
+                [&]<int... F>(std::integer_sequence<int, F...>) {
+                    (([&] {
+                         asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(cur[F]) : "n"((NEXT ? 5 : 0) + 4 - F));
+                         acc[iN][k] = mfma16<DT>(wf[0 * NF + F], cur[F], F == 0 ? cst4 : acc[iN][k]);
+                         acc[iM][k] = mfma16<DT>(wf[1 * NF + F], cur[F], acc[iM][k]);
+                         acc[iO][k] = mfma16<DT>(wf[2 * NF + F], cur[F], acc[iO][k]);
+                     }()),
+                     ...);
+                }(std::make_integer_sequence<int, 5>{});
+            };
             if (s < nin) {
-                reads(IC<0>{});
-                batch(IC<0>{}, IC<1>{});
-                batch(IC<1>{}, IC<1>{});
-                emit(IC<0>{});
-                batch(IC<2>{}, IC<1>{});
-                batch(IC<3>{}, IC<1>{});
-                emit(IC<1>{});
-                batch(IC<4>{}, IC<1>{});
-                batch(IC<5>{}, IC<0>{});
-                emit(IC<2>{});
+                if constexpr (K48) {
+                    reads5(IC<0>{});
+                    tile5(IC<0>{}, IC<1>{});
+                    emit(IC<0>{});
+                    tile5(IC<1>{}, IC<1>{});
+                    emit(IC<1>{});
+                    tile5(IC<2>{}, IC<0>{});
+                    emit(IC<2>{});
+                } else {
+                    reads(IC<0>{});
+                    batch(IC<0>{}, IC<1>{});
+                    batch(IC<1>{}, IC<1>{});
+                    emit(IC<0>{});
+                    batch(IC<2>{}, IC<1>{});
+                    batch(IC<3>{}, IC<1>{});
+                    emit(IC<1>{});
+                    batch(IC<4>{}, IC<1>{});
+                    batch(IC<5>{}, IC<0>{});
+                    emit(IC<2>{});
+                }
             }
             slot_cur = slot_cur == B_NS - 1 ? 0 : slot_cur + 1;
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -372,8 +416,8 @@ bool rn_backend_supported(const rn_handle* h) {
     return true;
 }
 
-int rn_backend_launch(rn_handle* h, const i32x4* wfrag6, const float* ptab6, const i32x4* wfrag7, const float* ptab7, const i32x4* wfrag_a,
-                      const i32x4* wfrag_b, const HeadArgs& head, int n, float* d_probs, int64_t* d_ids) {
+int rn_backend_launch(rn_handle* h, const i32x4* wfrag6, const float* ptab6, const float* cstart6, const i32x4* wfrag7, const float* ptab7,
+                      const i32x4* wfrag_a, const i32x4* wfrag_b, const HeadArgs& head, int n, float* d_probs, int64_t* d_ids) {
     const size_t ns = h->stages.size();
     const StagePlan& s5 = h->stages[ns - 5];
     const StagePlan& s6 = h->stages[ns - 4];
@@ -382,6 +426,7 @@ int rn_backend_launch(rn_handle* h, const i32x4* wfrag6, const float* ptab6, con
     a.in = static_cast<const unsigned short*>(h->nodes[s5.node_bn2 >= 0 ? s5.node_bn2 : s5.node_bn].ptr);
     a.wfrag6 = wfrag6;
     a.ptab6 = ptab6;
+    a.cstart6 = cstart6;
     a.W = s6.in_side;
     a.Wo = s6.out_side;
     a.wfrag7 = wfrag7;
@@ -400,6 +445,10 @@ int rn_backend_launch(rn_handle* h, const i32x4* wfrag6, const float* ptab6, con
         RN_CHECK_LAUNCH();
         return RN_OK;
     };
-    if (h->dtype == RN_DTYPE_BF16) return launch(backend_kernel<RN_DTYPE_BF16>);
-    return launch(backend_kernel<RN_DTYPE_F16>);
+    if (cstart6) {
+        if (h->dtype == RN_DTYPE_BF16) return launch(backend_kernel<RN_DTYPE_BF16, true>);
+        return launch(backend_kernel<RN_DTYPE_F16, true>);
+    }
+    if (h->dtype == RN_DTYPE_BF16) return launch(backend_kernel<RN_DTYPE_BF16, false>);
+    return launch(backend_kernel<RN_DTYPE_F16, false>);
 }

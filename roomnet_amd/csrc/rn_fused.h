@@ -70,6 +70,9 @@ bool rn_stage6x_plan(int out_side, int* n_cb, int* xo0, int* wo);       // colum
 void rn_stage6x_pack(const float* w_hwio, int dtype, unsigned short (*cvt_bf16)(float), unsigned short (*cvt_f16)(float),
                      std::vector<unsigned short>* out);
 int rn_stage6x_launch(int dtype, hipStream_t s, const rnk::StageArgs& a, int n);
+// ... without its input channels 48..63 (constants of the handle): StageArgs::cstart carries their sum
+void rn_stage6x_pack48(const float* w_hwio, int dtype, unsigned short (*cvt_bf16)(float), unsigned short (*cvt_f16)(float),
+                       std::vector<unsigned short>* out);
 // the 32 -> 64 stage with pool 4/2 on 16x16x32 tiles with row-register blocking (rn_stage4x.hip)
 bool rn_stage4x_supported(int cin, int cout, int pool_k, int pool_s, bool res, int in_side);
 bool rn_stage4x_plan(int out_side, int* n_cb, int* xo0, int* wo);
@@ -100,5 +103,6 @@ int rn_f32m_launch(rn_handle* h, int stage, const float* in, int n);      // wri
 
 // ---- the back end in one launch: stage 6 -> 7 -> 8 -> 9 -> head (rn_backend.hip)
 bool rn_backend_supported(const rn_handle* h);
-int rn_backend_launch(rn_handle* h, const rnk::i32x4* wfrag6, const float* ptab6, const rnk::i32x4* wfrag7, const float* ptab7,
-                      const rnk::i32x4* wfrag_a, const rnk::i32x4* wfrag_b, const HeadArgs& head, int n, float* d_probs, int64_t* d_ids);
+int rn_backend_launch(rn_handle* h, const rnk::i32x4* wfrag6, const float* ptab6, const float* cstart6, const rnk::i32x4* wfrag7,
+                      const float* ptab7, const rnk::i32x4* wfrag_a, const rnk::i32x4* wfrag_b, const HeadArgs& head, int n, float* d_probs,
+                      int64_t* d_ids);

@@ -654,6 +654,8 @@ struct FusedState {
     unsigned short const4_val[16] = {};   // their stored values (s4.bn positions 48..63)
     unsigned short const5_val[16] = {};   // ... and of the residual stage's output (s5.bn2 positions 48..63)
     unsigned short* const_vals_dev = nullptr;   // [2][16] on the device: const4_val | const5_val (StageArgs::cvals)
+    i32x4* s6_wfrag48 = nullptr;     // the stage behind the residual stage without ITS constant input channels (rn_stage6x_pack48) ...
+    float* s6_cstart = nullptr;      // ... and their contribution [128]
     float* s5_cstart = nullptr;      // [64] what the 16 constant input channels add to every conv output of the residual stage
     i32x4* s5_wfrag48 = nullptr;     // the residual stage's fragments without them (rn_stage5x_pack48)
     std::map<int, std::vector<int>> node_perm;
@@ -1051,6 +1053,37 @@ int rn_fused_prepare(rn_handle* h, const rn_weights* w_in) {
             f.wfrag16 = static_cast<i32x4*>(d16);
             f.use_s6x = true;
             f.use_c16 = false;
+            if (fs->const4 && static_cast<int>(i) == fs->fold5_stage + 1 && s.cin == 64 && s.cout == 128) {
+                // the residual stage's output channels 48..63 are constants (const5_val): this stage contracts 48 input channels and
+                // starts from their contribution, like the residual stage itself
+                rn_stage6x_pack48(wsrc, h->dtype, f32_to_bf16, f32_to_f16, &f16);
+                void* d48 = nullptr;
+                if (hipMalloc(&d48, f16.size() * 2) != hipSuccess) {
+                    rn_set_error("hipMalloc(stage6x weights) failed");
+                    return RN_E_NOMEM;
+                }
+                h->allocs.push_back(d48);
+                RN_HIP(hipMemcpy(d48, f16.data(), f16.size() * 2, hipMemcpyHostToDevice));
+                fs->s6_wfrag48 = static_cast<i32x4*>(d48);
+                const auto cv = [&](float v) { return h->dtype == RN_DTYPE_BF16 ? f32_to_bf16(v) : f32_to_f16(v); };
+                const auto bk = [&](unsigned short u) { return h->dtype == RN_DTYPE_BF16 ? bf16_bits_to_f32(u) : f16_to_f32(u); };
+                std::vector<float> cst(128);
+                for (int co = 0; co < 128; ++co) {
+                    double sum = 0.0;
+                    for (int tap = 0; tap < 9; ++tap)
+                        for (int p = 48; p < 64; ++p)
+                            sum += static_cast<double>(bk(cv(wsrc[(static_cast<size_t>(tap) * 64 + p) * 128 + co]))) * static_cast<double>(bk(fs->const5_val[p - 48]));
+                    cst[co] = static_cast<float>(sum);
+                }
+                void* dc = nullptr;
+                if (hipMalloc(&dc, cst.size() * 4) != hipSuccess) {
+                    rn_set_error("hipMalloc(stage6x constants) failed");
+                    return RN_E_NOMEM;
+                }
+                h->allocs.push_back(dc);
+                RN_HIP(hipMemcpy(dc, cst.data(), cst.size() * 4, hipMemcpyHostToDevice));
+                fs->s6_cstart = static_cast<float*>(dc);
+            }
         }
         if (f.ptab && want_s4x) {
             std::vector<unsigned short> f16;
@@ -1128,6 +1161,7 @@ int rn_fused_prepare(rn_handle* h, const rn_weights* w_in) {
     }
     if (fs->const4 && !(fs->fold5_stage >= 1 && fs->st[fs->fold5_stage - 1].use_s4x && fs->st[fs->fold5_stage].use_s5x && fs->s5_wfrag48 && fs->s5_cstart))
         fs->const4 = false;          // (another kernel family runs one of the two stages: every channel is computed)
+    if (!fs->const4) fs->s6_wfrag48 = nullptr, fs->s6_cstart = nullptr;
     if (fs->const4) {
         unsigned short both[32];
         std::memcpy(both, fs->const4_val, 32);
@@ -1440,8 +1474,9 @@ int rn_fused_forward(rn_handle* h, const uint8_t* d_bgr, const float* d_rgb, int
             for (size_t k = i; k + 1 < ns; ++k) rn_record_event(h, 2 + static_cast<int>(k));
             HeadArgs head;
             rn_fill_head_args(h, &head);
-            int rc = rn_backend_launch(h, fs->st[ns - 4].wfrag16, fs->st[ns - 4].ptab, fs->st[ns - 3].wfrag16, fs->st[ns - 3].ptab, fs->st[ns - 2].wfrag,
-                                       fs->st[ns - 1].wfrag, head, n, d_probs, d_ids);
+            const bool k48_6 = fs->s6_cstart && static_cast<int>(ns) - 4 == fs->fold5_stage + 1;
+            int rc = rn_backend_launch(h, k48_6 ? fs->s6_wfrag48 : fs->st[ns - 4].wfrag16, fs->st[ns - 4].ptab, k48_6 ? fs->s6_cstart : nullptr,
+                                       fs->st[ns - 3].wfrag16, fs->st[ns - 3].ptab, fs->st[ns - 2].wfrag, fs->st[ns - 1].wfrag, head, n, d_probs, d_ids);
             if (rc != RN_OK) return rc;
             fs->last_backend = true;         // (only now: a failed launch must not report s6.bn / s7.bn as elided)
             rn_record_event(h, 2 + static_cast<int>(ns - 1));
@@ -1666,6 +1701,10 @@ int rn_fused_forward(rn_handle* h, const uint8_t* d_bgr, const float* d_rgb, int
             if (fs->const4 && f.use_s4x && static_cast<int>(i) + 1 == fs->fold5_stage) {      // its last cout quarter is constant
                 a.live_q = 3;
                 a.cvals = fs->const_vals_dev;
+            }
+            if (fs->s6_cstart && f.use_s6x && static_cast<int>(i) == fs->fold5_stage + 1) {
+                a.wfrag = fs->s6_wfrag48;
+                a.cstart = fs->s6_cstart;
             }
             if (fs->const4 && f.use_s5x && static_cast<int>(i) == fs->fold5_stage) {
                 a.wfrag = fs->s5_wfrag48;

@@ -42,8 +42,13 @@ __device__ __forceinline__ f32x4 mfma16(i32x4 a, i32x4 b, f32x4 c) {
         return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
 }
 
-template <int DT>
+// K48 (round 6): the input channels 48..63 are constants of the handle (the residual stage in front writes them from a table,
+// rn_fused_prepare): five operand fragments per tile and row step instead of six -- rn_stage5x.hip's scheme: (kx, channels 0..31)
+// for kx = 0, 1, 2, then [kx 0 | kx 1] and [kx 2 | zero weights] of channels 32..47 -- read a whole tile ahead, and the
+// accumulators start from the constants' contribution (StageArgs::cstart).
+template <int DT, bool K48>
 __global__ __launch_bounds__(512, 2) void stage6x_kernel(const StageArgs a) {
+    constexpr int NF = K48 ? 5 : 6;
 #ifdef RN_CLOCK
     unsigned long long ck_t0, ck_r0;
     clock_pair(ck_t0, ck_r0);
@@ -72,10 +77,10 @@ __global__ __launch_bounds__(512, 2) void stage6x_kernel(const StageArgs a) {
         if (p >= W) *reinterpret_cast<i32x4*>(ring + slot * S6_ROW + p * 128 + c * 16) = i32x4{0, 0, 0, 0};
     }
 
-    // ---- weights: fragment f = (ky * 3 + kx) * 2 + ch, A operand of D[cout][pixel]
-    i32x4 wf[18];
+    // ---- weights: fragment f = (ky * 3 + kx) * 2 + ch (K48: ky * 5 + j, rn_stage6x_pack48), A operand of D[cout][pixel]
+    i32x4 wf[3 * NF];
 #pragma unroll
-    for (int f = 0; f < 18; ++f) {
+    for (int f = 0; f < 3 * NF; ++f) {
         const i32x4* src = a.wfrag + (f * 8 + wave) * 64 + lane;
         asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(wf[f]) : "v"(src) : "memory");
     }
@@ -105,6 +110,15 @@ __global__ __launch_bounds__(512, 2) void stage6x_kernel(const StageArgs a) {
             const int p = px16 + kx;
             base[kx][ch] = ring_lds + static_cast<unsigned>(p * 128 + (((4 * ch + g) ^ swz8(p)) << 4));
         }
+    f32x4 cst4 = zero4;
+    if constexpr (K48) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {          // merged fragments: lane groups 0, 1 = chunks 4, 5 of tap column 0 (j = 1: 2), groups 2, 3 of column 1
+            const int p = px16 + (j == 0 ? (g >> 1) : 2);
+            base[j][1] = ring_lds + static_cast<unsigned>(p * 128 + (((4 + (g & 1)) ^ swz8(p)) << 4));
+        }
+        cst4 = *reinterpret_cast<const f32x4*>(a.cstart + 16 * wave + 4 * g);      // (D[cout][pixel]: the lane's 4 couts)
+    }
     int voff[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
@@ -126,7 +140,7 @@ __global__ __launch_bounds__(512, 2) void stage6x_kernel(const StageArgs a) {
     for (int j = 0; j < S6_AHEAD; ++j) issue_row(j, j);
     wait_vmcnt<0>();
 #pragma unroll
-    for (int f = 0; f < 18; ++f) asm volatile("" : "+v"(wf[f]));
+    for (int f = 0; f < 3 * NF; ++f) asm volatile("" : "+v"(wf[f]));
     lds_barrier();
 
     int slot_cur = 0;
@@ -186,16 +200,49 @@ __global__ __launch_bounds__(512, 2) void stage6x_kernel(const StageArgs a) {
             const i32x2 d = {static_cast<int>(pack2<DT>(y[0], y[1])), static_cast<int>(pack2<DT>(y[2], y[3]))};
             __builtin_amdgcn_raw_buffer_store_b64(d, rs, voff[k] | emask, 0, 0);
         };
-        reads(IC<0>{});
-        batch(IC<0>{}, IC<1>{});
-        batch(IC<1>{}, IC<1>{});
-        emit(IC<0>{});
-        batch(IC<2>{}, IC<1>{});
-        batch(IC<3>{}, IC<1>{});
-        emit(IC<1>{});
-        batch(IC<4>{}, IC<1>{});
-        batch(IC<5>{}, IC<0>{});
-        emit(IC<2>{});
+        [[maybe_unused]] i32x4 fq5[2][K48 ? 5 : 1];
+        auto reads5 = [&](auto KC) __attribute__((always_inline)) {
+            constexpr int k = decltype(KC)::value;
+            auto& dst = fq5[k & 1];
+            auto& bcr = bc;
+#pragma unroll
+            for (int f = 0; f < 5; ++f) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst[f]) : "v"(f < 3 ? bcr[f][0] : bcr[f - 3][1]), "n"(k * 2048));
+        };
+        auto tile5 = [&](auto KC, auto NEXTC) __attribute__((always_inline)) {
+            constexpr int k = decltype(KC)::value;
+            constexpr bool NEXT = decltype(NEXTC)::value != 0;
+            if constexpr (NEXT) reads5(IC<k + 1>{});
+            auto& cur = fq5[k & 1];
+            [&]<int... F>(std::integer_sequence<int, F...>) {
+                (([&] {
+                     asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(cur[F]) : "n"((NEXT ? 5 : 0) + 4 - F));
+                     acc[iN][k] = mfma16<DT>(wf[0 * NF + F], cur[F], F == 0 ? cst4 : acc[iN][k]);
+                     acc[iM][k] = mfma16<DT>(wf[1 * NF + F], cur[F], acc[iM][k]);
+                     acc[iO][k] = mfma16<DT>(wf[2 * NF + F], cur[F], acc[iO][k]);
+                 }()),
+                 ...);
+            }(std::make_integer_sequence<int, 5>{});
+        };
+        if constexpr (K48) {
+            reads5(IC<0>{});
+            tile5(IC<0>{}, IC<1>{});
+            emit(IC<0>{});
+            tile5(IC<1>{}, IC<1>{});
+            emit(IC<1>{});
+            tile5(IC<2>{}, IC<0>{});
+            emit(IC<2>{});
+        } else {
+            reads(IC<0>{});
+            batch(IC<0>{}, IC<1>{});
+            batch(IC<1>{}, IC<1>{});
+            emit(IC<0>{});
+            batch(IC<2>{}, IC<1>{});
+            batch(IC<3>{}, IC<1>{});
+            emit(IC<1>{});
+            batch(IC<4>{}, IC<1>{});
+            batch(IC<5>{}, IC<0>{});
+            emit(IC<2>{});
+        }
         slot_cur = slot_cur == S6_NS - 1 ? 0 : slot_cur + 1;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     };
@@ -246,12 +293,43 @@ void rn_stage6x_pack(const float* w_hwio, int dtype, unsigned short (*cvt_bf16)(
                 }
 }
 
+// K48 fragments (rn_stage5x_pack48's layout with eight 16-cout groups): frag[f = ky * 5 + j][group q][lane][e]
+void rn_stage6x_pack48(const float* w_hwio, int dtype, unsigned short (*cvt_bf16)(float), unsigned short (*cvt_f16)(float),
+                       std::vector<unsigned short>* out) {
+    out->assign(static_cast<size_t>(15) * 8 * 64 * 8, 0);
+    for (int ky = 0; ky < 3; ++ky)
+        for (int j = 0; j < 5; ++j)
+            for (int q = 0; q < 8; ++q)
+                for (int l = 0; l < 64; ++l)
+                    for (int e = 0; e < 8; ++e) {
+                        const int g = l >> 4, co = 16 * q + (l & 15);
+                        int kx, ch;
+                        if (j < 3) {
+                            kx = j;
+                            ch = 8 * g + e;
+                        } else if (j == 3) {
+                            kx = g >> 1;
+                            ch = 32 + 8 * (g & 1) + e;
+                        } else {
+                            if (g >= 2) continue;
+                            kx = 2;
+                            ch = 32 + 8 * g + e;
+                        }
+                        const float v = w_hwio[(static_cast<size_t>(ky * 3 + kx) * 64 + ch) * 128 + co];
+                        (*out)[((static_cast<size_t>(ky * 5 + j) * 8 + q) * 64 + l) * 8 + e] = dtype == RN_DTYPE_BF16 ? cvt_bf16(v) : cvt_f16(v);
+                    }
+}
+
 int rn_stage6x_launch(int dtype, hipStream_t s, const StageArgs& a, int n) {
     auto launch = [&](auto kern) -> int {
         hipLaunchKernelGGL(kern, dim3(a.n_bands * a.n_cb, n), dim3(512), S6_LDS, s, a);
         RN_CHECK_LAUNCH();
         return RN_OK;
     };
-    if (dtype == RN_DTYPE_BF16) return launch(stage6x_kernel<RN_DTYPE_BF16>);
-    return launch(stage6x_kernel<RN_DTYPE_F16>);
+    if (a.cstart) {
+        if (dtype == RN_DTYPE_BF16) return launch(stage6x_kernel<RN_DTYPE_BF16, true>);
+        return launch(stage6x_kernel<RN_DTYPE_F16, true>);
+    }
+    if (dtype == RN_DTYPE_BF16) return launch(stage6x_kernel<RN_DTYPE_BF16, false>);
+    return launch(stage6x_kernel<RN_DTYPE_F16, false>);
 }

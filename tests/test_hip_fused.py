@@ -15,7 +15,12 @@ from roomnet_amd.graph import build_graph
 
 pytestmark = pytest.mark.gpu
 
-TOL_LOGITS = 0.1
+TOL_LOGITS = 0.1          # SURVEY 8c's bound on |logit - fp64 truth| for 16-bit storage: the contract
+# What the tests ASSERT on the parity sets since round 6 (conv weights rounded with the residual carried from tap to tap; bf16 stores
+# of stages 1, 3, 4, 5 dithered by the output row): measured 0.024 (bf16) / 0.022 (fp16) at 224 and 0.047 / 0.017 at 600
+# (profiles/r6_parity.json; rounds 1-5: 0.080 / 0.022 and 0.126 / 0.014)
+TOL_LOGITS_224 = {"bf16": 0.06, "f16": 0.05}
+TOL_LOGITS_600 = {"bf16": 0.1, "f16": 0.05}
 MARGIN = 0.2
 # max |err| / absmax of the stage output.  Observed (profiles/r3_parity.json): bf16 <= 0.0067 at 224 and <= 0.0059 at 600,
 # f16 <= 0.0048 / 0.0024: the bounds sit at about twice that (round 2 carried 0.04 for bf16)
@@ -123,7 +128,7 @@ def _downstream_same(fused, plain, names, nb, dtype, probs_f, probs_p, ids_f, id
         if name.startswith("d"):              # the fp32 logits: every element moves a little, none by much
             np.testing.assert_allclose(fused.tap(name, nb), plain.tap(name, nb), rtol=0, atol=1e-2, err_msg=name)
             continue
-        _same_up_to_sum_order(fused.tap(name, nb), plain.tap(name, nb), dtype, name, frac=6e-2, n_ulp=8)
+        _same_up_to_sum_order(fused.tap(name, nb), plain.tap(name, nb), dtype, name, frac=6e-2, n_ulp=12)
     np.testing.assert_allclose(probs_f, probs_p, rtol=0, atol=2e-3)
     np.testing.assert_array_equal(ids_f, ids_p)
 
@@ -174,7 +179,7 @@ def test_logits_probs_ids_vs_golden(engine, parity_images, golden_parity, record
         "max_abs_dprob_vs_fp64": float(np.abs(probs - golden_parity["probs_f64"]).max()),
         "ids_differing_from_fp64": int((ids != golden_parity["ids"]).sum()),
         "smallest_top2_margin_fp64": float(golden_parity["top2_margin"].min())})
-    assert err <= TOL_LOGITS, err
+    assert err <= TOL_LOGITS_224[engine.dtype_name], err
     safe = golden_parity["top2_margin"] > MARGIN
     assert safe.sum() >= 25
     np.testing.assert_array_equal(ids[safe], golden_parity["ids"][safe])
@@ -251,7 +256,7 @@ def test_one_launch_back_end_is_bit_identical_to_the_stage_launches(weights, par
         # another fp32 order than the per-stage launches (see _same_up_to_sum_order), so from s3.bn2 on the two handles agree up
         # to that -- 16-bit tensors within a few ulp on a few elements, the fp32 logits within the bound the probabilities get
         for name in ("s8.bn", "s9.bn2"):
-            _same_up_to_sum_order(taps_f[name], plain.tap(name, nb), dtype, name, frac=5e-2, n_ulp=8)
+            _same_up_to_sum_order(taps_f[name], plain.tap(name, nb), dtype, name, frac=5e-2, n_ulp=12)
         np.testing.assert_allclose(taps_f["d3.relu"], plain.tap("d3.relu", nb), rtol=0, atol=1e-2)
         np.testing.assert_allclose(probs_f, probs_p, rtol=0, atol=2e-3)
         np.testing.assert_array_equal(ids_f, ids_p)
@@ -366,7 +371,7 @@ def test_randomized_batch_256_against_the_f32_hip_path(weights, record):
                 worst_stage = max(worst_stage, float(per_image.max()))
                 assert per_image.max() <= 2 * STAGE_TOL["bf16"], (i, per_image.argmax(), per_image.max())
         record("random_256_images_224", "bf16_vs_float32_hip_path", {"max_abs_dlogit": worst, "max_stage_rel_err_s3_s8": worst_stage})
-        assert worst <= TOL_LOGITS, worst
+        assert worst <= TOL_LOGITS_224["bf16"], worst
         np.testing.assert_allclose(probs.sum(1), 1.0, atol=1e-5)
     finally:
         big.close()
@@ -428,14 +433,13 @@ def test_batch_limits(engine):
 
 
 # ------------------------------------------------------------------ 600x600 variant (BASELINE config 5)
-@pytest.mark.parametrize("dtype,tol", [("f16", 0.1), ("bf16", 0.16), ("f32", 1e-4)])
+@pytest.mark.parametrize("dtype,tol", [("f16", TOL_LOGITS_600["f16"]), ("bf16", TOL_LOGITS_600["bf16"]), ("f32", 1e-4)])
 def test_600_variant_vs_golden(weights, dtype, tol, record):
     """Large-activation variant: conv/BN weights from the checkpoint, seeded synthetic dense/kernel
     (the shipped one only fits 224).  Exercises column blocks and multi-band launches.
-    Tolerances: BASELINE config 5 is the fp16 one and keeps SURVEY 8c's 0.1 on the logits.  bf16 at 600 is an extra: its first
-    dense layer sums 3 136 bf16-rounded inputs (224: 64) against a synthetic kernel nobody trained, and over the 16 images of
-    the round-5 set the largest logit error is 0.126 (the round-4 set of 4 images: 0.07) -- stated as 0.16 here; the ids are
-    held to the same 0.2 margin rule as everywhere."""
+    Tolerances: SURVEY 8c's 0.1 on the logits for bf16 (rounds 4-5 had to state 0.16: the first dense layer sums 3 136 rounded
+    inputs, and before round 6 their rounding errors were coherent -- 0.126 on the 16-image set; with the dithered stores and the
+    carried weight rounding 0.047), 0.05 for fp16 (BASELINE config 5's dtype: 0.017); the ids are held to the 0.2 margin rule."""
     import os
     from conftest import GOLDEN
     from oracle import roomnet_ref as R
@@ -467,10 +471,12 @@ def test_600_variant_vs_golden(weights, dtype, tol, record):
                 rels[name] = float(np.abs(got - want).max() / max(np.abs(want).max(), 1e-6))
             rec["stage_rel_err"] = rels
             record("parity_600", dtype, rec)
-            # (600 x 600: the late tensors are means over more rounded inputs than at 224; bf16 is not BASELINE's dtype at this
-            #  size -- config 5 is fp16 -- and its s8.bn reaches 0.022 of abs-max on one image of the round-5 set: factor 2)
+            # (600 x 600: the late tensors are means over more rounded inputs than at 224.  bf16: a dithered store is within ONE ulp
+            #  of the exact value instead of half an ulp -- the price of errors that cancel in the next window -- so the largest
+            #  single element of the small late tensors moves more (s8.bn / s9.bn2 0.030 of abs-max on this image; plain rounding
+            #  0.022) while the logits behind them move 2.7 times less: factor 2.5)
             for name, rel in rels.items():
-                assert rel <= STAGE_TOL[dtype] * (2.0 if dtype == "bf16" else 1.5), (name, rel)
+                assert rel <= STAGE_TOL[dtype] * (2.5 if dtype == "bf16" else 1.5), (name, rel)
         else:
             record("parity_600", dtype, rec)
     finally:
@@ -737,7 +743,7 @@ def test_600_variant_at_baseline_size_64_images(weights, dtype):
         np.testing.assert_array_equal(small.tap("s3.bn2", 4), s3)          # 64-image vs 4-image launch geometry
         np.testing.assert_array_equal(small.tap("s5.bn2", 4), s5)
         logits4 = small.tap("d3.relu", 4)
-        assert np.abs(logits4 - g["logits_f64"]).max() <= (TOL_LOGITS if dtype == "f16" else 0.16)      # (bf16 at 600: test_600_variant_vs_golden)
+        assert np.abs(logits4 - g["logits_f64"]).max() <= TOL_LOGITS_600[dtype]
         safe = g["top2_margin"] > MARGIN
         np.testing.assert_array_equal(ids[:4][safe], g["ids"][safe])
         # every other image against its batch-of-4 result

@@ -3,12 +3,12 @@
 # imply: tools/power_pass.sh > gpurun_out/r3/power.txt   (rocm-smi sampled once per second; the bench line's img/s)
 cd $GRAFT_REPO_ROOT
 smi() { rocm-smi --showclocks --showpower 2>&1 | grep -E "sclk|Package Power" | sed -e 's/.*sclk clock level: [0-9S]*: //' -e 's/.*Power (W): /W /' | tr '\n' ' '; echo; }
-for arm in "--dtype bf16" "--dtype f16" "--dtype bf16 --pair32" "--dtype f32 --steps 600"; do
+for arm in "--dtype bf16" "--dtype f16" "--dtype bf16 --no-dither" "--dtype f32 --steps 600"; do
   echo "--- bench.py --steps 6000 $arm"
   T=$(mktemp)
   (while true; do echo "   [smi] $(smi)"; sleep 1; done) > $T &
   SP=$!
-  L=$(python bench.py --steps 6000 --warmup 20 --no-cpu-baseline --no-parity-check $arm 2>/dev/null | tail -1)
+  L=$(python bench.py --steps 6000 --warmup 20 --no-cpu-baseline --no-parity-check --no-other-configs --no-unfolded-arm $arm 2>/dev/null | tail -1)
   kill $SP; wait $SP 2>/dev/null
   cat $T
   python3 - "$T" <<PY

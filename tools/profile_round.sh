@@ -13,7 +13,7 @@ O=$R/gpurun_out
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
-  rm -rf /tmp/p_$c && rocprofv3 --pmc $c -d /tmp/p_$c -o p --output-format csv -- python3 $R/bench.py --steps 3 --warmup 1 --spinup-steps 0 --no-cpu-baseline --profile-steps 1 > /tmp/p_$c.log 2>&1
+  rm -rf /tmp/p_$c && rocprofv3 --pmc $c -d /tmp/p_$c -o p --output-format csv -- python3 $R/bench.py --steps 3 --warmup 1 --spinup-steps 0 --no-cpu-baseline --no-other-configs --profile-steps 1 > /tmp/p_$c.log 2>&1
   f=$(find /tmp/p_$c -name "*counter_collection.csv" | head -1)
   lc=$(echo $c | tr A-Z a-z)
   grep -E "stage|head|tail|conv16|backend|Counter_Name" "$f" > $O/${tag}_pmc_${lc}.csv
@@ -26,6 +26,6 @@ rm -rf /tmp/kt && rocprofv3 --kernel-trace --stats -d /tmp/kt -o kt --output-for
 f=$(find /tmp/kt -name "*kernel_stats.csv" | head -1); cp "$f" $O/${tag}_kernel_stats.csv
 $R/tools/pmc_run.sh $tag > $O/${tag}_sq_summary.txt 2>&1
 if [ -f $R/tools/ab/libroomnet_hip_stamps.so ]; then
-  cd $R && ROOMNET_HIP_LIB=tools/ab/libroomnet_hip_stamps.so python3 bench.py --steps 2 --warmup 1 --spinup-steps 0 --no-cpu-baseline --profile-steps 1 2>&1 | grep "stamps" > $O/${tag}_stamps.txt
+  cd $R && ROOMNET_HIP_LIB=tools/ab/libroomnet_hip_stamps.so python3 bench.py --steps 2 --warmup 1 --spinup-steps 0 --no-cpu-baseline --no-other-configs --profile-steps 1 2>&1 | grep "stamps" > $O/${tag}_stamps.txt
 fi
 head -c 600 $O/${tag}_bench.json; echo; head -14 $O/${tag}_kernel_stats.csv | cut -c1-160
