@@ -760,8 +760,10 @@ def main():
                 p32 = [k for k in range(n_st - 1) if graph.stages[k].cin == 32 and graph.stages[k].cout == 32 and not graph.stages[k].residual]
                 dead = fold_info["pair_channels_not_convolved"]
                 if dead > 0 and p32:
-                    share[p32[0]] = 1.0 - dead / 32.0
-                    share[p32[0] + 1] = (5 * 32) / (9 * 32.0) if not f32 else 1.0 - dead / 32.0
+                    # 16-bit: the producer computes one 16-cout half whatever the ring holds; the consumer contracts five two-tap
+                    # chunks (16-channel ring) or three four-tap chunks (8-channel ring, round 6) instead of nine K = 32 taps
+                    share[p32[0]] = (1.0 - dead / 32.0) if f32 else 0.5
+                    share[p32[0] + 1] = (1.0 - dead / 32.0) if f32 else ((3 if dead >= 24 else 5) * 32) / (9 * 32.0)
                 if fold_info["residual_stage_folded"] >= 0:
                     share[fold_info["residual_stage_folded"]] = fold_info["residual_stage_live_quarters"] / 4.0
                 cc = fold_info.get("constant_channels") or {}

@@ -94,6 +94,8 @@ void rn_stage23x_pack(const float* w_hwio, int dtype, unsigned short (*cvt_bf16)
 int rn_stage23x_launch(int dtype, hipStream_t s, const rnk::Stage23Args& a, int n);
 void rn_stage23x_pack_narrow(const float* w_hwio, const int* ring_cin, int dtype, unsigned short (*cvt_bf16)(float), unsigned short (*cvt_f16)(float),
                              std::vector<unsigned short>* out);
+void rn_stage23x_pack_narrow8(const float* w_hwio, const int* ring_cin, int dtype, unsigned short (*cvt_bf16)(float), unsigned short (*cvt_f16)(float),
+                              std::vector<unsigned short>* out);
 
 // ---- float32 conv stages on the matrix cores (rn_stage_f32m.hip): the throughput path of RN_DTYPE_F32 handles without RN_FLAG_TAPS
 int rn_f32m_prepare(rn_handle* h, const rn_weights* w);

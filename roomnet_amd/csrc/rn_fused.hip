@@ -661,6 +661,7 @@ struct FusedState {
     std::map<int, std::vector<int>> node_perm;
     float* pair_ptab_x = nullptr;    // rn_stage23x.hip's table: pair_ptab with the first stage's channels in the B ring's order
     int pair_producer_halves = 2;    // 1: 16 channels of the pair's on-chip tensor are frozen and not computed (Stage23Args)
+    int pair_narrow = 0;             // with it: 1 = the ring holds 16 channels, 2 = eight (24 constant channels; round 6)
     int pair_frozen = 0;             // how many channels of it are frozen on this handle
     // stage 0
     i32x4* s0_wfrag = nullptr;
@@ -1222,22 +1223,32 @@ int rn_fused_prepare(rn_handle* h, const rn_weights* w_in) {
                 }
                 int perm[32];
                 {
+                    // Round 6: the criterion is the tensor's 16-BIT STORE (as for the constant quarter of the 64-channel block above): the
+                    // channel is constant when the two ends of the pooled sum's range, H = 0 and H = 16, store the same 16-bit number
+                    // (fma and the conversion are monotone in H) -- every channel whose fma returns its addend in float32 (round 5's
+                    // criterion: 18 on the shipped checkpoint) and those whose scale is below half an ulp of the shift (26 in bf16,
+                    // 25 in fp16).  With >= 24 of them the ring holds EIGHT channels (live ones at positions 0..3, 8..11: the lane
+                    // groups 0, 1 of the producer's half), with >= 16 sixteen (positions (p & 7) < 4).
                     std::vector<int> frozen, live;
                     for (int c = 0; c < 32; ++c) {
-                        const double sc = t1[c], sh = t1[32 + c];
-                        const bool fz = std::fabs(sc) * 16.0 * (1.0 + 1e-6) < std::fabs(sh) * 2.98023223876953125e-8;      // 2^-25
+                        const float sc = t1[c], sh = t1[32 + c];
+                        const bool fz = std::isfinite(sh) && cv_store(std::fmaf(0.0f, sc, sh)) == cv_store(std::fmaf(16.0f, sc, sh));
                         (fz ? frozen : live).push_back(c);
                     }
                     fs->pair_frozen = static_cast<int>(frozen.size());
-                    fs->pair_producer_halves = (frozen.size() >= 16 && !(h->flags & RN_FLAG_COMPUTE_FROZEN)) ? 1 : 2;
+                    const bool fold_pair = !(h->flags & RN_FLAG_COMPUTE_FROZEN);
+                    fs->pair_producer_halves = (frozen.size() >= 16 && fold_pair) ? 1 : 2;
+                    fs->pair_narrow = fs->pair_producer_halves == 1 ? (frozen.size() >= 24 ? 2 : 1) : 0;
+                    const int n_fold = fs->pair_narrow == 2 ? 24 : 16;
+                    const auto live_pos = [&](int p) { return fs->pair_narrow == 2 ? ((p & 7) < 4 && p < 16) : (p & 7) < 4; };
                     if (fs->pair_producer_halves == 1) {
-                        while (frozen.size() > 16) {             // the spare frozen channels are computed like live ones
+                        while (static_cast<int>(frozen.size()) > n_fold) {             // the spare constant channels are computed like live ones
                             live.push_back(frozen.back());
                             frozen.pop_back();
                         }
                         std::sort(live.begin(), live.end());
                         size_t nl = 0, nf = 0;
-                        for (int p = 0; p < 32; ++p) perm[p] = (p & 7) >= 4 ? frozen[nf++] : live[nl++];
+                        for (int p = 0; p < 32; ++p) perm[p] = live_pos(p) ? live[nl++] : frozen[nf++];
                     } else {
                         for (int p = 0; p < 32; ++p) perm[p] = p;
                     }
@@ -1263,7 +1274,7 @@ int rn_fused_prepare(rn_handle* h, const rn_weights* w_in) {
                         for (int co = 0; co < 32; ++co) {
                             double sum = 0.0;
                             for (int p = 0; p < 32; ++p) {
-                                if ((p & 7) < 4) continue;
+                                if (live_pos(p)) continue;
                                 const double val = bk(cv_store(t1[32 + perm[p]]));      // (the channel's stored value: the kernels' own store)
                                 for (int tap = 0; tap < 9; ++tap)
                                     sum += static_cast<double>(bk(cv(w3src[(static_cast<size_t>(tap) * 32 + perm[p]) * 32 + co]))) * val;
@@ -1293,8 +1304,11 @@ int rn_fused_prepare(rn_handle* h, const rn_weights* w_in) {
                                                : wsrc6[(static_cast<size_t>(tap) * 32 + perm[ci]) * 32 + co];       // ... and the second conv's cins
                     if (which == 1 && fs->pair_producer_halves == 1) {
                         int ring_cin[16];
-                        for (int r = 0; r < 16; ++r) ring_cin[r] = perm[8 * (r >> 2) + (r & 3)];
-                        rn_stage23x_pack_narrow(wq[1].data(), ring_cin, h->dtype, f32_to_bf16, f32_to_f16, &f16);
+                        for (int r = 0; r < 16; ++r) ring_cin[r] = perm[8 * (r >> 2) + (r & 3)];       // (eight-channel ring: r < 8)
+                        if (fs->pair_narrow == 2)
+                            rn_stage23x_pack_narrow8(wq[1].data(), ring_cin, h->dtype, f32_to_bf16, f32_to_f16, &f16);
+                        else
+                            rn_stage23x_pack_narrow(wq[1].data(), ring_cin, h->dtype, f32_to_bf16, f32_to_f16, &f16);
                     } else
                         rn_stage23x_pack(w6.data(), h->dtype, f32_to_bf16, f32_to_f16, &f16);
                     void* d16 = nullptr;
@@ -1338,7 +1352,7 @@ void rn_fused_frozen_info(const rn_handle* h, int info[4]) {
     info[2] = -1;
     info[3] = 4;
     if (!fs) return;
-    info[0] = fs->pair_x16 && fs->pair_producer_halves == 1 ? 16 : 0;
+    info[0] = fs->pair_x16 && fs->pair_producer_halves == 1 ? (fs->pair_narrow == 2 ? 24 : 16) : 0;
     info[1] = fs->pair_frozen;
     info[2] = fs->fold5_stage;
     info[3] = fs->fold5_stage >= 0 ? fs->fold5_live_q : 4;
@@ -1515,7 +1529,7 @@ int rn_fused_forward(rn_handle* h, const uint8_t* d_bgr, const float* d_rgb, int
             fa.ptab = fs->pair_x16 ? fs->pair_ptab_x : fs->pair_ptab;
             fa.producer_halves = fs->pair_x16 ? fs->pair_producer_halves : 2;
             fa.dither = fs->dither_out[i + 1];
-            fa.narrow_b = fa.producer_halves == 1 ? 1 : 0;
+            fa.narrow_b = fa.producer_halves == 1 ? fs->pair_narrow : 0;
             fa.rlo = s2.rt.lo;
             fa.rhi = s2.rt.hi;
             fa.rlerp = s2.rt.lerp;

@@ -355,8 +355,9 @@ struct Stage23Args {
     // handle's dtype and orders the channels accordingly) -- and are written from the table, bit for bit what the full
     // computation would store.  2 = every channel is computed.
     int producer_halves;
-    int narrow_b;                 // (with producer_halves == 1) the B ring holds the 16 computed channels only; wfrag3 = rn_stage23x_pack_narrow's
-                                  // 12 fragments, ptab row 5 = the second conv's constant of the frozen channels
+    int narrow_b;                 // (with producer_halves == 1) 1: the B ring holds the 16 computed channels only; wfrag3 = rn_stage23x_pack_narrow's
+                                  // 10 fragments, ptab row 5 = the second conv's constant of the frozen channels.  2 (round 6): the ring holds
+                                  // EIGHT channels (24 constant ones), wfrag3 = rn_stage23x_pack_narrow8's 6 fragments
     int dither;                   // bf16: the pair's OUTPUT rows are stored with rn_dither_seed(row) (its on-chip tensor never is)
 };
 

@@ -62,6 +62,7 @@ constexpr int X_BDUMMY = X_WMAX - 5;             // B ring column that invalid l
 constexpr int X_ROWB = (X_BDUMMY + 1) * 64;
 constexpr int X_SKROW = 64 * 64;                 // one private skip row: 64 columns
 constexpr int X_ROWB_N = (X_BDUMMY + 1) * 32;    // ... of the narrow B ring (16 channels per pixel)
+constexpr int X_ROWB_8 = (X_BDUMMY + 1) * 16;    // ... of the eight-channel B ring (round 6: 24 constant channels)
 constexpr int X_NTAB = 6 * 32;                   // folded BN tables: sc2, sh2 | sc3', sh3', sc4 | narrow form: the second conv's per-cout constant
 constexpr int X_RINGA_OFF = 1024;
 constexpr int X_RINGB_OFF = X_RINGA_OFF + X_NA * X_ROWA;
@@ -104,10 +105,17 @@ __device__ __forceinline__ f32x4 mfma16(i32x4 a, i32x4 b, f32x4 c) {
 // then [kx 2 | zero weights]: 6 operand reads and 12 MFMAs per tile where the 32-channel ring takes 9 and 18) and starts its
 // accumulators from the per-cout constant of the 16 frozen channels (Stage23Args::ptab row 5: sum over taps and frozen
 // channels of weight x stored 16-bit value -- a VALID convolution sees every tap of every pixel, so the constant is exact).
-template <int DT, int PH, bool NB>
+// N8 (with NB; round 6) = EIGHT computed channels: rn_fused_prepare proves 24 channels of B constant in the handle's 16-bit store
+// (the shipped checkpoint: 26 in bf16, 25 in fp16) and puts the live ones at B positions 0..3 and 8..11 -- the lane groups 0, 1 of
+// the producer's half -- so the ring pixel is ONE 16-byte chunk and a K = 32 operand of the second conv is FOUR TAPS x 8 channels:
+// lane group g of chunk c reads tap 4 c + g (each from its own ring row and column: the offsets sit in the lane's base), three
+// chunks for the nine taps (the last three groups of chunk 2 carry zero weights) -- 3 operand reads and 6 MFMAs per tile where the
+// 16-channel ring takes 5 and 10.
+template <int DT, int PH, bool NB, bool N8 = false>
 __global__ __launch_bounds__(512, 2) void stage23x_kernel(const Stage23Args a) {
     static_assert(!NB || PH == 1, "the narrow B ring holds the computed half only");
-    constexpr int ROWB = NB ? X_ROWB_N : X_ROWB;
+    static_assert(!N8 || NB, "the eight-channel ring is a narrow ring");
+    constexpr int ROWB = N8 ? X_ROWB_8 : NB ? X_ROWB_N : X_ROWB;
 // Registers: the kernel sits at 256 VGPRs with six spilled dwords, two of them reloaded inside the consumer's loop.  A build that
 // keeps four of the consumers' weight fragments in LDS instead has no scratch access at all and is 3 % SLOWER (0.490 against
 // 0.475 ms, one session, round 4; two fragments: equal); the reloads are not what bounds the kernel (NOTES.md).
@@ -324,7 +332,9 @@ __global__ __launch_bounds__(512, 2) void stage23x_kernel(const Stage23Args a) {
             const int xo = xw + 16 * k + px16;
             const bool last = k == (has4 ? 3 : 2);
             const int col = (xo < Wb && !(last && px16 >= 13) && (k < 3 || has4)) ? xo : X_BDUMMY;
-            if constexpr (NB)       // 8 bytes (the lane's 4 computed couts) at 8 g of the 32-byte pixel (no swizzle: see baseN0)
+            if constexpr (N8)       // lane groups 0, 1 hold the 8 live couts: 8 bytes at 8 g of the 16-byte pixel; groups 2, 3 write the dummy pixel
+                wbB[k] = ringB_lds + static_cast<unsigned>((g < 2 ? col : X_BDUMMY) * 16 + 8 * (g & 1));
+            else if constexpr (NB)  // 8 bytes (the lane's 4 computed couts) at 8 g of the 32-byte pixel (no swizzle: see baseN0)
                 wbB[k] = ringB_lds + static_cast<unsigned>(col * 32 + 8 * g);
             else
                 wbB[k] = ringB_lds + static_cast<unsigned>(col * 64 + ((g ^ swzx(col)) << 4));
@@ -587,7 +597,7 @@ __global__ __launch_bounds__(512, 2) void stage23x_kernel(const Stage23Args a) {
     const bool has4 = wq >= 2;                                      // tiles of this wave: 3 3 4 4
     const int xw = xc_start(wq);
     const int xend = wq == 3 ? Wo : min(xc_start(wq + 1), Wo);      // this wave stores output columns [xw, xend)
-    constexpr int NW3 = NB ? 10 : 2 * X_KT;                          // narrow: fragment 2 * chunk + half
+    constexpr int NW3 = N8 ? 6 : NB ? 10 : 2 * X_KT;                 // narrow: fragment 2 * chunk + half
     i32x4 w3[2 * X_KT];
 #pragma unroll
     for (int f = 0; f < NW3; ++f) {
@@ -612,17 +622,31 @@ __global__ __launch_bounds__(512, 2) void stage23x_kernel(const Stage23Args a) {
         // slots of eight pixels from the g = 0 / 2 lanes and the odd slots of the other eight from g = 1 / 3 -- 16 distinct
         // slots of the 256-byte bank row at every alignment (an XOR of the chunk with bit 3 of the pixel made it 2-way: 30 %
         // conflict cycles, profiles/r5_b_sq_summary.txt)
+        if constexpr (!N8) {
         const unsigned lane0 = ringB_lds + static_cast<unsigned>((xw + px16) * 32 + ((g & 1) << 4));
         baseN0 = lane0 + static_cast<unsigned>((g >> 1) * 32);
         baseMix = lane0 + static_cast<unsigned>((g >> 1) ? X_ROWB_N : 64);
         baseMixW = lane0 + static_cast<unsigned>((g >> 1) ? 0 : 3 * X_ROWB_N + 64);
+        }
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const float c = a.ptab[160 + 8 * (px16 >> 2) + 4 * h + (px16 & 3)];       // D'[pixel][cout]: column px16 of half h
             cinit[h] = f32x4{c, c, c, c};
         }
         // (the ring's unwritten columns feed zero-weight K slots: they must be finite.  Consumer waves only: threads 256 .. 511)
-        for (int i = tid - 256; i < X_NB * X_ROWB_N / 16; i += 256) *reinterpret_cast<i32x4*>(ringB + i * 16) = i32x4{0, 0, 0, 0};
+        for (int i = tid - 256; i < X_NB * ROWB / 16; i += 256) *reinterpret_cast<i32x4*>(ringB + i * 16) = i32x4{0, 0, 0, 0};
+    }
+    // N8: tap 4 c + g of chunk c for lane group g (taps 9..11 of chunk 2: zero weights, they read tap 8's pixel): its kernel row and
+    // the lane's column address inside a ring row
+    [[maybe_unused]] int ky8[3] = {0, 0, 0};
+    [[maybe_unused]] unsigned col8[3] = {0, 0, 0};
+    if constexpr (N8) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const int tap = min(4 * c + g, 8);
+            ky8[c] = tap / 3;
+            col8[c] = ringB_lds + static_cast<unsigned>((xw + px16 + tap % 3) * 16);
+        }
     }
     // output stores: tile k = 1024 bytes further (immediate); a lane stores while its column lies left of the wave's limit
     // for that tile: lim(k) = columns of tile k this wave owns (13 in its last tile, cut at the next wave's start / the row end)
@@ -723,8 +747,32 @@ __global__ __launch_bounds__(512, 2) void stage23x_kernel(const Stage23Args a) {
         }(std::make_integer_sequence<int, 5>{});
         hook(IC<7>{});
     };
+    // the eight-channel second conv: three four-tap chunks; the lane's three operand addresses of this step's ring phase are formed
+    // once per chain (ring row (S0 + ky) mod 4 of the lane's tap)
+    [[maybe_unused]] auto chainN8 = [&](auto S0C, auto KC, f32x4 (&acc)[2], auto&& hook) __attribute__((always_inline)) {
+        constexpr int S0 = decltype(S0C)::value, k = decltype(KC)::value;
+        unsigned ad[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) ad[c] = col8[c] + static_cast<unsigned>(((S0 + ky8[c]) & 3) * X_ROWB_8);
+        i32x4 fq[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fq[c]) : "v"(ad[c]), "n"(k * 256));
+        [&]<int... I>(std::integer_sequence<int, I...>) {
+            (([&] {
+                 asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(fq[I]) : "n"(2 - I));
+                 acc[0] = mfma16<DT>(fq[I], w3[2 * I], I == 0 ? cinit[0] : acc[0]);
+                 acc[1] = mfma16<DT>(fq[I], w3[2 * I + 1], I == 0 ? cinit[1] : acc[1]);
+                 hook(IC<2 * I + 1>{});                     // (the hooks count MFMA pairs 1 .. 7 of a nine-tap chain: two of
+                 hook(IC<2 * I + 2>{});                     //  their slices behind every pair of this one)
+             }()),
+             ...);
+        }(std::make_integer_sequence<int, 3>{});
+        hook(IC<7>{});
+    };
     auto cchain = [&](auto PC_, auto KC, f32x4 (&acc)[2], auto&& hook) __attribute__((always_inline)) {
-        if constexpr (NB)
+        if constexpr (N8)
+            chainN8(PC_, KC, acc, hook);
+        else if constexpr (NB)
             chainN(PC_, KC, acc, hook);
         else
             chain(PC_, IC<X_ROWB>{}, KC, baseB, w3, acc, hook);
@@ -956,6 +1004,24 @@ void rn_stage23x_pack_narrow(const float* w_hwio, const int* ring_cin, int dtype
                 }
 }
 
+// Eight-channel second conv (N8): frag[c][half][lane][jj] = W[tap 4 c + lane / 16][cin = ring_cin[jj]][cout(half, lane % 16)] (taps > 8: zero);
+// ring_cin[r] = the stage-2 channel at ring channel r (8 entries).  `w_hwio` is the UNpermuted [tap][cin][cout] kernel.
+void rn_stage23x_pack_narrow8(const float* w_hwio, const int* ring_cin, int dtype, unsigned short (*cvt_bf16)(float), unsigned short (*cvt_f16)(float),
+                              std::vector<unsigned short>* out) {
+    out->assign(static_cast<size_t>(6) * 64 * 8, 0);
+    for (int c = 0; c < 3; ++c)
+        for (int h = 0; h < 2; ++h)
+            for (int l = 0; l < 64; ++l)
+                for (int jj = 0; jj < 8; ++jj) {
+                    const int tap = 4 * c + (l >> 4), nn = l & 15;
+                    if (tap > 8) continue;
+                    const int cin = ring_cin[jj];
+                    const int co = 8 * (nn >> 2) + 4 * h + (nn & 3);
+                    const float v = w_hwio[(static_cast<size_t>(tap) * 32 + cin) * 32 + co];
+                    (*out)[((static_cast<size_t>(c) * 2 + h) * 64 + l) * 8 + jj] = dtype == RN_DTYPE_BF16 ? cvt_bf16(v) : cvt_f16(v);
+                }
+}
+
 int rn_stage23x_launch(int dtype, hipStream_t s, const Stage23Args& a, int n) {
     auto launch = [&](auto kern) -> int {
         static std::atomic<unsigned long long> attr_devices{0};     // per device and instantiation
@@ -969,6 +1035,10 @@ int rn_stage23x_launch(int dtype, hipStream_t s, const Stage23Args& a, int n) {
         RN_CHECK_LAUNCH();
         return RN_OK;
     };
+    if (a.producer_halves == 1 && a.narrow_b == 2) {
+        if (dtype == RN_DTYPE_BF16) return launch(stage23x_kernel<RN_DTYPE_BF16, 1, true, true>);
+        return launch(stage23x_kernel<RN_DTYPE_F16, 1, true, true>);
+    }
     if (a.producer_halves == 1 && a.narrow_b) {
         if (dtype == RN_DTYPE_BF16) return launch(stage23x_kernel<RN_DTYPE_BF16, 1, true>);
         return launch(stage23x_kernel<RN_DTYPE_F16, 1, true>);

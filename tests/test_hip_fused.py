@@ -120,7 +120,9 @@ def _same_up_to_sum_order(a, b, dtype, what, frac=1e-4, n_ulp=6):
     d = np.abs(a.astype(np.float64) - b.astype(np.float64))
     lim = n_ulp * ulp * np.maximum(np.abs(b.astype(np.float64)), 0.01 * scale)
     worst = float((d / lim).max())
-    assert n <= max(2, frac * a.size) and worst <= 1.0, (what, dtype, n, a.size, worst, np.argwhere(bad)[:4].tolist())
+    # (tensors of a few hundred elements -- s9.bn2 is 2 x 2 x 16 per image -- get a floor of 32 differing elements: every one of
+    #  them sums the whole image, a handful of one-ulp flips upstream moves more than `frac` of them)
+    assert n <= max(32 if a.size < 4096 else 2, frac * a.size) and worst <= 1.0, (what, dtype, n, a.size, worst, np.argwhere(bad)[:4].tolist())
 
 
 def _downstream_same(fused, plain, names, nb, dtype, probs_f, probs_p, ids_f, ids_p):
@@ -897,6 +899,9 @@ def test_frozen_channels_fold_against_computing_them(weights, parity_images, dty
             assert ci["stage"] == 4 and ci["channels_not_convolved"] == 16 and ci["next_stage_input_channels"] == 48, ci
             assert ci["channels_proven_constant"] == len(const4) == (26 if dtype == "bf16" else 23), (ci, len(const4))
             assert full.const_info()["stage"] == -1
+            fi = fold.frozen_info()
+            assert fi["pair_channels_not_convolved"] == 24 and fi["pair_channels_proven_frozen"] == (26 if dtype == "bf16" else 25), fi
+            assert full.frozen_info()["pair_channels_not_convolved"] == 0
             ids_a, probs_a = fold.forward_u8(ims)
             ids_b, probs_b = full.forward_u8(ims)
             np.testing.assert_array_equal(fold.tap("s1.bn", nb), full.tap("s1.bn", nb))      # (in front of the pair: the same kernel)
@@ -940,6 +945,10 @@ def test_frozen_channels_are_their_table_value_at_every_pixel(weights, parity_im
     sc2, sh2 = _bn_tables(weights, 2, 16)
     frozen = [c for c in range(32) if abs(float(sc2[c])) * 16.0 * (1.0 + 1e-6) < abs(float(sh2[c])) * 2.0 ** -25]
     assert len(frozen) == 18
+    # round 6: the pair folds by the tensor's 16-bit STORE -- a superset (the scale below half an ulp of the shift): 26 / 25 channels
+    stored_const = [c for c in range(32) if _store16(sh2[c], dtype) == _store16(np.float32(np.float32(16.0) * sc2[c] + sh2[c]), dtype)]
+    assert set(frozen) <= set(stored_const) and len(stored_const) == (26 if dtype == "bf16" else 25)
+    frozen = stored_const
     ims = parity_images[[1, 14, 30, 41, 52, 56, 60, 63]]
     for cf in (False, True):
         e = _capi.Engine(g, weights, device=0, dtype=dtype, max_batch=8, stage_launches=True, compute_frozen=cf)
@@ -948,8 +957,8 @@ def test_frozen_channels_are_their_table_value_at_every_pixel(weights, parity_im
             t = e.tap("s2.bn", 8)
             for c in range(32):
                 if c in frozen:
-                    assert (t[..., c] == _to16_rne(sh2[c], dtype)).all(), (dtype, cf, c)
-            assert sum(np.unique(t[..., c]).size > 1 for c in range(32) if c not in frozen) >= 2      # (most live channels move less than a 16-bit ulp)
+                    assert (t[..., c] == _store16(sh2[c], dtype)).all(), (dtype, cf, c)
+            assert sum(np.unique(t[..., c]).size > 1 for c in range(32) if c not in frozen) >= 2      # (the live channels move)
         finally:
             e.close()
 
@@ -991,7 +1000,7 @@ def test_frozen_channel_fold_on_other_checkpoints(weights, parity_images, case):
     elif case == "both_other_sets":
         w, want = with_gammas(weights, rng.choice(32, 17, replace=False), rng.choice(64, 40, replace=False), 3), {"pair_channels_not_convolved": 16, "residual_stage_folded": 5, "residual_stage_live_quarters": 2}
     else:
-        w, want = with_gammas(weights, range(32), range(64), 4), {"pair_channels_not_convolved": 16, "pair_channels_proven_frozen": 32, "residual_stage_folded": 5}
+        w, want = with_gammas(weights, range(32), range(64), 4), {"pair_channels_not_convolved": 24, "pair_channels_proven_frozen": 32, "residual_stage_folded": 5}
     ims = parity_images[[14, 30, 2, 52]]
     ref = c_oracle.infer(w, ims, taps=True)
     for dtype in ("bf16", "f16"):
