@@ -22,7 +22,7 @@ python3 $R/tools/hbm_traffic.py $O/${tag}_pmc_fetch_size.csv $O/${tag}_pmc_write
 cp $O/${tag}_hbm_traffic.json $R/profiles/${tag}_hbm_traffic.json
 cd $R && python3 bench.py 2>/dev/null | tail -1 > $O/${tag}_bench.json
 cd /tmp
-rm -rf /tmp/kt && rocprofv3 --kernel-trace --stats -d /tmp/kt -o kt --output-format csv -- python3 $R/bench.py --no-cpu-baseline > /tmp/kt.log 2>&1
+rm -rf /tmp/kt && rocprofv3 --kernel-trace --stats -d /tmp/kt -o kt --output-format csv -- python3 $R/bench.py --no-cpu-baseline --no-other-configs > /tmp/kt.log 2>&1
 f=$(find /tmp/kt -name "*kernel_stats.csv" | head -1); cp "$f" $O/${tag}_kernel_stats.csv
 $R/tools/pmc_run.sh $tag > $O/${tag}_sq_summary.txt 2>&1
 if [ -f $R/tools/ab/libroomnet_hip_stamps.so ]; then
