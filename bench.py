@@ -845,11 +845,20 @@ def main():
                 args.stage_launches or args.pair32 or args.compute_frozen or args.no_dither)
             if headline and not args.no_other_configs:
                 # BASELINE's other single-GPU shards, same process, parity-gated (profiles/r6_*: the same numbers from own runs)
-                others = [measure_latency(torch, eng, graph, dev, stream, args.side)]
+                # (a failure here -- a parity gate that does not hold, an allocation -- is reported in its entry; it must not take the
+                #  headline line of the same run down with it)
+                others = []
+                try:
+                    others.append(measure_latency(torch, eng, graph, dev, stream, args.side))
+                except Exception as e:                                   # noqa: BLE001
+                    others.append({"config": "batch 1, %dx%d" % (args.side, args.side), "error": "%s: %s" % (type(e).__name__, e)})
                 w224 = BundleReader(os.path.join(ROOT, "roomnet_amd", "final_model", "roomnet")).load_all()
                 for side_o, batch_o, dt_o in ((600, 64, "f16"), (224, 256, "f32")):
-                    others.append(measure_other_config(_capi, torch, lambda sd: build_graph(6, sd), w224, dev, side_o, batch_o, dt_o,
-                                                       args.warmup, min(args.steps, 100)))
+                    try:
+                        others.append(measure_other_config(_capi, torch, lambda sd: build_graph(6, sd), w224, dev, side_o, batch_o, dt_o,
+                                                           args.warmup, min(args.steps, 100)))
+                    except Exception as e:                               # noqa: BLE001
+                        others.append({"config": "%d x %dx%d %s" % (batch_o, side_o, side_o, dt_o), "error": "%s: %s" % (type(e).__name__, e)})
                 out["other_configs"] = others
             if world == 1 and not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline(weights, args.side)

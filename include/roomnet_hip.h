@@ -251,8 +251,10 @@ RN_API int rn_set_stream_null(rn_handle* h);
  * returns RN_E_STATE.  This is the per-layer
  * debug read-out the reference gets from self.layers (network.py:30, :207). */
 /* What rn_create folded on this handle (zero / -1 where nothing is): info[0] = channels of the first 32 -> 32 stage's output
- * (16-bit handles: the fused pair's on-chip tensor) that are provably constant and therefore not convolved (16-bit) / not
- * contracted by the next stage (float32 matrix-core handles) (16 or 0), info[1] = how many of its 32 channels were proven so,
+ * (16-bit handles: the fused pair's on-chip tensor) that are provably constant and therefore not contracted by the next stage
+ * (24, 16 or 0; 16-bit handles since round 6 prove it on the tensor's 16-BIT STORE -- the two ends of the pooled sum's range store
+ * the same number -- which includes every channel whose fma returns its addend in float32, the criterion of the float32
+ * matrix-core handles: 16 or 0 there), info[1] = how many of its 32 channels were proven so,
  * info[2] = index of the 64 -> 64 residual stage whose frozen first-BN channels are folded (or -1), info[3] = 16-cout
  * quarters of that stage whose convolution still runs (4 = all).  RN_FLAG_COMPUTE_FROZEN and RN_FLAG_TAPS handles report
  * nothing folded. */

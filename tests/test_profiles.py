@@ -112,3 +112,29 @@ def test_kernel_trace_agrees_with_live_event_timing():
     # the profiler's own overhead and box-to-box spread stay within 12 %
     live_ms = r["launches"][r["dominant"]]["ms"] if "launches" in r else r["kernel_ms"]
     assert abs(float(top["AverageNs"]) * 1e-6 - live_ms) <= 0.12 * live_ms
+
+
+def test_round6_line_carries_bound_frac_and_the_other_configs():
+    """Round 6: the newest default bench line states `roofline.bound_frac` -- max(physical HBM bytes / 8 TB/s,
+    matrix flops issued / 2.5 PFLOP/s) / step time, a number that cannot pass 1 -- with its terms, and `other_configs`: 64 x 600 x 600 fp16,
+    256 x 224 x 224 float32 (each parity-gated, with roofline fraction and the computing arm) and the batch-1 latency."""
+    b = json.load(open(_newest("*_bench.json")))
+    r = b["roofline"]
+    if "bound_frac" not in r:
+        pytest.skip("a bench line from before round 6")
+    t = r["bound_terms"]
+    assert 0 < r["bound_frac"] <= 1.0
+    assert abs(r["bound_frac"] - max(t["mfma_ms"], t["hbm_ms"] or 0.0) / t["step_ms"]) < 1e-9
+    assert abs(t["hbm_ms"] - r["traffic"] / 8e12 * 1e3) < 1e-9 and abs(t["step_ms"] - b["ms_per_step"]) < 1e-9
+    assert t["issued_flops_per_step"] < b["config"]["images_per_gpu"] * 4.4864e9          # (the folded channels' flops are not issued)
+    oc = {o["config"]: o for o in b["other_configs"]}
+    lat = oc["batch 1, 224x224"]
+    assert 0.05 < lat["median_ms"] < 1.0 and lat["min_ms"] <= lat["median_ms"]
+    for name, bound in (("64 x 600x600 f16", "hbm"), ("256 x 224x224 f32", "mfma")):
+        o = oc[name]
+        assert o["parity"]["checked"] and o["parity"]["ids_wrong"] == 0
+        assert o["roofline"]["bound"] == bound and 0.3 < o["roofline"]["frac"] < 1.0
+        assert 0 < o["images_per_sec_computing_them"] < o["value"]
+    f = b["folding"]
+    assert f["untimed_steps_before_computing_them"] == b["untimed_steps_before_value"]
+    assert f["constant_channels"]["stage"] == 4 and f["constant_channels"]["channels_not_convolved"] == 16
