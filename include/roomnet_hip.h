@@ -97,10 +97,11 @@ extern "C" {
 #define RN_FLAG_NO_DITHER 32u /* 16-bit handles: plain rounding everywhere -- conv weights rounded to nearest one by one and every
                                 store round-to-nearest-even, as in rounds 1-5.  Default (round 6): the weights' rounding residual
                                 is carried from tap to tap (the nine taps of a (cin, cout) pair sum to the exact sum within half an
-                                ulp), and bf16 handles store the outputs of stages 1, 3, 4, 5 through v_cvt_sr_bf16_f32 with a
+                                ulp), and bf16 handles store the outputs of stages 3, 4, 5 through v_cvt_sr_bf16_f32 with a
                                 seed that depends on the output row -- a deterministic dither, each value within one ulp of the
                                 exact one -- so that the rounding errors of a 3 x 3 window cancel instead of adding on smooth
-                                image content: max |dlogit| on the parity set 0.080 -> see profiles/r6_parity.json.  Comparison arm. */
+                                image content: max |dlogit| on the parity set 0.080 -> 0.030 (600 x 600: 0.126 -> 0.026; profiles/r6_c_parity.json).
+                                Comparison arm. */
 #define RN_FLAG_PAIR_32X32 8u /* 16-bit handles: the round-2 kernels instead of the round-3 ones (comparison
                                arm, bench.py --pair32): the cross-stage fused pair of the 32-channel block
                                (network.py:183-203: rn_stage23.hip instead of rn_stage23x.hip; equal up to the fp32 order of

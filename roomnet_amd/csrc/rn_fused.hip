@@ -713,10 +713,15 @@ int rn_fused_prepare(rn_handle* h, const rn_weights* w_in) {
             const StagePlan& s = h->stages[i];
             const bool pair_first = i + 1 < ns && s.cin == 32 && s.cout == 32 && s.pool_k == 4 && s.pool_s == 1 && s.skip_stage < 0 &&
                                     h->stages[i + 1].cin == 32 && h->stages[i + 1].cout == 32 && h->stages[i + 1].skip_stage == i - 1;
-            fs->dither_out[i] = pair_first ? 0 : 1;
+            // (the stages whose kernels carry the SR store: 32+ channels in and out, residual or stride-2 pooling -- stages 3, 4, 5;
+            //  the first block's first step stays plain: its 1.5 M values per image cost more as SR stores than their dither returned)
+            const bool srp = s.cin >= 32 && s.cout >= 32 && (s.skip_stage >= 0 || s.pool_s == 2);
+            fs->dither_out[i] = (pair_first || !srp) ? 0 : 1;
         }
     }
     // the handle's 16-bit store of a value whose rounding is not dithered (constant channels, tables)
+    const auto cv_rne = [&](float v) -> unsigned short { return h->dtype == RN_DTYPE_BF16 ? f32_to_bf16(v) : f32_to_f16(v); };
+    // ... and of the tensors whose kernels store through v_cvt_sr_bf16_f32 (the 64-channel block's two outputs)
     const auto cv_store = [&](float v) -> unsigned short {
         // (bf16: the row-blocked stage kernels store through v_cvt_sr_bf16_f32 whether the handle dithers or not)
         if (h->dtype == RN_DTYPE_BF16) return rn_sr_bf16_host(v, RN_SEED_PLAIN);
@@ -1232,7 +1237,7 @@ int rn_fused_prepare(rn_handle* h, const rn_weights* w_in) {
                     std::vector<int> frozen, live;
                     for (int c = 0; c < 32; ++c) {
                         const float sc = t1[c], sh = t1[32 + c];
-                        const bool fz = std::isfinite(sh) && cv_store(std::fmaf(0.0f, sc, sh)) == cv_store(std::fmaf(16.0f, sc, sh));
+                        const bool fz = std::isfinite(sh) && cv_rne(std::fmaf(0.0f, sc, sh)) == cv_rne(std::fmaf(16.0f, sc, sh));      // (the B ring's store: round to nearest even)
                         (fz ? frozen : live).push_back(c);
                     }
                     fs->pair_frozen = static_cast<int>(frozen.size());
@@ -1275,7 +1280,7 @@ int rn_fused_prepare(rn_handle* h, const rn_weights* w_in) {
                             double sum = 0.0;
                             for (int p = 0; p < 32; ++p) {
                                 if (live_pos(p)) continue;
-                                const double val = bk(cv_store(t1[32 + perm[p]]));      // (the channel's stored value: the kernels' own store)
+                                const double val = bk(cv_rne(t1[32 + perm[p]]));        // (the channel's stored value: the kernels' own store)
                                 for (int tap = 0; tap < 9; ++tap)
                                     sum += static_cast<double>(bk(cv(w3src[(static_cast<size_t>(tap) * 32 + perm[p]) * 32 + co]))) * val;
                             }

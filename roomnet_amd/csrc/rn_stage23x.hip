@@ -39,14 +39,11 @@ using namespace rnk;
 
 namespace {
 
-// the on-chip tensor's 16-bit store (never dithered): bf16 goes through the same instruction as every other bf16 store of the
-// row-blocked kernels, with the plain seed -- round half up -- so that the stage-launch arm (rn_stage_rw.hip) stores the same bits
+// the on-chip tensor's 16-bit store: never dithered, round to nearest even (one v_cvt_pk per pair) -- like the stage-launch arm's
+// store of the same tensor (rn_stage_rw.hip: only the instantiations whose output can be dithered use the SR conversion)
 template <int DT>
 __device__ __forceinline__ unsigned pack2p(float a, float b) {
-    if constexpr (DT == RN_DTYPE_BF16)
-        return pack2_sr_bf16(a, b, RN_SEED_PLAIN);
-    else
-        return pack2<DT>(a, b);
+    return pack2<DT>(a, b);
 }
 
 // Cache policy (aux operand of the buffer store / LDS-DMA; 2 = nt): the output rows and the residual's second read of an A row are

@@ -960,8 +960,12 @@ __global__ __launch_bounds__((RwCfg<DT, CIN, COUT, PK, PS, RES, NPT, KS, S0F, WI
         const int j = s - 1;                         // conv row of the epilogue (local)
         const bool emit = PK ? j >= 3 : true;
         const int yo = yo0 + (PK ? (j - 3) / PS : j);   // emitted output row
-        // bf16: every output value goes through v_cvt_sr_bf16_f32 -- with the row's dither seed (StageArgs::dither) or the plain one
-        // (round half up); no branch, one instruction per value (rn_stage.h)
+        // bf16 instantiations of the stages whose output can be dithered (32+ channels in and out, residual or stride-2 pooling: the
+        // last step of the 32-channel block and the two steps of the 64-channel block) store through v_cvt_sr_bf16_f32 -- with the row's
+        // dither seed (StageArgs::dither) or the plain one (round half up); no branch, one instruction per value (rn_stage.h).  Every
+        // other instantiation rounds to nearest even with one v_cvt_pk per pair: the 1.5 M values per image of the first block's first
+        // step cost the stage 0 + 1 launch 0.02 ms as SR stores (round 6: 0.198-0.21 -> 0.22-0.236 ms), more than their dither returned
+        constexpr bool SRP = DT == RN_DTYPE_BF16 && CIN >= 32 && COUT >= 32 && (RES || PS == 2);
         [[maybe_unused]] const unsigned seed_out = a.dither ? rn_dither_seed(max(yo, 0)) : RN_SEED_PLAIN;
         float yl = 0.f;
         if constexpr (RESW) {
@@ -1070,9 +1074,9 @@ __global__ __launch_bounds__((RwCfg<DT, CIN, COUT, PK, PS, RES, NPT, KS, S0F, WI
                         yv[4 * g + jj] = y;
                     }
                     if constexpr (h2 == 0)
-                        pk[g].x = DT == RN_DTYPE_BF16 ? pack2_sr_bf16(yv[4 * g], yv[4 * g + 1], seed_out) : pack2<DT>(yv[4 * g], yv[4 * g + 1]);
+                        pk[g].x = SRP ? pack2_sr_bf16(yv[4 * g], yv[4 * g + 1], seed_out) : pack2<DT>(yv[4 * g], yv[4 * g + 1]);
                     else
-                        pk[g].y = DT == RN_DTYPE_BF16 ? pack2_sr_bf16(yv[4 * g + 2], yv[4 * g + 3], seed_out) : pack2<DT>(yv[4 * g + 2], yv[4 * g + 3]);
+                        pk[g].y = SRP ? pack2_sr_bf16(yv[4 * g + 2], yv[4 * g + 3], seed_out) : pack2<DT>(yv[4 * g + 2], yv[4 * g + 3]);
                 }
             } else if constexpr (k == M_STORE) {
                 if constexpr (emit_phase) {
