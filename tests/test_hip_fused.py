@@ -473,12 +473,10 @@ def test_600_variant_vs_golden(weights, dtype, tol, record):
                 rels[name] = float(np.abs(got - want).max() / max(np.abs(want).max(), 1e-6))
             rec["stage_rel_err"] = rels
             record("parity_600", dtype, rec)
-            # (600 x 600: the late tensors are means over more rounded inputs than at 224.  bf16: a dithered store is within ONE ulp
-            #  of the exact value instead of half an ulp -- the price of errors that cancel in the next window -- so the largest
-            #  single element of the small late tensors moves more (s8.bn / s9.bn2 0.030 of abs-max on this image; plain rounding
-            #  0.022) while the logits behind them move 2.7 times less: factor 2.5)
+            # (600 x 600: the late tensors are means over more rounded inputs than at 224; bf16 is not BASELINE's dtype at this
+            #  size -- config 5 is fp16 -- and its s8.bn reaches 0.023 of abs-max on this image, dithered or not: factor 2, as in round 5)
             for name, rel in rels.items():
-                assert rel <= STAGE_TOL[dtype] * (2.5 if dtype == "bf16" else 1.5), (name, rel)
+                assert rel <= STAGE_TOL[dtype] * (2.0 if dtype == "bf16" else 1.5), (name, rel)
         else:
             record("parity_600", dtype, rec)
     finally:
