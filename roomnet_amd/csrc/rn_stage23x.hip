@@ -840,6 +840,7 @@ __global__ __launch_bounds__(512, 2) void stage23x_kernel(const Stage23Args a) {
                 const float rs = __builtin_fmaf(r_hi[i] - lo, cx.yl, lo);
                 y[4 * h + i] = __builtin_fmaf(rs, tsc2[h][i], y1);
             }
+
         }
         i32x4 d;
         if constexpr (DT == RN_DTYPE_BF16)          // (bf16: v_cvt_sr_bf16_f32 with the output row's dither seed or the plain one, rn_stage.h)
