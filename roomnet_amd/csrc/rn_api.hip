@@ -902,8 +902,8 @@ extern "C" int rn_crop_resize_batch_u8_device(rn_handle* h, const uint8_t* const
     DeviceGuard guard(h->device);
     int rc = ensure_items(h);
     if (rc != RN_OK) return rc;
-    // (the previous call's table may still be on its way up: the host copy is rewritten only behind the stream)
-    RN_HIP(hipStreamSynchronize(h->stream));
+    // (the host copy of the table may be rewritten at once: a hipMemcpyAsync out of pageable memory returns when its source has been
+    //  read into the runtime's staging buffer -- the property rn_group_forward_u8's upload threads rely on too)
     for (int i = 0; i < n; ++i) {
         if (!d_srcs[i] || heights[i] < 1 || widths[i] < 1) {
             rn_set_error("rn_crop_resize_batch_u8_device: image %d is empty", i);
