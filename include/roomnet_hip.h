@@ -68,7 +68,13 @@ extern "C" {
  *   - residual resize: the horizontal interpolation is an MFMA against the interpolation
  *     matrix in the storage type -- stage 3, and stage 5 on the row-blocked kernel: one operand, lerp
  *     fraction rounded to 2^-8 (bf16) / 2^-11 (fp16) so that both weights are exact;
- *     stage 9, and stage 5 on the round-2 kernel (RN_FLAG_PAIR_32X32): hi + lo split (~16-bit weights). */
+ *     stage 9, and stage 5 on the round-2 kernel (RN_FLAG_PAIR_32X32): hi + lo split (~16-bit weights);
+ *   - rounding (round 6, default; RN_FLAG_NO_DITHER restores plain rounding): the conv weights of stages 1-9 are converted to
+ *     the storage type with the rounding residual CARRIED from tap to tap of every (cin, cout) pair -- a weight may be one ulp
+ *     from its nearest value, the nine taps sum to the exact sum within half an ulp -- and bf16 handles store the outputs of
+ *     stages 3, 4, 5 through v_cvt_sr_bf16_f32 with a seed that depends on the output row (1/6, 3/6, 5/6 of an ulp for rows
+ *     0, 1, 2 mod 3): deterministic, each stored value within one ulp of the exact one;
+ *   - channels rn_create proves constant are not computed at all (rn_frozen_info, rn_const_info): same bits as computing them. */
 #define RN_DTYPE_F32 0      /* reference arithmetic type (TensorFlow float32)      */
 #define RN_DTYPE_BF16 1
 #define RN_DTYPE_F16 2
